@@ -1,0 +1,240 @@
+"""ctypes binding of the CPU oracle (oracle/liborc.so) + NumPy restatement of the reference's
+TetGen readers.  TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py -- never by the product package."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+c_dp = C.POINTER(C.c_double)
+c_ip = C.POINTER(C.c_int)
+
+
+class Material(C.Structure):
+    _fields_ = [("model", C.c_int), ("lam", C.c_double), ("mu", C.c_double), ("mu10", C.c_double),
+                ("mu01", C.c_double), ("kappa", C.c_double), ("eta_damp", C.c_double),
+                ("lambda_damp", C.c_double), ("rho0", C.c_double)]
+
+
+class NewtonParams(C.Structure):
+    _fields_ = [("inner_atol", C.c_double), ("inner_rtol", C.c_double), ("outer_tol", C.c_double),
+                ("rho", C.c_double), ("max_outer", C.c_int), ("max_inner", C.c_int),
+                ("time_step", C.c_double)]
+
+
+def svk(E, nu, rho0=0.0, eta=0.0, lamd=0.0):
+    """FEAT10Data.cuh:594-611"""
+    return Material(0, (E * nu) / ((1 + nu) * (1 - 2 * nu)), E / (2 * (1 + nu)), 0, 0, 0, eta, lamd, rho0)
+
+
+def svk_lame(lam, mu, rho0=0.0, eta=0.0, lamd=0.0):
+    return Material(0, lam, mu, 0, 0, 0, eta, lamd, rho0)
+
+
+def mooney_rivlin(mu10, mu01, kappa, rho0=0.0, eta=0.0, lamd=0.0):
+    """FEAT10Data.cuh:618-634"""
+    return Material(1, 0, 0, mu10, mu01, kappa, eta, lamd, rho0)
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "liborc.so")
+    src = [os.path.join(_HERE, f) for f in ("tlfea_oracle.c", "tlfea_oracle.h")]
+    if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in src):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = C.CDLL(build())
+        _LIB.orc_t10_mass_pattern.restype = C.c_int
+        _LIB.orc_solve_spd_upper.restype = C.c_int
+        _LIB.orc_solve_pcg.restype = C.c_int
+        _LIB.orc_t10_newton_step.restype = C.c_int
+    return _LIB
+
+
+def dp(a):
+    return a.ctypes.data_as(c_dp) if a is not None else None
+
+
+def ip(a):
+    return a.ctypes.data_as(c_ip)
+
+
+# ---------------------------------------------------------------- host plumbing (integer-exact)
+TETGEN_TO_STANDARD = [0, 1, 2, 3, 6, 7, 9, 5, 8, 4]  # cpu_utils.cc:619
+
+
+def read_nodes(path):
+    """ANCFCPUUtils::FEAT10_read_nodes (cpu_utils.cc:626-682): adaptive 0/1-based ids."""
+    with open(path) as f:
+        hdr = f.readline().split()
+        n, dim = int(hdr[0]), int(hdr[1])
+        assert dim == 3
+        rows = []
+        for _ in range(n):
+            parts = f.readline().split()
+            if len(parts) >= 4:
+                rows.append((int(parts[0]), float(parts[1]), float(parts[2]), float(parts[3])))
+    min_id = min(r[0] for r in rows)
+    off = 0 if min_id == 0 else 1
+    X = np.zeros((n, 3))
+    for i, x, y, z in rows:
+        if 0 <= i - off < n:
+            X[i - off] = (x, y, z)
+    return X
+
+
+def read_elements(path):
+    """ANCFCPUUtils::FEAT10_read_elements (cpu_utils.cc:684-754) incl. the TetGen mid-node remap."""
+    with open(path) as f:
+        hdr = f.readline().split()
+        m, k = int(hdr[0]), int(hdr[1])
+        assert k == 10
+        rows = []
+        for _ in range(m):
+            parts = f.readline().split()
+            if parts:
+                rows.append([int(p) for p in parts[:11]])
+    rows = np.array(rows, dtype=np.int64)
+    eoff = 0 if rows[:, 0].min() == 0 else 1
+    noff = 0 if rows[:, 1:].min() == 0 else 1
+    conn = np.zeros((m, 10), dtype=np.int32)
+    for r in rows:
+        e = r[0] - eoff
+        if 0 <= e < m:
+            conn[e] = (r[1:] - noff)[TETGEN_TO_STANDARD]
+    return conn
+
+
+def keast5():
+    qx, qy, qz, qw = (np.zeros(5) for _ in range(4))
+    lib().orc_keast5(dp(qx), dp(qy), dp(qz), dp(qw))
+    return qx, qy, qz, qw
+
+
+class T10Oracle:
+    """Host-side mirror of the GPU_FEAT10_Data call sequence on the oracle (one object = one mesh)."""
+
+    def __init__(self, X, conn, mat, fixed=None, f_ext=None):
+        self.L = lib()
+        self.N, self.E = X.shape[0], conn.shape[0]
+        self.conn = np.ascontiguousarray(conn, dtype=np.int32)
+        self.conn_cm = np.ascontiguousarray(self.conn.T)  # [10][E] == column-major E x 10
+        self.x, self.y, self.z = (np.ascontiguousarray(X[:, i], dtype=np.float64).copy() for i in range(3))
+        self.xt, self.yt, self.zt = self.x.copy(), self.y.copy(), self.z.copy()  # x12_jac (FEAT10Data.cuh:453-458)
+        self.mat = mat
+        self.qx, self.qy, self.qz, self.qw = keast5()
+        self.fixed = np.ascontiguousarray(fixed if fixed is not None else np.zeros(0), dtype=np.int32)
+        self.f_ext = np.zeros(3 * self.N) if f_ext is None else np.ascontiguousarray(f_ext, dtype=np.float64)
+        self.gradN = np.zeros((self.E, 5, 3, 10))
+        self.detJ = np.zeros((self.E, 5))
+        self.v = np.zeros(3 * self.N)
+        self.v_prev = np.zeros(3 * self.N)
+        self.lam = np.zeros(3 * len(self.fixed))
+        self.m_off = self.m_col = self.m_val = None
+
+    def calc_dndu_pre(self):
+        self.L.orc_t10_dndu_pre(self.E, ip(self.conn_cm), dp(self.x), dp(self.y), dp(self.z),
+                                dp(self.qx), dp(self.qy), dp(self.qz), dp(self.gradN), dp(self.detJ))
+
+    def gradN_a_d(self):
+        """[E,5,10,3] view (node, direction) like the NumPy prototype's grad_N."""
+        return self.gradN.transpose(0, 1, 3, 2)
+
+    def calc_mass(self):
+        off = np.zeros(self.N + 1, dtype=np.int32)
+        colp = c_ip()
+        nnz = self.L.orc_t10_mass_pattern(self.E, self.N, ip(self.conn_cm), ip(off), C.byref(colp))
+        self.m_off = off
+        self.m_col = np.ctypeslib.as_array(colp, shape=(nnz,)).copy()
+        self.L.orc_free(colp)
+        self.m_val = np.zeros(nnz)
+        self.L.orc_t10_mass_values(self.E, ip(self.conn_cm), dp(self.detJ), dp(self.qx), dp(self.qy),
+                                   dp(self.qz), dp(self.qw), C.c_double(self.mat.rho0), ip(self.m_off),
+                                   ip(self.m_col), dp(self.m_val))
+
+    def compute_p(self, v=None):
+        F, P, Fd, Pv = (np.zeros((self.E, 5, 9)) for _ in range(4))
+        self.L.orc_t10_compute_p(self.E, ip(self.conn_cm), dp(self.x), dp(self.y), dp(self.z), dp(v),
+                                 dp(self.gradN), C.byref(self.mat), dp(F), dp(P), dp(Fd), dp(Pv))
+        return F, P, Fd, Pv
+
+    def internal_force(self, v=None):
+        _, P, _, _ = self.compute_p(v)
+        f = np.zeros(3 * self.N)
+        self.L.orc_t10_internal_force(self.E, self.N, ip(self.conn_cm), dp(P), dp(self.gradN),
+                                      dp(self.detJ), dp(self.qw), dp(f))
+        return f
+
+    def element_tangents(self, want_vis=False):
+        Ke = np.zeros((self.E, 30, 30))
+        Ce = np.zeros((self.E, 30, 30)) if want_vis else None
+        for e in range(self.E):
+            self.L.orc_t10_element_tangent(e, self.E, ip(self.conn_cm), dp(self.x), dp(self.y), dp(self.z),
+                                           dp(self.gradN), dp(self.detJ), dp(self.qw), C.byref(self.mat),
+                                           dp(Ke[e]), dp(Ce[e]) if want_vis else None)
+        return Ke, Ce
+
+    def hessian_pattern(self):
+        ro = np.zeros(3 * self.N + 1, dtype=np.int32)
+        ci = np.zeros(9 * len(self.m_col), dtype=np.int32)
+        self.L.orc_hessian_pattern(self.N, ip(self.m_off), ip(self.m_col), ip(ro), ip(ci))
+        return ro, ci
+
+    def assemble_hessian(self, h, rho, nthreads=1):
+        ro, ci = self.hessian_pattern()
+        val = np.zeros(len(ci))
+        self.L.orc_t10_assemble_hessian(self.E, self.N, ip(self.conn_cm), dp(self.x), dp(self.y), dp(self.z),
+                                        dp(self.gradN), dp(self.detJ), dp(self.qw), C.byref(self.mat),
+                                        ip(self.m_off), ip(self.m_col), dp(self.m_val), ip(self.fixed),
+                                        len(self.fixed), C.c_double(h), C.c_double(rho), ip(ro), ip(ci),
+                                        dp(val), nthreads)
+        return ro, ci, val
+
+    def constraint(self):
+        c = np.zeros(3 * len(self.fixed))
+        c[0::3] = self.x[self.fixed] - self.xt[self.fixed]
+        c[1::3] = self.y[self.fixed] - self.yt[self.fixed]
+        c[2::3] = self.z[self.fixed] - self.zt[self.fixed]
+        return c
+
+    def grad_L(self, f_int, h, rho):
+        g = np.zeros(3 * self.N)
+        c = self.constraint()
+        self.L.orc_grad_L(self.N, ip(self.m_off), ip(self.m_col), dp(self.m_val), dp(self.v), dp(self.v_prev),
+                          dp(f_int), dp(self.f_ext), ip(self.fixed), len(self.fixed), dp(c), dp(self.lam),
+                          C.c_double(h), C.c_double(rho), dp(g))
+        return g
+
+    def newton_step(self, prm, solver=0, nthreads=1):
+        stats = np.zeros(4)
+        rc = self.L.orc_t10_newton_step(
+            self.E, self.N, ip(self.conn_cm), dp(self.x), dp(self.y), dp(self.z), dp(self.xt), dp(self.yt),
+            dp(self.zt), dp(self.gradN), dp(self.detJ), dp(self.qw), C.byref(self.mat), ip(self.m_off),
+            ip(self.m_col), dp(self.m_val), ip(self.fixed), len(self.fixed), dp(self.f_ext), C.byref(prm),
+            dp(self.v), dp(self.v_prev), dp(self.lam), solver, nthreads, dp(stats))
+        if rc != 0:
+            raise RuntimeError("oracle: Cholesky failed (matrix not SPD)")
+        return stats
+
+
+def solve_spd_upper(ro, ci, val, rhs):
+    sol = np.zeros_like(rhs)
+    rc = lib().orc_solve_spd_upper(len(rhs), ip(ro), ip(ci), dp(val), dp(rhs), dp(sol))
+    if rc:
+        raise RuntimeError("not SPD")
+    return sol
+
+
+def solve_pcg(ro, ci, val, rhs, rel_tol=1e-12, max_iter=20000, nthreads=1):
+    sol = np.zeros_like(rhs)
+    it = lib().orc_solve_pcg(len(rhs), ip(ro), ip(ci), dp(val), dp(rhs), dp(sol), C.c_double(rel_tol),
+                             max_iter, nthreads)
+    return sol, it
