@@ -1,0 +1,165 @@
+/* tlfea_c.h -- C-ABI of the MI355X-native Total-Lagrangian element engine (libtlfea_hip.so).
+ *
+ * This is the drop-in boundary for the T10 hot path of uwsbel/Total-Lagrangian-FEA.  The reference
+ * has no FFI: its boundary is the C++ class surface the drivers in lib_bin/ call
+ * (GPU_FEAT10_Data, SyncedNewtonSolver).  Every entry point below replaces one member function of
+ * those classes (cited as file:line, paths relative to the reference root) with a handle-based
+ * `extern "C"` function taking plain pointers and sizes.  The header-only C++ facade in
+ * total-lagrangian-fea_amd/host/ re-creates the reference class names on top of this ABI, and
+ * total-lagrangian-fea_amd/__init__.py binds it with ctypes.
+ *
+ * Conventions
+ *   - all floating point is fp64, all indices int32, zero based;
+ *   - host pointers unless the name says `_device_ptr`;
+ *   - every function returns 0 on success, non-zero on failure (tlfea_last_error() gives text);
+ *     API misuse mirrors the reference: message on stderr + early return (non-zero here);
+ *   - one handle <-> one GPU (the current HIP device at create time), default stream, blocking,
+ *     not thread-safe (as the reference: FEAT10Data.cu:291,311,332);
+ *   - ownership: the data handle owns every device buffer until tlfea_t10_destroy(); a solver
+ *     handle borrows the data handle, which must outlive it (SyncedNewton.cuh:37-46).
+ *   - layouts handed across the ABI are the reference's: connectivity column-major E x 10
+ *     (FEAT10Data.cuh:36-39), grad-N blocks 10x3 column-major per (elem,qp) (:41-45), F/P 3x3
+ *     column-major per (elem,qp) (:114-158), forces/velocities xyz-interleaved per node.
+ */
+#ifndef TLFEA_C_H
+#define TLFEA_C_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct tlfea_t10_s *tlfea_t10_t;       /* GPU_FEAT10_Data   (FEAT10Data.cuh:19)   */
+typedef struct tlfea_newton_s *tlfea_newton_t; /* SyncedNewtonSolver (SyncedNewton.cuh:35) */
+
+/* SyncedNewtonParams (SyncedNewton.cuh:29-33) -- identical field order. */
+typedef struct {
+  double inner_atol, inner_rtol, outer_tol, rho;
+  int max_outer, max_inner;
+  double time_step;
+} tlfea_newton_params;
+
+/* Linear-solve options.  The reference calls cuDSS (sparse Cholesky, SyncedNewton.cu:995-1029,
+ * 1103-1114); this engine solves the same SPD system H dv = -g with a block-Jacobi preconditioned
+ * CG on the device.  rel_tol is on ||r||/||b||. */
+typedef struct {
+  double rel_tol; /* default 1e-12 */
+  int max_iter;   /* default 20000 */
+  int check_every; /* iterations between host convergence checks (default 25) */
+} tlfea_linsolve_opts;
+
+const char *tlfea_last_error(void);
+int tlfea_version(void);
+/* number of visible HIP devices; <=0 means the product path cannot run (it never falls back to CPU) */
+int tlfea_device_count(void);
+
+/* ---- GPU_FEAT10_Data ------------------------------------------------------------------------ */
+/* ctor (FEAT10Data.cuh:377-380) + Initialize() (:382-433) */
+int tlfea_t10_create(int n_elem, int n_nodes, tlfea_t10_t *out);
+/* Destroy() (:714-779) */
+int tlfea_t10_destroy(tlfea_t10_t h);
+/* Setup(tet5pt_x,y,z,w, x12,y12,z12, element_connectivity) (:435-533); conn column-major E x 10 */
+int tlfea_t10_setup(tlfea_t10_t h, const double *qx, const double *qy, const double *qz,
+                    const double *qw, const double *x, const double *y, const double *z,
+                    const int *conn_colmajor);
+int tlfea_t10_set_density(tlfea_t10_t h, double rho0);                       /* :538-546 */
+int tlfea_t10_set_damping(tlfea_t10_t h, double eta_damp, double lambda_damp); /* :553-563 */
+int tlfea_t10_set_svk_select(tlfea_t10_t h);                                   /* SetSVK() :568-587 */
+int tlfea_t10_set_svk(tlfea_t10_t h, double E, double nu);                     /* SetSVK(E,nu) :594-611 */
+int tlfea_t10_set_mooney_rivlin(tlfea_t10_t h, double mu10, double mu01, double kappa); /* :618-634 */
+int tlfea_t10_set_external_force(tlfea_t10_t h, const double *f_ext, int n);   /* :636-646 (n must be 3N) */
+int tlfea_t10_set_nodal_fixed(tlfea_t10_t h, const int *fixed_nodes, int n_fixed);    /* FEAT10Data.cu:728-749 */
+int tlfea_t10_update_nodal_fixed(tlfea_t10_t h, const int *fixed_nodes, int n_fixed); /* FEAT10Data.cu:751-832 */
+int tlfea_t10_update_positions(tlfea_t10_t h, const double *x, const double *y, const double *z, int n);          /* :671-685 */
+int tlfea_t10_update_constraint_targets(tlfea_t10_t h, const double *x, const double *y, const double *z, int n); /* :687-701 */
+
+int tlfea_t10_calc_dndu_pre(tlfea_t10_t h);            /* CalcDnDuPre        FEAT10Data.cu:284-292 */
+int tlfea_t10_build_mass_csr_pattern(tlfea_t10_t h);   /* BuildMassCSRPattern FEAT10Data.cu:372-440 */
+int tlfea_t10_calc_mass_matrix(tlfea_t10_t h);         /* CalcMassMatrix     FEAT10Data.cu:351-370 */
+int tlfea_t10_calc_constraint_data(tlfea_t10_t h);     /* CalcConstraintData FEAT10Data.cu:335-349 */
+int tlfea_t10_convert_to_csr_constraint_jac(tlfea_t10_t h);  /* FEAT10Data.cu:501-534 */
+int tlfea_t10_convert_to_csr_constraint_jact(tlfea_t10_t h); /* FEAT10Data.cu:538-601 */
+int tlfea_t10_calc_p(tlfea_t10_t h);                   /* CalcP              FEAT10Data.cu:307-312 */
+int tlfea_t10_calc_internal_force(tlfea_t10_t h);      /* CalcInternalForce  FEAT10Data.cu:328-333 */
+
+int tlfea_t10_get_n_elem(tlfea_t10_t h);
+int tlfea_t10_get_n_coef(tlfea_t10_t h);
+int tlfea_t10_get_n_constraint(tlfea_t10_t h);
+int tlfea_t10_is_constraint_setup(tlfea_t10_t h); /* Get_Is_Constraint_Setup :785-787 */
+
+/* Retrieve*ToCPU (FEAT10Data.cu:603-726,834-839); flat arrays in the reference's device layouts */
+int tlfea_t10_mass_csr_nnz(tlfea_t10_t h, int *nnz);
+int tlfea_t10_retrieve_mass_csr(tlfea_t10_t h, int *offsets /*N+1*/, int *columns /*nnz*/, double *values /*nnz*/);
+int tlfea_t10_retrieve_internal_force(tlfea_t10_t h, double *f /*3N*/);
+int tlfea_t10_retrieve_external_force(tlfea_t10_t h, double *f /*3N*/);
+int tlfea_t10_retrieve_position(tlfea_t10_t h, double *x, double *y, double *z);
+int tlfea_t10_retrieve_p_from_f(tlfea_t10_t h, double *P /*E*5*9*/);
+int tlfea_t10_retrieve_deformation_gradient(tlfea_t10_t h, double *F /*E*5*9*/);
+int tlfea_t10_retrieve_dndu_pre(tlfea_t10_t h, double *gradN /*E*5*30*/);
+int tlfea_t10_retrieve_detj(tlfea_t10_t h, double *detJ /*E*5*/);
+int tlfea_t10_retrieve_connectivity(tlfea_t10_t h, int *conn_colmajor /*E*10*/);
+int tlfea_t10_retrieve_constraint_data(tlfea_t10_t h, double *c /*n_constraint*/);
+int tlfea_t10_retrieve_constraint_jac_csr(tlfea_t10_t h, int *offsets /*nc+1*/, int *columns /*nc*/, double *values /*nc*/);
+int tlfea_t10_retrieve_constraint_jact_csr(tlfea_t10_t h, int *offsets /*3N+1*/, int *columns /*nc*/, double *values /*nc*/);
+int tlfea_t10_write_output_vtk(tlfea_t10_t h, const char *filename); /* FEAT10Data.cu:841-877 */
+
+/* device pointers (FEAT10Data.cuh:648-666,781-783) */
+const double *tlfea_t10_x12_device_ptr(tlfea_t10_t h);
+const double *tlfea_t10_y12_device_ptr(tlfea_t10_t h);
+const double *tlfea_t10_z12_device_ptr(tlfea_t10_t h);
+double *tlfea_t10_external_force_device_ptr(tlfea_t10_t h);
+double *tlfea_t10_constraint_device_ptr(tlfea_t10_t h);
+
+/* ---- SyncedNewtonSolver --------------------------------------------------------------------- */
+int tlfea_newton_create(tlfea_t10_t data, int n_constraints, tlfea_newton_t *out); /* SyncedNewton.cuh:37-149 */
+int tlfea_newton_destroy(tlfea_newton_t s);                                        /* dtor :151-204 */
+int tlfea_newton_setup(tlfea_newton_t s);                                          /* Setup :231-245 */
+int tlfea_newton_set_parameters(tlfea_newton_t s, const tlfea_newton_params *p);   /* SetParameters :206-229 */
+int tlfea_newton_analyze_hessian_sparsity(tlfea_newton_t s);                       /* SyncedNewton.cu:546-907 */
+int tlfea_newton_set_fixed_sparsity_pattern(tlfea_newton_t s, int fixed);          /* :351-353 */
+int tlfea_newton_solve(tlfea_newton_t s);            /* Solve()/OneStepNewtonCuDSS  SyncedNewton.cu:909-1394 */
+double *tlfea_newton_velocity_guess_device_ptr(tlfea_newton_t s);                  /* :341-343 */
+/* compute_l2_norm_cublas (SyncedNewton.cu:536-544) on a device vector */
+int tlfea_newton_l2_norm(tlfea_newton_t s, const double *d_vec, int n, double *out);
+
+/* ---- engine extras (no reference counterpart; used by tests/bench/INTEGRATION) -------------- */
+int tlfea_newton_set_linsolve_opts(tlfea_newton_t s, const tlfea_linsolve_opts *o);
+int tlfea_newton_hessian_nnz(tlfea_newton_t s, int *nnz);
+/* H in the reference's DOF-level CSR (SyncedNewton.cu:163-205): rows 3N, sorted columns */
+int tlfea_newton_retrieve_hessian_csr(tlfea_newton_t s, int *row_offsets, int *col_indices, double *values);
+/* One residual evaluation at the current state: compute_p + internal force + constraints + grad L
+ * (SyncedNewton.cu:1046-1065). Returns ||g||. */
+int tlfea_newton_eval_gradient(tlfea_newton_t s, double *norm_g);
+/* One Hessian assembly at the current state (SyncedNewton.cu:1080-1099). */
+int tlfea_newton_assemble_hessian(tlfea_newton_t s);
+/* Solve H x = b for host vectors (b,x length 3N) with the current H; iterations returned. */
+int tlfea_newton_linear_solve(tlfea_newton_t s, const double *b, double *x, int *iters, double *rel_res);
+/* One full Newton iteration without the convergence test (gradient, assembly, solve, update):
+ * the unit bench.py times.  iters = PCG iterations used. */
+int tlfea_newton_iteration(tlfea_newton_t s, double *norm_g, int *iters);
+int tlfea_newton_retrieve_gradient(tlfea_newton_t s, double *g /*3N*/);
+int tlfea_newton_retrieve_velocity(tlfea_newton_t s, double *v /*3N*/);
+int tlfea_newton_set_velocity(tlfea_newton_t s, const double *v /*3N*/, const double *v_prev /*3N or NULL*/);
+int tlfea_newton_retrieve_lambda(tlfea_newton_t s, double *lam /*n_constraints*/);
+/* stats of the last tlfea_newton_solve(): [0] outer iterations, [1] Newton solves, [2] last ||g||,
+ * [3] last ||c||, [4] total PCG iterations, [5] device ms of the step (hipEvent) */
+int tlfea_newton_get_stats(tlfea_newton_t s, double *stats6);
+/* per-stage device time (ms, hipEvent on the launch stream) accumulated since the last reset:
+ * [0] residual kernel, [1] f_int gather + grad, [2] tangent blocks, [3] row assembly, [4] PCG, [5] updates */
+int tlfea_newton_get_stage_ms(tlfea_newton_t s, double *ms6, int reset);
+int tlfea_newton_set_verbose(tlfea_newton_t s, int verbose);
+/* per-stage hipEvent timing for tlfea_newton_get_stage_ms (one host sync per stage; off by default) */
+int tlfea_newton_set_profiling(tlfea_newton_t s, int on);
+
+/* Multi-GPU hook: partition-boundary exchange.  When set, the solver calls `fn(user, d_buf, n)`
+ * (device buffer of n doubles, packed interface DOFs) wherever the path needs the sum over ranks:
+ * after the f_int gather, after every SpMV, and for the 2-3 scalars of each reduction.  The Python
+ * host layer points it at torch.distributed.all_reduce (RCCL over xGMI). */
+typedef int (*tlfea_allreduce_fn)(void *user, double *d_buf, int n);
+int tlfea_newton_set_interface(tlfea_newton_t s, const int *iface_dofs, int n_iface,
+                               const double *dof_weight /*3N, 1/multiplicity*/,
+                               tlfea_allreduce_fn fn, void *user);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TLFEA_C_H */

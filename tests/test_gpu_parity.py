@@ -1,0 +1,304 @@
+"""GPU parity tests: every stage of the T10 hot path through the C-ABI (libtlfea_hip.so) against the CPU
+oracle on the same inputs.  Bit-exact for connectivity / sparsity indices; fp64 tolerances written per test
+(north_star: nodal displacement within 1e-10 relative of the CPU reference)."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import orc
+from tests.helpers import (MATERIALS, csr_to_dense, fixed_x0, load_mesh, make_gpu, make_oracle, perturbed_state,
+                           relerr, tl)
+
+pytestmark = pytest.mark.gpu
+TOL_ELEM = 1e-12   # element-level quantities, relative to the largest entry
+TOL_DISP = 1e-10   # nodal displacement after Newton steps, relative to the largest displacement
+
+
+@pytest.fixture(scope="module", params=["cube", "beam_3x2x1", "res2", "bunny"])
+def mesh(request):
+    return (request.param,) + load_mesh(request.param)
+
+
+def set_state(o, d, x):
+    o.x, o.y, o.z = (np.ascontiguousarray(x[:, i]) for i in range(3))
+    d.UpdatePositions(x[:, 0], x[:, 1], x[:, 2])
+
+
+def test_loaded_native_library():
+    assert os.path.exists(tl.LIB_PATH) and tl.device_count() >= 1
+
+
+def test_dndu_pre_and_connectivity(mesh):
+    _, X, conn = mesh
+    m = MATERIALS["svk"]
+    o, d = make_oracle(X, conn, m), make_gpu(X, conn, m)
+    assert np.array_equal(d.RetrieveConnectivityToCPU(), conn)
+    assert relerr(d.RetrieveDetJToCPU(), o.detJ) < 1e-13
+    assert relerr(d.RetrieveDnDuPreToCPU(), o.gradN_a_d()) < 1e-12
+    d.Destroy()
+
+
+def test_mass_csr(mesh):
+    _, X, conn = mesh
+    m = MATERIALS["svk"]
+    o, d = make_oracle(X, conn, m), make_gpu(X, conn, m)
+    off, col, val = d.RetrieveMassCSRToCPU()
+    assert np.array_equal(off, o.m_off) and np.array_equal(col, o.m_col)  # bit-exact pattern
+    assert relerr(val, o.m_val) < 1e-13
+    d.Destroy()
+
+
+@pytest.mark.parametrize("mat", ["svk", "mr", "neo"])
+def test_calc_p_and_internal_force(mesh, mat):
+    _, X, conn = mesh
+    m = MATERIALS[mat]
+    o, d = make_oracle(X, conn, m), make_gpu(X, conn, m)
+    x, _ = perturbed_state(X)
+    set_state(o, d, x)
+    F, P, _, _ = o.compute_p(None)
+    d.CalcP()
+    d.CalcInternalForce()
+    Fg, Pg = d.RetrieveDeformationGradientToCPU(), d.RetrievePFromFToCPU()
+    Fo = F.reshape(-1, 5, 3, 3).transpose(0, 1, 3, 2)
+    Po = P.reshape(-1, 5, 3, 3).transpose(0, 1, 3, 2)
+    assert relerr(Fg, Fo) < 1e-13
+    assert relerr(Pg, Po) < TOL_ELEM
+    f_o = o.internal_force(None)
+    f_g = d.RetrieveInternalForceToCPU()
+    assert relerr(f_g, f_o) < TOL_ELEM
+    # size-independent property: internal forces are self-equilibrated (sum_a grad N_a = 0)
+    assert np.abs(f_g.reshape(-1, 3).sum(axis=0)).max() < 1e-9 * np.abs(f_g).max()
+    d.Destroy()
+
+
+@pytest.mark.parametrize("mat", ["svk", "svk_damped", "mr_damped"])
+def test_gradient(mesh, mat):
+    """g = M(v - v_prev)/h + f_int(x, v) - f_ext + h J^T(lam + rho c)  (SyncedNewton.cu:344-407)."""
+    _, X, conn = mesh
+    m = MATERIALS[mat]
+    fixed = fixed_x0(X) if len(fixed_x0(X)) else np.array([0, 3], dtype=np.int32)
+    rng = np.random.default_rng(7)
+    f_ext = rng.normal(0, 1e3, 3 * X.shape[0])
+    o, d = make_oracle(X, conn, m, fixed, f_ext), make_gpu(X, conn, m, fixed, f_ext)
+    x, v = perturbed_state(X)
+    vp = 0.5 * v
+    set_state(o, d, x)
+    s = tl.SyncedNewtonSolver(d, d.get_n_constraint())
+    prm = tl.SyncedNewtonParams(1e-4, 1e-4, 1e-4, 1e14, 5, 10, 1e-3)
+    s.SetParameters(prm)
+    s.SetVelocity(v, vp)
+    ng = s.EvalGradient()
+    g = s.RetrieveGradientToCPU()
+    o.v, o.v_prev = v.copy(), vp.copy()
+    f_int = o.internal_force(v)
+    g_o = o.grad_L(f_int, prm.time_step, prm.rho)
+    assert relerr(g, g_o) < TOL_ELEM
+    assert abs(ng - np.linalg.norm(g_o)) / np.linalg.norm(g_o) < 1e-12
+    assert relerr(d.RetrieveConstraintDataToCPU(), o.constraint()) < 1e-13 or np.abs(o.constraint()).max() == 0
+    del s
+    d.Destroy()
+
+
+@pytest.mark.parametrize("mat", ["svk", "svk_damped", "mr", "neo", "mr_damped"])
+def test_hessian(mesh, mat):
+    """H = M/h + h K + C_vis + h^2 rho J^T J: CSR index arrays bit-exact, values to 1e-12 of max|H|."""
+    tag, X, conn = mesh
+    m = MATERIALS[mat]
+    fixed = fixed_x0(X) if len(fixed_x0(X)) else np.array([0, 3], dtype=np.int32)
+    o, d = make_oracle(X, conn, m, fixed), make_gpu(X, conn, m, fixed)
+    x, _ = perturbed_state(X)
+    set_state(o, d, x)
+    h, rho = 1e-3, 1e12
+    s = tl.SyncedNewtonSolver(d, d.get_n_constraint())
+    s.SetParameters(tl.SyncedNewtonParams(1e-4, 1e-4, 1e-4, rho, 5, 10, h))
+    s.AnalyzeHessianSparsity()
+    s.AssembleHessian()
+    ro, ci, val = s.RetrieveHessianCSRToCPU()
+    ro_o, ci_o, val_o = o.assemble_hessian(h, rho)
+    assert np.array_equal(ro, ro_o) and np.array_equal(ci, ci_o)
+    assert relerr(val, val_o) < TOL_ELEM
+    # bitwise reproducible (no atomics): assemble again and compare exactly
+    s.AssembleHessian()
+    _, _, val2 = s.RetrieveHessianCSRToCPU()
+    assert np.array_equal(val, val2)
+    if X.shape[0] <= 600:
+        H = csr_to_dense(ro, ci, val, 3 * X.shape[0])
+        assert np.max(np.abs(H - H.T)) < 1e-12 * np.abs(H).max()
+    del s
+    d.Destroy()
+
+
+@pytest.mark.parametrize("tag", ["beam_3x2x1", "res2"])
+def test_linear_solve_against_direct(tag):
+    X, conn = load_mesh(tag)
+    m = MATERIALS["svk"]
+    fixed = fixed_x0(X)
+    o, d = make_oracle(X, conn, m, fixed), make_gpu(X, conn, m, fixed)
+    x, _ = perturbed_state(X, sigma=1e-4)
+    set_state(o, d, x)
+    h, rho = 1e-3, 1e14
+    s = tl.SyncedNewtonSolver(d, d.get_n_constraint())
+    s.SetParameters(tl.SyncedNewtonParams(1e-4, 1e-4, 1e-4, rho, 5, 10, h))
+    s.SetLinSolveOpts(tl.LinSolveOpts(1e-13, 20000, 10))
+    s.AssembleHessian()
+    ro, ci, val = o.assemble_hessian(h, rho)
+    b = np.random.default_rng(3).normal(size=3 * X.shape[0])
+    x_ref = orc.solve_spd_upper(ro, ci, val, b)
+    x_gpu, iters, rel = s.LinearSolve(b)
+    assert iters > 0 and rel < 1e-12
+    assert relerr(x_gpu, x_ref) < 1e-8  # cond(H) ~ 1e8 with the rho=1e14 penalty
+    del s
+    d.Destroy()
+
+
+def _run_steps(X, conn, m, fixed, f_ext, prm, n_steps, lin=None):
+    o, d = make_oracle(X, conn, m, fixed, f_ext), make_gpu(X, conn, m, fixed, f_ext)
+    s = tl.SyncedNewtonSolver(d, d.get_n_constraint())
+    s.Setup()
+    s.SetParameters(prm)
+    s.SetLinSolveOpts(lin or tl.LinSolveOpts(1e-13, 50000, 10))
+    s.AnalyzeHessianSparsity()
+    s.SetFixedSparsityPattern(True)
+    oprm = orc.NewtonParams(prm.inner_atol, prm.inner_rtol, prm.outer_tol, prm.rho, prm.max_outer, prm.max_inner,
+                            prm.time_step)
+    out = []
+    for _ in range(n_steps):
+        s.Solve()
+        st_o = o.newton_step(oprm, solver=0)
+        st_g = s.GetStats()
+        xg = np.stack(d.RetrievePositionToCPU(), axis=1)
+        xo = np.stack([o.x, o.y, o.z], axis=1)
+        out.append((xg, xo, st_g, st_o))
+    vg = s.RetrieveVelocityToCPU()
+    lam_g = s.RetrieveLambdaToCPU()
+    del s
+    d.Destroy()
+    return out, vg, o.v.copy(), lam_g, o.lam.copy()
+
+
+def test_newton_steps_beam_vs_oracle_and_prototype(golden_dir):
+    """Prototype setup (f-form-T10-beam-newton.py:373-397): beam_3x2x1, node 19 +x 1000 N, h=1e-3, rho=1e14."""
+    g = np.load(os.path.join(golden_dir, "t10_beam_3x2x1_newton.npz"))
+    X, conn = g["X"], g["conn"]
+    m = dict(kind="svk", E=7e8, nu=0.33, rho0=2700.0, eta=0.0, lamd=0.0)
+    prm = tl.SyncedNewtonParams(1e-9, 0.0, 1e-6, float(g["rho"]), 5, 30, float(g["h"]))
+    out, vg, vo, lam_g, lam_o = _run_steps(X, conn, m, g["fixed"], g["f_ext"], prm, 3)
+    for step, (xg, xo, st_g, st_o) in enumerate(out):
+        disp = np.max(np.abs(xo - X))
+        assert np.max(np.abs(xg - xo)) / disp < TOL_DISP, (step, st_g, st_o)
+        assert st_g["outer"] == st_o[0] and st_g["newton"] == st_o[1]
+        # reference prototype (dense Cholesky, converged to round-off)
+        assert np.max(np.abs(xg - g["x_steps"][step])) / disp < 1e-8
+    assert relerr(vg, vo) < 1e-9
+    assert relerr(lam_g, lam_o) < 1e-6
+
+
+def test_newton_steps_res4_driver_parameters():
+    """test_feat10_resolution.cc flow: x=0 pinned, 5000 N over the x=3 face, params {1e-4,1e-4,1e-4,1e14,5,10,1e-3}
+    (:283-312,365); utest_feat10_cudss.cc runs 2 steps on this 936-element mesh as a smoke test."""
+    X, conn = load_mesh("res4")
+    fixed = fixed_x0(X)
+    f_ext = np.zeros(3 * X.shape[0])
+    face = np.where(np.abs(X[:, 0] - 3.0) < 1e-8)[0]
+    f_ext[3 * face] = 5000.0 / len(face)
+    prm = tl.SyncedNewtonParams(1e-4, 1e-4, 1e-4, 1e14, 5, 10, 1e-3)
+    out, *_ = _run_steps(X, conn, MATERIALS["svk"], fixed, f_ext, prm, 2)
+    for xg, xo, st_g, st_o in out:
+        disp = np.max(np.abs(xo - X))
+        assert np.max(np.abs(xg - xo)) / disp < TOL_DISP
+        assert st_g["outer"] == st_o[0] and st_g["newton"] == st_o[1]
+
+
+def test_newton_damped_neo_hookean_bunny():
+    """mesh_deform/test_feat10_bunny_newton.cc flow (0-based mesh, E=3e8 nu=0.4 rho=920, Mooney-Rivlin,
+    params {1e-4,1e-6,1e-4,1e14,5,10,1e-3}, :26-28,121-126,201) with Kelvin-Voigt damping switched on."""
+    X, conn = load_mesh("bunny")
+    zmin = X[:, 2].min()
+    fixed = np.where(X[:, 2] < zmin + 0.02 * (X[:, 2].max() - zmin))[0].astype(np.int32)
+    f_ext = np.zeros(3 * X.shape[0])
+    top = np.where(X[:, 2] > X[:, 2].max() - 0.05 * (X[:, 2].max() - zmin))[0]
+    f_ext[3 * top + 2] = -1000.0 / len(top)
+    m = dict(MATERIALS["neo"], eta=1e4, lamd=1e4)
+    prm = tl.SyncedNewtonParams(1e-4, 1e-6, 1e-4, 1e14, 5, 10, 1e-3)
+    out, *_ = _run_steps(X, conn, m, fixed, f_ext, prm, 2)
+    for xg, xo, st_g, st_o in out:
+        disp = np.max(np.abs(xo - X))
+        assert np.max(np.abs(xg - xo)) / disp < TOL_DISP
+        assert st_g["outer"] == st_o[0] and st_g["newton"] == st_o[1]
+
+
+def test_no_constraints_runs_all_outer_iterations():
+    """Without pinned nodes the outer loop has no exit test (SyncedNewton.cu:1135-1145)."""
+    X, conn = load_mesh("cube")
+    f_ext = np.zeros(3 * X.shape[0])
+    f_ext[2::3] = -10.0
+    prm = tl.SyncedNewtonParams(1e-6, 0.0, 1e-6, 1e14, 3, 10, 1e-3)
+    o, d = make_oracle(X, conn, MATERIALS["svk"], None, f_ext), make_gpu(X, conn, MATERIALS["svk"], None, f_ext)
+    s = tl.SyncedNewtonSolver(d, 0)
+    s.SetParameters(prm)
+    s.SetLinSolveOpts(tl.LinSolveOpts(1e-13, 20000, 5))
+    s.Solve()
+    st = o.newton_step(orc.NewtonParams(1e-6, 0.0, 1e-6, 1e14, 3, 10, 1e-3), solver=0)
+    assert s.GetStats()["outer"] == 3 == st[0]
+    xg = np.stack(d.RetrievePositionToCPU(), axis=1)
+    xo = np.stack([o.x, o.y, o.z], axis=1)
+    assert np.max(np.abs(xg - xo)) / np.max(np.abs(xo - X)) < TOL_DISP
+    del s
+    d.Destroy()
+
+
+def test_api_misuse_mirrors_reference():
+    X, conn = load_mesh("cube")
+    q = tl.quadrature
+    d = tl.GPU_FEAT10_Data(conn.shape[0], X.shape[0])
+    d.Initialize()
+    with pytest.raises(tl.TlfeaError):  # "must be set up before setting density" (FEAT10Data.cuh:539-543)
+        d.SetDensity(1.0)
+    d.Setup(q.tet5pt_x, q.tet5pt_y, q.tet5pt_z, q.tet5pt_weights, X[:, 0], X[:, 1], X[:, 2], conn)
+    with pytest.raises(tl.TlfeaError):  # "already set up" (:442-445)
+        d.Setup(q.tet5pt_x, q.tet5pt_y, q.tet5pt_z, q.tet5pt_weights, X[:, 0], X[:, 1], X[:, 2], conn)
+    with pytest.raises(tl.TlfeaError):  # size mismatch (:637-640)
+        d.SetExternalForce(np.zeros(5))
+    d.SetNodalFixed(np.array([0, 1], dtype=np.int32))
+    with pytest.raises(tl.TlfeaError):  # constraints already set up (FEAT10Data.cu:729-732)
+        d.SetNodalFixed(np.array([2], dtype=np.int32))
+    assert d.get_n_constraint() == 6
+    joff, jcol, jval = d.RetrieveConstraintJacobianCSRToCPU()
+    assert jcol.tolist() == [0, 1, 2, 3, 4, 5] and np.all(jval == 1.0) and joff.tolist() == list(range(7))
+    toff, tcol, _ = d.RetrieveConstraintJacobianTransposeCSRToCPU()
+    assert toff[6] == 6 and toff[-1] == 6 and tcol.tolist() == [0, 1, 2, 3, 4, 5]
+    d.Destroy()
+
+
+def test_full_size_config_b_properties():
+    """BASELINE config B (12^3 cells x 6 = 10 368 T10, neo-Hookean): size-independent properties --
+    self-equilibrated f_int, symmetric H (via H x . y == x . H y through the device SpMV-free path: direct CSR),
+    bitwise-reproducible assembly, PCG residual."""
+    X, conn = tl.mesh_utils.structured_t10_box(12, 12, 12)
+    assert conn.shape[0] == 10368 and X.shape[0] == 15625
+    fixed = np.where(X[:, 2] < 1e-12)[0].astype(np.int32)
+    d = make_gpu(X, conn, MATERIALS["neo"], fixed)
+    u = 1e-2 * np.sin(np.pi * X)
+    x = X + u + np.random.default_rng(12345).normal(0, 1e-4 / 24, X.shape)
+    d.UpdatePositions(x[:, 0], x[:, 1], x[:, 2])
+    d.CalcP()
+    d.CalcInternalForce()
+    f = d.RetrieveInternalForceToCPU()
+    assert np.abs(f.reshape(-1, 3).sum(axis=0)).max() < 1e-9 * np.abs(f).max()
+    s = tl.SyncedNewtonSolver(d, d.get_n_constraint())
+    s.SetParameters(tl.SyncedNewtonParams(1e-4, 1e-6, 1e-4, 1e14, 5, 10, 1e-3))
+    s.AssembleHessian()
+    ro, ci, val = s.RetrieveHessianCSRToCPU()
+    assert ro[-1] == len(val) == 9 * d.RetrieveMassCSRToCPU()[0][-1]
+    import scipy.sparse as sp
+    H = sp.csr_matrix((val, ci, ro), shape=(3 * X.shape[0],) * 2)
+    asym = abs(H - H.T).max()
+    assert asym < 1e-12 * abs(H).max()
+    s.AssembleHessian()
+    assert np.array_equal(val, s.RetrieveHessianCSRToCPU()[2])
+    b = np.random.default_rng(1).normal(size=3 * X.shape[0])
+    xs, iters, rel = s.LinearSolve(b)
+    assert rel < 1e-11 and np.linalg.norm(H @ xs - b) / np.linalg.norm(b) < 1e-10
+    del s
+    d.Destroy()

@@ -1,0 +1,70 @@
+"""CPU-side checks: host plumbing is integer-exact with the oracle's restatement of the reference readers,
+and the C-ABI library loads and exports every symbol include/tlfea_c.h declares (no compute calls)."""
+import importlib
+import os
+
+import numpy as np
+import pytest
+
+from oracle import orc
+from tests.helpers import MESH_FILES, MESHES, load_mesh, tl
+
+
+@pytest.mark.parametrize("tag", sorted(MESH_FILES))
+def test_readers_bit_exact(tag):
+    X, conn = load_mesh(tag)
+    Xo = orc.read_nodes(os.path.join(MESHES, MESH_FILES[tag] + ".node"))
+    co = orc.read_elements(os.path.join(MESHES, MESH_FILES[tag] + ".ele"))
+    assert conn.dtype == np.int32 and np.array_equal(conn, co)
+    assert np.array_equal(X, Xo)
+
+
+def test_remap_table():
+    t = np.arange(10) + 100
+    assert tl.mesh_utils.FEAT10_remap_tetgen_indices(t).tolist() == [100, 101, 102, 103, 106, 107, 109, 105, 108, 104]
+    with pytest.raises(ValueError):
+        tl.mesh_utils.FEAT10_remap_tetgen_indices(np.arange(9))
+
+
+def test_quadrature_tables_match_oracle():
+    qx, qy, qz, qw = orc.keast5()
+    q = tl.quadrature
+    assert np.array_equal(q.tet5pt_x, qx) and np.array_equal(q.tet5pt_y, qy) and np.array_equal(q.tet5pt_z, qz)
+    assert np.array_equal(q.tet5pt_weights, qw)
+
+
+def test_library_exports_every_declared_symbol():
+    syms = tl.exported_symbols()
+    assert len(syms) >= 60
+    lib = tl.load_library()
+    missing = [s for s in syms if not hasattr(lib, s)]
+    assert not missing, missing
+    assert lib.tlfea_version() >= 100
+
+
+def test_no_cpu_fallback_without_gpu():
+    """The product path must fail loudly without a GPU instead of computing on the CPU."""
+    if tl.device_count() > 0:
+        pytest.skip("GPU present")
+    d = tl.GPU_FEAT10_Data(6, 27)
+    with pytest.raises(tl.TlfeaError):
+        d.Initialize()
+
+
+@pytest.mark.parametrize("shape", [(1, 1, 1), (2, 3, 1), (4, 4, 4)])
+def test_structured_box_is_a_valid_t10_mesh(shape):
+    nx, ny, nz = shape
+    X, conn = tl.mesh_utils.structured_t10_box(nx, ny, nz, 3.0, 2.0, 1.0)
+    assert conn.shape == (6 * nx * ny * nz, 10) and conn.dtype == np.int32
+    assert X.shape[0] == (2 * nx + 1) * (2 * ny + 1) * (2 * nz + 1)
+    assert conn.min() == 0 and conn.max() == X.shape[0] - 1 and len(np.unique(conn)) == X.shape[0]
+    # mid-edge nodes sit at edge midpoints in the standard order
+    for k, (a, b) in enumerate(tl.mesh_utils.EDGES):
+        assert np.allclose(X[conn[:, 4 + k]], 0.5 * (X[conn[:, a]] + X[conn[:, b]]))
+    o = orc.T10Oracle(X, conn, orc.svk(7e8, 0.33, rho0=2700.0))
+    o.calc_dndu_pre()
+    assert o.detJ.min() > 0
+    qw = o.qw
+    assert abs((o.detJ * qw).sum() - 6.0) < 1e-12  # volume of the 3x2x1 box
+    o.calc_mass()
+    assert abs(o.m_val.sum() - 2700.0 * 6.0) < 1e-9  # total mass

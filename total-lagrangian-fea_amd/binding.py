@@ -1,0 +1,69 @@
+"""ctypes binding of libtlfea_hip.so -- argument/return types for every symbol in include/tlfea_c.h."""
+import ctypes as C
+import os
+import re
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtlfea_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "tlfea_c.h")
+_LIB = None
+
+c_dp = C.POINTER(C.c_double)
+c_ip = C.POINTER(C.c_int)
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int)
+
+
+class TlfeaError(RuntimeError):
+    pass
+
+
+class NewtonParams(C.Structure):  # SyncedNewtonParams (SyncedNewton.cuh:29-33)
+    _fields_ = [("inner_atol", C.c_double), ("inner_rtol", C.c_double), ("outer_tol", C.c_double),
+                ("rho", C.c_double), ("max_outer", C.c_int), ("max_inner", C.c_int), ("time_step", C.c_double)]
+
+
+class LinSolveOptsC(C.Structure):
+    _fields_ = [("rel_tol", C.c_double), ("max_iter", C.c_int), ("check_every", C.c_int)]
+
+
+def exported_symbols():
+    """Names of every function declared in include/tlfea_c.h (parsed from the header)."""
+    txt = open(HEADER_PATH).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(tlfea_[a-z0-9_]+)\s*\(", txt)) - {"tlfea_allreduce_fn"})
+
+
+def load_library():
+    """dlopen the HIP library; fails loudly when it has not been built (no CPU path exists)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise TlfeaError(f"{LIB_PATH} is missing: build it with `make -C {_HERE}` "
+                         "(or python -c 'import __graft_entry__ as g; g.build()').")
+    lib = C.CDLL(LIB_PATH)
+    lib.tlfea_last_error.restype = C.c_char_p
+    for name in ("tlfea_t10_x12_device_ptr", "tlfea_t10_y12_device_ptr", "tlfea_t10_z12_device_ptr",
+                 "tlfea_t10_external_force_device_ptr", "tlfea_t10_constraint_device_ptr",
+                 "tlfea_newton_velocity_guess_device_ptr"):
+        getattr(lib, name).restype = C.c_void_p
+        getattr(lib, name).argtypes = [C.c_void_p]
+    _LIB = lib
+    return lib
+
+
+def device_count():
+    return load_library().tlfea_device_count()
+
+
+def check(rc):
+    if rc != 0:
+        raise TlfeaError(load_library().tlfea_last_error().decode())
+
+
+def dp(a):
+    return a.ctypes.data_as(c_dp) if a is not None else None
+
+
+def ip(a):
+    return a.ctypes.data_as(c_ip) if a is not None else None

@@ -1,0 +1,763 @@
+// t10_kernels.hip -- hand-written gfx950 kernels for the 10-node tetrahedron hot path.
+//
+// What the reference does with four kernels, HBM round trips of F/P and ~4500 double atomics +
+// binary searches per element (FEAT10DataFunc.cuh:85-293,397-458,513-791) is done here as
+//
+//   residual : t10_residual_kernel   thread per element (coalesced element-fastest grad-N copy):
+//                                    F -> P (SVK | Mooney-Rivlin, + Kelvin-Voigt) -> 30 nodal force
+//                                    components, written element-major; no F/P round trip, no atomics
+//              grad_kernel           thread per node: gathers its elements' force rows, adds
+//                                    M(v-v_prev)/h - f_ext + h J^T(lam + rho c)   (SyncedNewton.cu:344-407)
+//   tangent  : t10_tangent_blocks    one element per wavefront, x / grad-N / F / F*h staged in LDS,
+//                                    lane p<55 owns the 3x3 node-pair block (i<=j) and sums its 5 QPs
+//                                    in registers (h*K + C_vis fused) -> element-major block buffer
+//              assemble_rows_kernel  one node row per wavefront: sums the contributions of the
+//                                    row's elements in LDS in a fixed order, adds M/h and
+//                                    h^2*rho*J^T J, streams the 3 CSR rows out once (no memset, no
+//                                    atomics, bitwise reproducible).
+//
+// Math follows SVK.cuh:14-55, MooneyRivlin.cuh:17-225, FEAT10Data.cu:97-278 (cited inline).
+#include "tlfea_internal.h"
+
+namespace tlfea {
+
+// ------------------------------------------------------------------------------------------------
+// small 3x3 helpers (registers only)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double det3(const double A[3][3]) {
+  return A[0][0] * (A[1][1] * A[2][2] - A[1][2] * A[2][1]) - A[0][1] * (A[1][0] * A[2][2] - A[1][2] * A[2][0]) +
+         A[0][2] * (A[1][0] * A[2][1] - A[1][1] * A[2][0]);
+}
+
+// inverse-transpose with the reference's determinant clamp (MooneyRivlin.cuh:25-43)
+__device__ __forceinline__ void inv_transpose3(const double A[3][3], double detA, double G[3][3]) {
+  const double eps = 1e-12;
+  double sd = detA;
+  if (fabs(sd) < eps) sd = (sd >= 0.0) ? eps : -eps;
+  const double id = 1.0 / sd;
+  G[0][0] = (A[1][1] * A[2][2] - A[1][2] * A[2][1]) * id;
+  G[0][1] = (A[1][2] * A[2][0] - A[1][0] * A[2][2]) * id;
+  G[0][2] = (A[1][0] * A[2][1] - A[1][1] * A[2][0]) * id;
+  G[1][0] = (A[0][2] * A[2][1] - A[0][1] * A[2][2]) * id;
+  G[1][1] = (A[0][0] * A[2][2] - A[0][2] * A[2][0]) * id;
+  G[1][2] = (A[0][1] * A[2][0] - A[0][0] * A[2][1]) * id;
+  G[2][0] = (A[0][1] * A[1][2] - A[0][2] * A[1][1]) * id;
+  G[2][1] = (A[0][2] * A[1][0] - A[0][0] * A[1][2]) * id;
+  G[2][2] = (A[0][0] * A[1][1] - A[0][1] * A[1][0]) * id;
+}
+
+// Invariants and helper matrices of compressible Mooney-Rivlin (MooneyRivlin.cuh:48-95).
+struct MRState {
+  double C[3][3], FC[3][3], FFT[3][3], G[3][3];  // G = F^-T
+  double I1, I2, J, t1, t2, t3;
+};
+
+__device__ __forceinline__ void mr_state(const double F[3][3], double mu10, double mu01, double kappa, MRState& s) {
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      double c = 0.0, b = 0.0;
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        c += F[k][i] * F[k][j];
+        b += F[i][k] * F[j][k];
+      }
+      s.C[i][j] = c;
+      s.FFT[i][j] = b;
+    }
+  s.I1 = s.C[0][0] + s.C[1][1] + s.C[2][2];
+  double trC2 = 0.0;
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int k = 0; k < 3; k++) trC2 += s.C[i][k] * s.C[k][i];
+  s.I2 = 0.5 * (s.I1 * s.I1 - trC2);
+  s.J = det3(F);
+  inv_transpose3(F, s.J, s.G);
+  const double J13 = cbrt(s.J);
+  const double Jm23 = 1.0 / (J13 * J13);
+  const double Jm43 = Jm23 * Jm23;
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      double v = 0.0;
+#pragma unroll
+      for (int k = 0; k < 3; k++) v += F[i][k] * s.C[k][j];
+      s.FC[i][j] = v;
+    }
+  s.t1 = 2.0 * mu10 * Jm23;
+  s.t2 = 2.0 * mu01 * Jm43;
+  s.t3 = kappa * (s.J - 1.0) * s.J;
+}
+
+// First Piola-Kirchhoff stress.  SVK: SVK.cuh:14-32;  MR: MooneyRivlin.cuh:45-111.
+__device__ __forceinline__ void elastic_P(const double F[3][3], const Material& mat, double P[3][3]) {
+  if (mat.model == kMooneyRivlin) {
+    MRState s;
+    mr_state(F, mat.mu10, mat.mu01, mat.kappa, s);
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+      for (int j = 0; j < 3; j++) {
+        const double term1 = F[i][j] - (s.I1 / 3.0) * s.G[i][j];
+        const double term2 = s.I1 * F[i][j] - s.FC[i][j] - (2.0 * s.I2 / 3.0) * s.G[i][j];
+        P[i][j] = s.t1 * term1 + s.t2 * term2 + s.t3 * s.G[i][j];
+      }
+  } else {
+    double FFt[3][3], trFtF = 0.0;
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+      for (int j = 0; j < 3; j++) {
+        double b = 0.0;
+#pragma unroll
+        for (int k = 0; k < 3; k++) b += F[i][k] * F[j][k];
+        FFt[i][j] = b;
+        trFtF += F[i][j] * F[i][j];
+      }
+    const double lf = mat.lambda * (0.5 * trFtF - 1.5);
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+      for (int j = 0; j < 3; j++) {
+        double fftf = 0.0;
+#pragma unroll
+        for (int k = 0; k < 3; k++) fftf += FFt[i][k] * F[k][j];
+        P[i][j] = lf * F[i][j] + mat.mu * (fftf - F[i][j]);
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// reference gradients: dn_du_pre_kernel (FEAT10Data.cu:97-204), thread per (element, qp)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void solve3(const double A[3][3], const double b[3], double x[3]) {
+  // partial-pivot Gaussian elimination, zero solution if |pivot| < 1e-14 (FEAT10DataFunc.cuh:30-83)
+  double m[3][4];
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+#pragma unroll
+    for (int j = 0; j < 3; j++) m[i][j] = A[i][j];
+    m[i][3] = b[i];
+  }
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    int piv = k;
+    double best = fabs(m[k][k]);
+#pragma unroll
+    for (int i = k + 1; i < 3; i++)
+      if (fabs(m[i][k]) > best) {
+        best = fabs(m[i][k]);
+        piv = i;
+      }
+#pragma unroll
+    for (int i = k + 1; i < 3; i++)
+      if (piv == i) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const double t = m[k][j];
+          m[k][j] = m[i][j];
+          m[i][j] = t;
+        }
+      }
+    if (fabs(m[k][k]) < 1e-14) {
+      x[0] = x[1] = x[2] = 0.0;
+      return;
+    }
+#pragma unroll
+    for (int i = k + 1; i < 3; i++) {
+      const double f = m[i][k] / m[k][k];
+#pragma unroll
+      for (int j = k; j < 4; j++) m[i][j] -= f * m[k][j];
+    }
+  }
+  x[2] = m[2][3] / m[2][2];
+  x[1] = (m[1][3] - m[1][2] * x[2]) / m[1][1];
+  x[0] = (m[0][3] - m[0][2] * x[2] - m[0][1] * x[1]) / m[0][0];
+}
+
+__global__ void dndu_pre_kernel(int E, int Epad, const int* __restrict__ conn, const double* __restrict__ x,
+                                const double* __restrict__ y, const double* __restrict__ z,
+                                const double* __restrict__ qx, const double* __restrict__ qy,
+                                const double* __restrict__ qz, double* __restrict__ gradN,
+                                double* __restrict__ gradN_t, double* __restrict__ detJ) {
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int e = tid / kNQ, q = tid % kNQ;
+  if (e >= E) return;
+  const double L[4] = {1.0 - qx[q] - qy[q] - qz[q], qx[q], qy[q], qz[q]};
+  const double dL[4][3] = {{-1, -1, -1}, {1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+  const int edges[6][2] = {{0, 1}, {1, 2}, {0, 2}, {0, 3}, {1, 3}, {2, 3}};  // FEAT10Data.cu:143
+  double dN[kNN][3];
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int d = 0; d < 3; d++) dN[i][d] = (4.0 * L[i] - 1.0) * dL[i][d];
+#pragma unroll
+  for (int k = 0; k < 6; k++)
+#pragma unroll
+    for (int d = 0; d < 3; d++)
+      dN[k + 4][d] = 4.0 * (L[edges[k][0]] * dL[edges[k][1]][d] + L[edges[k][1]] * dL[edges[k][0]][d]);
+  double Jm[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+#pragma unroll
+  for (int a = 0; a < kNN; a++) {
+    const int g = conn[a * E + e];
+    const double X[3] = {x[g], y[g], z[g]};
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+      for (int j = 0; j < 3; j++) Jm[i][j] += X[i] * dN[a][j];
+  }
+  detJ[e * kNQ + q] = det3(Jm);
+  double JT[3][3];
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) JT[i][j] = Jm[j][i];
+  double* g_ref = gradN + ((size_t)e * kNQ + q) * 30;
+#pragma unroll
+  for (int a = 0; a < kNN; a++) {
+    double ga[3];
+    solve3(JT, dN[a], ga);
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+      g_ref[a + 10 * d] = ga[d];
+      gradN_t[((size_t)(q * 3 + d) * kNN + a) * Epad + e] = ga[d];
+    }
+  }
+}
+
+void launch_dndu_pre(hipStream_t s, int E, int Epad, const int* conn, const double* x, const double* y,
+                     const double* z, const double* qx, const double* qy, const double* qz, double* gradN,
+                     double* gradN_t, double* detJ) {
+  const int total = E * kNQ;
+  hipLaunchKernelGGL(dndu_pre_kernel, dim3((total + 127) / 128), dim3(128), 0, s, E, Epad, conn, x, y, z, qx, qy,
+                     qz, gradN, gradN_t, detJ);
+}
+
+// ------------------------------------------------------------------------------------------------
+// residual: fused compute_p + compute_internal_force (FEAT10DataFunc.cuh:85-293,397-458)
+// thread per element; fbuf[e][a][d] = sum_q (P_q grad N_a) detJ_q w_q
+// ------------------------------------------------------------------------------------------------
+template <bool STORE>
+__global__ __launch_bounds__(128) void t10_residual_kernel(T10View m, Material mat, const double* __restrict__ v,
+                                                          double* __restrict__ fbuf, double* __restrict__ Fo,
+                                                          double* __restrict__ Po, double* __restrict__ Fdo,
+                                                          double* __restrict__ Pvo) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= m.E) return;
+  const bool damp = (v != nullptr) && (mat.eta != 0.0 || mat.lamd != 0.0);  // FEAT10DataFunc.cuh:137
+  int gn[kNN];
+  double xn[kNN][3];
+#pragma unroll
+  for (int a = 0; a < kNN; a++) {
+    gn[a] = m.conn[a * m.E + e];
+    xn[a][0] = m.x[gn[a]];
+    xn[a][1] = m.y[gn[a]];
+    xn[a][2] = m.z[gn[a]];
+  }
+  double f[kNN][3];
+#pragma unroll
+  for (int a = 0; a < kNN; a++) f[a][0] = f[a][1] = f[a][2] = 0.0;
+
+#pragma unroll 1
+  for (int q = 0; q < kNQ; q++) {
+    double hq[kNN][3];
+#pragma unroll
+    for (int d = 0; d < 3; d++)
+#pragma unroll
+      for (int a = 0; a < kNN; a++) hq[a][d] = m.gradN_t[((size_t)(q * 3 + d) * kNN + a) * m.Epad + e];
+    double F[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+#pragma unroll
+    for (int a = 0; a < kNN; a++)
+#pragma unroll
+      for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) F[i][j] += xn[a][i] * hq[a][j];
+    double P[3][3];
+    elastic_P(F, mat, P);
+    double Fd[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, Pv[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+    if (damp) {
+      // Fdot = sum v_a (x) h_a ; Edot = sym(Fdot^T F) ; S = 2 eta Edot + lamd tr(Edot) I ; P_vis = F S
+#pragma unroll
+      for (int a = 0; a < kNN; a++) {
+        const double va[3] = {v[3 * gn[a] + 0], v[3 * gn[a] + 1], v[3 * gn[a] + 2]};
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+          for (int j = 0; j < 3; j++) Fd[i][j] += va[i] * hq[a][j];
+      }
+      double Ed[3][3];
+#pragma unroll
+      for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+          double a1 = 0.0, a2 = 0.0;
+#pragma unroll
+          for (int k = 0; k < 3; k++) {
+            a1 += Fd[k][i] * F[k][j];
+            a2 += F[k][i] * Fd[k][j];
+          }
+          Ed[i][j] = 0.5 * (a1 + a2);
+        }
+      const double trEd = Ed[0][0] + Ed[1][1] + Ed[2][2];
+      double S[3][3];
+#pragma unroll
+      for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) S[i][j] = 2.0 * mat.eta * Ed[i][j] + (i == j ? mat.lamd * trEd : 0.0);
+#pragma unroll
+      for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+          double s = 0.0;
+#pragma unroll
+          for (int k = 0; k < 3; k++) s += F[i][k] * S[k][j];
+          Pv[i][j] = s;
+          P[i][j] += s;
+        }
+    }
+    if (STORE) {  // CalcP keeps the reference's F/P buffers (col-major 3x3 per (e,q)) for Retrieve*
+      const size_t o = ((size_t)e * kNQ + q) * 9;
+#pragma unroll
+      for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+          Fo[o + i + 3 * j] = F[i][j];
+          Po[o + i + 3 * j] = P[i][j];
+          Fdo[o + i + 3 * j] = Fd[i][j];
+          Pvo[o + i + 3 * j] = Pv[i][j];
+        }
+    }
+    const double dV = m.detJ[e * kNQ + q] * m.qw[q];
+#pragma unroll
+    for (int a = 0; a < kNN; a++)
+#pragma unroll
+      for (int i = 0; i < 3; i++) {
+        const double c = P[i][0] * hq[a][0] + P[i][1] * hq[a][1] + P[i][2] * hq[a][2];
+        f[a][i] += c * dV;
+      }
+  }
+  double* out = fbuf + (size_t)e * 30;
+#pragma unroll
+  for (int a = 0; a < kNN; a++)
+#pragma unroll
+    for (int i = 0; i < 3; i++) out[a * 3 + i] = f[a][i];
+}
+
+void launch_residual(hipStream_t s, const T10View& m, const Material& mat, const double* v, double* fbuf, double* F,
+                     double* P, double* Fdot, double* Pvis) {
+  const dim3 grid((m.E + 127) / 128), block(128);
+  if (F)
+    hipLaunchKernelGGL(t10_residual_kernel<true>, grid, block, 0, s, m, mat, v, fbuf, F, P, Fdot, Pvis);
+  else
+    hipLaunchKernelGGL(t10_residual_kernel<false>, grid, block, 0, s, m, mat, v, fbuf, nullptr, nullptr, nullptr,
+                       nullptr);
+}
+
+// f_int[3i+d] = sum over the node's elements of their force rows (fixed order: ascending element id)
+__global__ void fint_gather_kernel(int N, Incidence inc, const double* __restrict__ fbuf,
+                                   double* __restrict__ f_int) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  double f0 = 0.0, f1 = 0.0, f2 = 0.0;
+  for (int k = inc.n2e_off[i]; k < inc.n2e_off[i + 1]; k++) {
+    const double* r = fbuf + (size_t)inc.n2e[k] * 3;  // (e*10+il)*3 == e*30 + il*3
+    f0 += r[0];
+    f1 += r[1];
+    f2 += r[2];
+  }
+  f_int[3 * i + 0] = f0;
+  f_int[3 * i + 1] = f1;
+  f_int[3 * i + 2] = f2;
+}
+
+void launch_fint_gather(hipStream_t s, int N, const Incidence& inc, const double* fbuf, double* f_int) {
+  hipLaunchKernelGGL(fint_gather_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, inc, fbuf, f_int);
+}
+
+// constraint values c = x[fixed] - target (FEAT10DataFunc.cuh:468-483)
+__global__ void constraint_kernel(int n_fixed, const int* __restrict__ fixed, const double* __restrict__ x,
+                                  const double* __restrict__ y, const double* __restrict__ z,
+                                  const double* __restrict__ xt, const double* __restrict__ yt,
+                                  const double* __restrict__ zt, double* __restrict__ c) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n_fixed) return;
+  const int n = fixed[k];
+  c[3 * k + 0] = x[n] - xt[n];
+  c[3 * k + 1] = y[n] - yt[n];
+  c[3 * k + 2] = z[n] - zt[n];
+}
+
+void launch_constraint(hipStream_t s, int n_fixed, const int* fixed_nodes, const double* x, const double* y,
+                       const double* z, const double* xt, const double* yt, const double* zt, double* cons) {
+  if (n_fixed <= 0) return;
+  hipLaunchKernelGGL(constraint_kernel, dim3((n_fixed + 255) / 256), dim3(256), 0, s, n_fixed, fixed_nodes, x, y, z,
+                     xt, yt, zt, cons);
+}
+
+// Fused: f_int gather + constraints + grad L (SyncedNewton.cu:344-407), thread per node.
+__global__ void grad_kernel(int N, Incidence inc, const double* __restrict__ fbuf, const double* __restrict__ mval,
+                            const double* __restrict__ v, const double* __restrict__ vprev,
+                            const double* __restrict__ f_ext, const double* __restrict__ x,
+                            const double* __restrict__ y, const double* __restrict__ z,
+                            const double* __restrict__ xt, const double* __restrict__ yt,
+                            const double* __restrict__ zt, const int* __restrict__ fixed_slot,
+                            const double* __restrict__ lam, double h, double rho, double* __restrict__ f_int,
+                            double* __restrict__ cons, double* __restrict__ g) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  double f[3] = {0.0, 0.0, 0.0};
+  for (int k = inc.n2e_off[i]; k < inc.n2e_off[i + 1]; k++) {
+    const double* r = fbuf + (size_t)inc.n2e[k] * 3;
+    f[0] += r[0];
+    f[1] += r[1];
+    f[2] += r[2];
+  }
+  const double inv_h = 1.0 / h;
+  double res[3] = {0.0, 0.0, 0.0};
+  for (int k = inc.off[i]; k < inc.off[i + 1]; k++) {
+    const int c = inc.cols[k];
+    const double mij = mval[k];
+#pragma unroll
+    for (int d = 0; d < 3; d++) res[d] += mij * (v[3 * c + d] - vprev[3 * c + d]) * inv_h;
+  }
+  const int slot = fixed_slot ? fixed_slot[i] : -1;
+  double cv[3] = {0, 0, 0};
+  if (slot >= 0) {
+    cv[0] = x[i] - xt[i];
+    cv[1] = y[i] - yt[i];
+    cv[2] = z[i] - zt[i];
+  }
+#pragma unroll
+  for (int d = 0; d < 3; d++) {
+    f_int[3 * i + d] = f[d];
+    double r = res[d] + f[d] - f_ext[3 * i + d];
+    if (slot >= 0) {
+      cons[3 * slot + d] = cv[d];
+      r += h * (lam[3 * slot + d] + rho * cv[d]);
+    }
+    g[3 * i + d] = r;
+  }
+}
+
+void launch_grad(hipStream_t s, int N, const Incidence& inc, const double* fbuf, const double* mval, const double* v,
+                 const double* vprev, const double* f_ext, const double* x, const double* y, const double* z,
+                 const double* xt, const double* yt, const double* zt, const int* fixed_slot, const double* lam,
+                 double h, double rho, double* f_int, double* cons, double* g) {
+  hipLaunchKernelGGL(grad_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, inc, fbuf, mval, v, vprev, f_ext, x, y,
+                     z, xt, yt, zt, fixed_slot, lam, h, rho, f_int, cons, g);
+}
+
+// ------------------------------------------------------------------------------------------------
+// tangent: one element per wavefront, lane p < 55 owns node pair (i <= j)
+// ------------------------------------------------------------------------------------------------
+__device__ __constant__ unsigned char kPairI[kNPair] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 1, 1,
+                                                        2, 2, 2, 2, 2, 2, 2, 2, 3, 3, 3, 3, 3, 3, 3, 4, 4, 4, 4,
+                                                        4, 4, 5, 5, 5, 5, 5, 6, 6, 6, 6, 7, 7, 7, 8, 8, 9};
+__device__ __constant__ unsigned char kPairJ[kNPair] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 1, 2, 3, 4, 5, 6, 7, 8, 9,
+                                                        2, 3, 4, 5, 6, 7, 8, 9, 3, 4, 5, 6, 7, 8, 9, 4, 5, 6, 7,
+                                                        8, 9, 5, 6, 7, 8, 9, 6, 7, 8, 9, 7, 8, 9, 8, 9, 9};
+__host__ __device__ __forceinline__ int pair_index(int i, int j) { return i * 10 - (i * (i - 1)) / 2 + (j - i); }
+
+// LDS map (doubles).  One 64-thread workgroup == one wavefront, so __syncthreads() is a wave-local
+// fence; the staging area for the coalesced write-out aliases the whole array after the last read.
+constexpr int kOffX = 0;      // xs[3][10]
+constexpr int kOffH = 32;     // hs[5][3][10]   (same order as the global reference layout)
+constexpr int kOffF = 184;    // Fs[5][9]
+constexpr int kOffU = 232;    // SVK: Fh[5][10][3] | FFT[5][6] | sc[5][4] ; MR: st[5][64] | At[5][81]
+constexpr int kLdsDoubles = 232 + 5 * 64 + 5 * 81;  // 957
+
+template <int MODEL>
+__global__ __launch_bounds__(64) void t10_tangent_blocks_kernel(T10View m, Material mat, double h,
+                                                               double* __restrict__ Kbuf) {
+  __shared__ double lds[kLdsDoubles];
+  double* xs = lds + kOffX;
+  double* hs = lds + kOffH;
+  double* Fs = lds + kOffF;
+  double* U = lds + kOffU;
+  const int e = blockIdx.x;
+  const int lane = threadIdx.x;
+  const int E = m.E;
+
+  if (lane < 30) {
+    const int a = lane % 10, d = lane / 10;
+    const int g = m.conn[a * E + e];
+    const double* src = (d == 0) ? m.x : ((d == 1) ? m.y : m.z);
+    xs[d * 10 + a] = src[g];
+  }
+  {
+    const double* gsrc = m.gradN + (size_t)e * 150;
+    hs[lane] = gsrc[lane];
+    hs[lane + 64] = gsrc[lane + 64];
+    if (lane < 22) hs[lane + 128] = gsrc[lane + 128];
+  }
+  __syncthreads();
+  if (lane < 45) {  // F_q[r][c] = sum_a x_a[r] h_a^q[c]
+    const int q = lane / 9, r = (lane % 9) / 3, c = lane % 3;
+    double s = 0.0;
+#pragma unroll
+    for (int a = 0; a < kNN; a++) s += xs[r * 10 + a] * hs[q * 30 + c * 10 + a];
+    Fs[lane] = s;
+  }
+  __syncthreads();
+
+  double acc[9];
+#pragma unroll
+  for (int k = 0; k < 9; k++) acc[k] = 0.0;
+  const int pi = (lane < kNPair) ? kPairI[lane] : 0;
+  const int pj = (lane < kNPair) ? kPairJ[lane] : 0;
+
+  if (MODEL == kSVK) {
+    double* Fh = U;         // [5][10][3]
+    double* FFT = U + 150;  // [5][6]  (00,01,02,11,12,22)
+    double* sc = U + 180;   // [5][4]
+    for (int t = lane; t < 150; t += 64) {  // Fh_a^q[r] = sum_c F_q[r][c] h_a^q[c]
+      const int q = t / 30, a = (t % 30) / 3, r = t % 3;
+      Fh[t] = Fs[q * 9 + r * 3 + 0] * hs[q * 30 + 0 + a] + Fs[q * 9 + r * 3 + 1] * hs[q * 30 + 10 + a] +
+              Fs[q * 9 + r * 3 + 2] * hs[q * 30 + 20 + a];
+    }
+    if (lane < 30) {
+      const int q = lane / 6, k = lane % 6;
+      const int i = (k < 3) ? 0 : ((k < 5) ? 1 : 2);
+      const int j = (k < 3) ? k : ((k < 5) ? k - 2 : 2);
+      const double* F = Fs + q * 9;
+      FFT[lane] = F[i * 3 + 0] * F[j * 3 + 0] + F[i * 3 + 1] * F[j * 3 + 1] + F[i * 3 + 2] * F[j * 3 + 2];
+    } else if (lane >= 32 && lane < 37) {
+      const int q = lane - 32;
+      const double* F = Fs + q * 9;
+      double trC = 0.0;
+#pragma unroll
+      for (int k = 0; k < 9; k++) trC += F[k] * F[k];
+      const double trE = 0.5 * (trC - 3.0);
+      const double dV = m.detJ[e * kNQ + q] * m.qw[q];
+      // h*K (SVK.cuh:35-55) + C_vis (FEAT10DataFunc.cuh:695-762) share their rank-1 structure:
+      sc[q * 4 + 0] = dV * (h * mat.lambda + mat.lamd);           // * Fh_i (x) Fh_j
+      sc[q * 4 + 1] = dV * (h * mat.mu + mat.eta);                // * Fh_j (x) Fh_i  and  * (h_i.h_j) FF^T
+      sc[q * 4 + 2] = dV * h * (mat.lambda * trE - mat.mu);       // * (h_i.h_j) I
+      sc[q * 4 + 3] = dV * h * mat.mu;                            // * (Fh_i.Fh_j) I
+    }
+    __syncthreads();
+    if (lane < kNPair) {
+#pragma unroll 1
+      for (int q = 0; q < kNQ; q++) {
+        const double* hq = hs + q * 30;
+        const double hi0 = hq[pi], hi1 = hq[10 + pi], hi2 = hq[20 + pi];
+        const double hj0 = hq[pj], hj1 = hq[10 + pj], hj2 = hq[20 + pj];
+        const double* fi = Fh + q * 30 + pi * 3;
+        const double* fj = Fh + q * 30 + pj * 3;
+        const double fi0 = fi[0], fi1 = fi[1], fi2 = fi[2];
+        const double fj0 = fj[0], fj1 = fj[1], fj2 = fj[2];
+        const double A1 = sc[q * 4 + 0], B1 = sc[q * 4 + 1], C0 = sc[q * 4 + 2], C1 = sc[q * 4 + 3];
+        const double s = hi0 * hj0 + hi1 * hj1 + hi2 * hj2;
+        const double t = fi0 * fj0 + fi1 * fj1 + fi2 * fj2;
+        const double bs = B1 * s;
+        const double cd = C0 * s + C1 * t;
+        const double u0 = A1 * fi0, u1 = A1 * fi1, u2 = A1 * fi2;
+        const double w0 = B1 * fj0, w1 = B1 * fj1, w2 = B1 * fj2;
+        const double* T = FFT + q * 6;
+        acc[0] += u0 * fj0 + w0 * fi0 + bs * T[0] + cd;
+        acc[1] += u0 * fj1 + w0 * fi1 + bs * T[1];
+        acc[2] += u0 * fj2 + w0 * fi2 + bs * T[2];
+        acc[3] += u1 * fj0 + w1 * fi0 + bs * T[1];
+        acc[4] += u1 * fj1 + w1 * fi1 + bs * T[3] + cd;
+        acc[5] += u1 * fj2 + w1 * fi2 + bs * T[4];
+        acc[6] += u2 * fj0 + w2 * fi0 + bs * T[2];
+        acc[7] += u2 * fj1 + w2 * fi1 + bs * T[4];
+        acc[8] += u2 * fj2 + w2 * fi2 + bs * T[5] + cd;
+      }
+    }
+  } else {
+    // Mooney-Rivlin: per-qp state on lanes 0..4, then the 5x81 entries of
+    //   At = dV * ( h * dP/dF  +  A_vis )         (MooneyRivlin.cuh:113-225, FEAT10DataFunc.cuh:695-762)
+    // spread over the wave, then block(i,j)[d][e] = sum_JL At[d][J][e][L] h_i[J] h_j[L].
+    double* st = U;            // [5][64]: C 0, FC 9, FFT 18, G 27, T1 36, T2 45, scalars 54..
+    double* At = U + 5 * 64;   // [5][81]
+    if (lane < kNQ) {
+      const int q = lane;
+      double F[3][3];
+#pragma unroll
+      for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) F[i][j] = Fs[q * 9 + i * 3 + j];
+      MRState s;
+      mr_state(F, mat.mu10, mat.mu01, mat.kappa, s);
+      double* o = st + q * 64;
+#pragma unroll
+      for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+          o[0 + i * 3 + j] = s.C[i][j];
+          o[9 + i * 3 + j] = s.FC[i][j];
+          o[18 + i * 3 + j] = s.FFT[i][j];
+          o[27 + i * 3 + j] = s.G[i][j];
+          o[36 + i * 3 + j] = F[i][j] - (s.I1 / 3.0) * s.G[i][j];
+          o[45 + i * 3 + j] = s.I1 * F[i][j] - s.FC[i][j] - (2.0 * s.I2 / 3.0) * s.G[i][j];
+        }
+      o[54] = s.I1;
+      o[55] = s.I2;
+      o[56] = s.t1;
+      o[57] = s.t2;
+      o[58] = s.t3;
+      o[59] = mat.kappa * (2.0 * s.J - 1.0) * s.J;
+      o[60] = m.detJ[e * kNQ + q] * m.qw[q];
+    }
+    __syncthreads();
+    for (int n = lane; n < kNQ * 81; n += 64) {
+      const int q = n / 81, r = n % 81;
+      const int i = r / 27, j = (r / 9) % 3, k = (r / 3) % 3, l = r % 3;
+      const double* o = st + q * 64;
+      const double* F = Fs + q * 9;
+      const double* C = o;
+      const double* FC = o + 9;
+      const double* FFT = o + 18;
+      const double* G = o + 27;
+      const double* T1 = o + 36;
+      const double* T2 = o + 45;
+      const double I1 = o[54], I2 = o[55], t1 = o[56], t2 = o[57], t3 = o[58], k3 = o[59], dV = o[60];
+      const double dik = (i == k) ? 1.0 : 0.0, djl = (j == l) ? 1.0 : 0.0;
+      const double Gkl = G[k * 3 + l], Gij = G[i * 3 + j], GilGkj = G[i * 3 + l] * G[k * 3 + j];
+      const double dt1 = (-2.0 / 3.0) * t1 * Gkl;
+      const double dt2 = (-4.0 / 3.0) * t2 * Gkl;
+      const double dt3 = k3 * Gkl;
+      const double dT1 = dik * djl - (2.0 / 3.0) * F[k * 3 + l] * Gij + (I1 / 3.0) * GilGkj;
+      const double dT2 = 2.0 * F[k * 3 + l] * F[i * 3 + j] + I1 * dik * djl -
+                         (dik * C[l * 3 + j] + F[i * 3 + l] * F[k * 3 + j] + djl * FFT[i * 3 + k]) -
+                         (4.0 / 3.0) * (I1 * F[k * 3 + l] - FC[k * 3 + l]) * Gij + (2.0 * I2 / 3.0) * GilGkj;
+      const double Ael = dt1 * T1[i * 3 + j] + t1 * dT1 + dt2 * T2[i * 3 + j] + t2 * dT2 + dt3 * Gij - t3 * GilGkj;
+      // viscous: eta F[d][L]F[e][J] + eta FF^T[d][e] d_JL + lamd F[d][J]F[e][L]   (d=i, J=j, e=k, L=l)
+      const double Avis = mat.eta * (F[i * 3 + l] * F[k * 3 + j] + FFT[i * 3 + k] * djl) +
+                          mat.lamd * F[i * 3 + j] * F[k * 3 + l];
+      At[n] = dV * (h * Ael + Avis);
+    }
+    __syncthreads();
+    if (lane < kNPair) {
+#pragma unroll 1
+      for (int q = 0; q < kNQ; q++) {
+        const double* hq = hs + q * 30;
+        const double hi[3] = {hq[pi], hq[10 + pi], hq[20 + pi]};
+        const double hj[3] = {hq[pj], hq[10 + pj], hq[20 + pj]};
+        const double* A = At + q * 81;
+#pragma unroll
+        for (int d = 0; d < 3; d++)
+#pragma unroll
+          for (int ee = 0; ee < 3; ee++) {
+            double s = 0.0;
+#pragma unroll
+            for (int J = 0; J < 3; J++) {
+              const double* a = A + ((d * 3 + J) * 3 + ee) * 3;
+              s += hi[J] * (a[0] * hj[0] + a[1] * hj[1] + a[2] * hj[2]);
+            }
+            acc[d * 3 + ee] += s;
+          }
+      }
+    }
+  }
+  __syncthreads();  // everyone is done reading the staged inputs: reuse LDS as the write-out stage
+  if (lane < kNPair) {
+#pragma unroll
+    for (int k = 0; k < 9; k++) lds[lane * 9 + k] = acc[k];
+  }
+  __syncthreads();
+  double* out = Kbuf + (size_t)e * (kNPair * 9);
+  for (int t = lane; t < kNPair * 9; t += 64) out[t] = lds[t];
+}
+
+void launch_tangent_blocks(hipStream_t s, const T10View& m, const Material& mat, double h, double* Kbuf) {
+  if (mat.model == kMooneyRivlin)
+    hipLaunchKernelGGL(t10_tangent_blocks_kernel<kMooneyRivlin>, dim3(m.E), dim3(64), 0, s, m, mat, h, Kbuf);
+  else
+    hipLaunchKernelGGL(t10_tangent_blocks_kernel<kSVK>, dim3(m.E), dim3(64), 0, s, m, mat, h, Kbuf);
+}
+
+// ------------------------------------------------------------------------------------------------
+// row-owner assembly: one node row (3 CSR rows of H) per wavefront.
+// H layout == the reference's DOF-level CSR (SyncedNewton.cu:163-205): for node i with deg
+// neighbours, values[9*off[i] + d*3*deg + 3*k + e] = H(3i+d, 3*cols[off[i]+k]+e).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void assemble_rows_kernel(int N, Incidence inc, const double* __restrict__ Kbuf,
+                                                          const double* __restrict__ mval, double inv_h,
+                                                          const int* __restrict__ fixed_slot, double penalty,
+                                                          double* __restrict__ Hval) {
+  extern __shared__ double acc[];
+  const int i = blockIdx.x;
+  const int lane = threadIdx.x;
+  const int off0 = inc.off[i];
+  const int deg = inc.off[i + 1] - off0;
+  const int n9 = 9 * deg, row = 3 * deg;
+  for (int t = lane; t < n9; t += 64) acc[t] = 0.0;
+  __syncthreads();
+  // M/h on the xyz-diagonal of every block (SyncedNewton.cu:214-259)
+  for (int k = lane; k < deg; k += 64) {
+    const double mh = mval[off0 + k] * inv_h;
+    acc[0 * row + 3 * k + 0] = mh;
+    acc[1 * row + 3 * k + 1] = mh;
+    acc[2 * row + 3 * k + 2] = mh;
+  }
+  __syncthreads();
+  // h^2 rho J^T J: one 1.0 per pinned DOF (SyncedNewton.cu:292-341, FEAT10Data.cu:443-459)
+  if (lane < 3 && fixed_slot && fixed_slot[i] >= 0) acc[lane * row + 3 * inc.diagpos[i] + lane] += penalty;
+  __syncthreads();
+  const int k0 = inc.n2e_off[i], k1 = inc.n2e_off[i + 1];
+  for (int k = k0; k < k1; k++) {
+    const int code = inc.n2e[k];
+    const int e = code / 10, il = code - e * 10;
+    const double* Ke = Kbuf + (size_t)e * (kNPair * 9);
+    const int* pos = inc.n2e_pos + (size_t)k * 10;
+    for (int t = lane; t < 90; t += 64) {
+      const int j = t / 9, dd = (t % 9) / 3, ee = t % 3;
+      const double val = (il <= j) ? Ke[pair_index(il, j) * 9 + dd * 3 + ee] : Ke[pair_index(j, il) * 9 + ee * 3 + dd];
+      acc[dd * row + 3 * pos[j] + ee] += val;
+    }
+    __syncthreads();
+  }
+  double* out = Hval + (size_t)9 * off0;
+  for (int t = lane; t < n9; t += 64) out[t] = acc[t];
+}
+
+void launch_assemble_rows(hipStream_t s, int N, int maxdeg, const Incidence& inc, const double* Kbuf,
+                          const double* mval, double inv_h, const int* fixed_slot, double penalty, double* Hval) {
+  const size_t lds = (size_t)9 * maxdeg * sizeof(double);
+  hipLaunchKernelGGL(assemble_rows_kernel, dim3(N), dim3(64), lds, s, N, inc, Kbuf, mval, inv_h, fixed_slot, penalty,
+                     Hval);
+}
+
+// ------------------------------------------------------------------------------------------------
+// consistent mass (FEAT10Data.cu:206-278), row-owner form: thread per node row, fixed order
+// ------------------------------------------------------------------------------------------------
+__global__ void mass_values_kernel(T10View m, Incidence inc, const double* __restrict__ qx,
+                                   const double* __restrict__ qy, const double* __restrict__ qz, double rho0,
+                                   double* __restrict__ mval) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m.N) return;
+  const int edges[6][2] = {{0, 1}, {1, 2}, {0, 2}, {0, 3}, {1, 3}, {2, 3}};
+  double Nq[kNQ][kNN];
+#pragma unroll
+  for (int q = 0; q < kNQ; q++) {
+    const double L[4] = {1.0 - qx[q] - qy[q] - qz[q], qx[q], qy[q], qz[q]};
+#pragma unroll
+    for (int k = 0; k < 4; k++) Nq[q][k] = L[k] * (2.0 * L[k] - 1.0);
+#pragma unroll
+    for (int k = 0; k < 6; k++) Nq[q][k + 4] = 4.0 * L[edges[k][0]] * L[edges[k][1]];
+  }
+  const int off0 = inc.off[i];
+  for (int k = off0; k < inc.off[i + 1]; k++) mval[k] = 0.0;
+  for (int k = inc.n2e_off[i]; k < inc.n2e_off[i + 1]; k++) {
+    const int code = inc.n2e[k];
+    const int e = code / 10, il = code - e * 10;
+    const int* pos = inc.n2e_pos + (size_t)k * 10;
+    for (int j = 0; j < kNN; j++) {
+      double s = 0.0;
+      for (int q = 0; q < kNQ; q++) s += rho0 * Nq[q][il] * Nq[q][j] * m.detJ[e * kNQ + q] * m.qw[q];
+      mval[off0 + pos[j]] += s;
+    }
+  }
+}
+
+void launch_mass_values(hipStream_t s, const T10View& m, const Incidence& inc, const double* qx, const double* qy,
+                        const double* qz, double rho0, double* mval) {
+  hipLaunchKernelGGL(mass_values_kernel, dim3((m.N + 127) / 128), dim3(128), 0, s, m, inc, qx, qy, qz, rho0, mval);
+}
+
+}  // namespace tlfea

@@ -1,0 +1,95 @@
+// tlfea_internal.h -- device views and launch wrappers shared by the .hip translation units.
+// gfx950 (MI355X) only.  Nothing here is part of the C-ABI (see include/tlfea_c.h).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+
+namespace tlfea {
+
+constexpr int kNQ = 5;     // Keast 5-point rule (quadrature_utils.h:134)
+constexpr int kNN = 10;    // nodes per T10 element
+constexpr int kNPair = 55; // upper-triangular node pairs (i<=j) of one element
+constexpr int kWave = 64;  // CDNA wavefront
+
+enum MaterialModel : int { kSVK = 0, kMooneyRivlin = 1 }; // MaterialModel.cuh:14-17
+
+// Material scalars travel as kernel arguments (SGPRs) -- the reference dereferences one device
+// pointer per scalar per thread (FEAT10Data.cuh:825-829).
+struct Material {
+  int model;
+  double lambda, mu;          // SVK
+  double mu10, mu01, kappa;   // Mooney-Rivlin
+  double eta, lamd;           // Kelvin-Voigt damping
+  double rho0;
+};
+
+// Device view of one T10 mesh + state (all pointers are device pointers).
+struct T10View {
+  int E, N, Epad;
+  const int* conn;        // [10][E]   column-major E x 10 (reference layout)
+  const double* x;        // [N] current coordinates, SoA like the reference (d_h_x12/y12/z12)
+  const double* y;
+  const double* z;
+  const double* gradN;    // [E][5][3][10]  reference layout: wave-per-element kernels read 1200 B runs
+  const double* gradN_t;  // [5][3][10][Epad] element-fastest copy: thread-per-element kernels coalesce
+  const double* detJ;     // [E][5]
+  double qw[kNQ];         // Keast weights
+};
+
+// node -> element incidence and the scatter map of the row-owner ("gather") assembly
+struct Incidence {
+  const int* n2e_off;   // [N+1]
+  const int* n2e;       // [10E]   e*10 + local index, ascending e per node
+  const int* n2e_pos;   // [10E][10] position of column node conn(e,j) inside row i
+  const int* off;       // [N+1]   node-level adjacency CSR (== mass CSR pattern)
+  const int* cols;      // [nnz_coef] sorted per row
+  const int* diagpos;   // [N]     position of i in row i
+};
+
+// ---- launch wrappers (defined in the .hip files) -------------------------------------------
+void launch_dndu_pre(hipStream_t s, int E, int Epad, const int* conn, const double* x, const double* y,
+                     const double* z, const double* qx, const double* qy, const double* qz,
+                     double* gradN, double* gradN_t, double* detJ);
+void launch_residual(hipStream_t s, const T10View& m, const Material& mat, const double* v /*or null*/,
+                     double* fbuf /*[E][30]*/, double* F, double* P, double* Fdot, double* Pvis);
+void launch_tangent_blocks(hipStream_t s, const T10View& m, const Material& mat, double h,
+                           double* Kbuf /*[E][55][9]*/);
+void launch_assemble_rows(hipStream_t s, int N, int maxdeg, const Incidence& inc, const double* Kbuf,
+                          const double* mval, double inv_h, const int* fixed_slot, double penalty,
+                          double* Hval);
+void launch_mass_values(hipStream_t s, const T10View& m, const Incidence& inc, const double* qx,
+                        const double* qy, const double* qz, double rho0, double* mval);
+void launch_grad(hipStream_t s, int N, const Incidence& inc, const double* fbuf, const double* mval,
+                 const double* v, const double* vprev, const double* f_ext, const double* x,
+                 const double* y, const double* z, const double* xt, const double* yt, const double* zt,
+                 const int* fixed_slot, const double* lam, double h, double rho, double* f_int,
+                 double* cons, double* g);
+void launch_fint_gather(hipStream_t s, int N, const Incidence& inc, const double* fbuf, double* f_int);
+void launch_constraint(hipStream_t s, int n_fixed, const int* fixed_nodes, const double* x, const double* y,
+                       const double* z, const double* xt, const double* yt, const double* zt, double* cons);
+
+// vector / PCG kernels
+constexpr int kNPart = 512; // partial sums per reduction (fixed -> run-to-run bitwise reproducible)
+void launch_norm2(hipStream_t s, const double* a, const double* w /*weights or null*/, int n, double* part,
+                  double* out /*device scalar: sum of squares*/);
+void launch_extract_dinv(hipStream_t s, int N, const Incidence& inc, const double* Hval, double* Dinv);
+void launch_pcg_init(hipStream_t s, int N, const double* b, const double* Dinv, const double* w, double* x,
+                     double* r, double* z, double* p, double* rz_part, double* bb_part);
+void launch_spmv_dot(hipStream_t s, int N, const Incidence& inc, const double* Hval, const double* p,
+                     const double* w, double* q, double* pq_part);
+void launch_pcg_update(hipStream_t s, int N, const double* Dinv, const double* w, const double* p,
+                       const double* q, const double* rz_part_old, const double* pq_part, double* x,
+                       double* r, double* z, double* rz_part_new, double* rr_part);
+void launch_pcg_direction(hipStream_t s, int N, const double* z, const double* rz_part_old,
+                          const double* rz_part_new, double* p);
+void launch_sum_parts(hipStream_t s, const double* part, double* out);
+void launch_newton_update(hipStream_t s, int N, const double* dv, double* v, const double* xp, const double* yp,
+                          const double* zp, double h, double* x, double* y, double* z);
+void launch_axpy_neg(hipStream_t s, int n, const double* g, double* r);
+void launch_dual_update(hipStream_t s, int nc, const double* cons, double rho, double* lam);
+void launch_pack(hipStream_t s, int n, const int* idx, const double* src, double* buf);
+void launch_unpack(hipStream_t s, int n, const int* idx, const double* buf, double* dst);
+
+}  // namespace tlfea

@@ -1,0 +1,208 @@
+"""GPU_FEAT10_Data -- host mirror of the reference class (lib_src/elements/FEAT10Data.cuh:19-852) on the
+C-ABI.  Method names, argument order and call-order contract follow the reference; Eigen vectors become
+NumPy arrays, Eigen::MatrixXi connectivity is an (E,10) int array (sent column-major as the reference does)."""
+import ctypes as C
+
+import numpy as np
+
+from .binding import check, dp, ip, load_library
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+class GPU_FEAT10_Data:
+    TYPE = "TYPE_T10"  # ElementBase.h:20
+
+    def __init__(self, num_elements, num_nodes):
+        self._lib = load_library()
+        self.n_elem, self.n_coef = int(num_elements), int(num_nodes)
+        self._h = C.c_void_p()
+        self._initialized = False
+
+    # -- lifecycle ------------------------------------------------------------------------------
+    def Initialize(self):
+        check(self._lib.tlfea_t10_create(self.n_elem, self.n_coef, C.byref(self._h)))
+        self._initialized = True
+
+    def Destroy(self):
+        if self._initialized:
+            check(self._lib.tlfea_t10_destroy(self._h))
+            self._initialized = False
+
+    def Setup(self, tet5pt_x, tet5pt_y, tet5pt_z, tet5pt_weights, h_x12, h_y12, h_z12, element_connectivity):
+        conn = np.asarray(element_connectivity)
+        assert conn.shape == (self.n_elem, 10)
+        conn_cm = np.ascontiguousarray(conn.T, dtype=np.int32)  # [10][E] == column-major E x 10
+        qx, qy, qz, qw = _f64(tet5pt_x), _f64(tet5pt_y), _f64(tet5pt_z), _f64(tet5pt_weights)
+        x, y, z = _f64(h_x12), _f64(h_y12), _f64(h_z12)
+        assert x.size == y.size == z.size == self.n_coef
+        check(self._lib.tlfea_t10_setup(self._h, dp(qx), dp(qy), dp(qz), dp(qw), dp(x), dp(y), dp(z), ip(conn_cm)))
+
+    # -- setters --------------------------------------------------------------------------------
+    def SetDensity(self, rho0):
+        check(self._lib.tlfea_t10_set_density(self._h, C.c_double(rho0)))
+
+    def SetDamping(self, eta_damp, lambda_damp):
+        check(self._lib.tlfea_t10_set_damping(self._h, C.c_double(eta_damp), C.c_double(lambda_damp)))
+
+    def SetSVK(self, E=None, nu=None):
+        if E is None:
+            check(self._lib.tlfea_t10_set_svk_select(self._h))
+        else:
+            check(self._lib.tlfea_t10_set_svk(self._h, C.c_double(E), C.c_double(nu)))
+
+    def SetMooneyRivlin(self, mu10, mu01, kappa):
+        check(self._lib.tlfea_t10_set_mooney_rivlin(self._h, C.c_double(mu10), C.c_double(mu01), C.c_double(kappa)))
+
+    def SetExternalForce(self, h_f_ext):
+        f = _f64(h_f_ext)
+        check(self._lib.tlfea_t10_set_external_force(self._h, dp(f), int(f.size)))
+
+    def SetNodalFixed(self, fixed_nodes):
+        fx = np.ascontiguousarray(fixed_nodes, dtype=np.int32)
+        check(self._lib.tlfea_t10_set_nodal_fixed(self._h, ip(fx), int(fx.size)))
+
+    def UpdateNodalFixed(self, fixed_nodes):
+        fx = np.ascontiguousarray(fixed_nodes, dtype=np.int32)
+        check(self._lib.tlfea_t10_update_nodal_fixed(self._h, ip(fx), int(fx.size)))
+
+    def UpdatePositions(self, h_x12, h_y12, h_z12):
+        x, y, z = _f64(h_x12), _f64(h_y12), _f64(h_z12)
+        check(self._lib.tlfea_t10_update_positions(self._h, dp(x), dp(y), dp(z), int(x.size)))
+
+    def UpdateConstraintTargets(self, h_x12, h_y12, h_z12):
+        x, y, z = _f64(h_x12), _f64(h_y12), _f64(h_z12)
+        check(self._lib.tlfea_t10_update_constraint_targets(self._h, dp(x), dp(y), dp(z), int(x.size)))
+
+    # -- computations -----------------------------------------------------------------------------
+    def CalcDnDuPre(self):
+        check(self._lib.tlfea_t10_calc_dndu_pre(self._h))
+
+    def BuildMassCSRPattern(self):
+        check(self._lib.tlfea_t10_build_mass_csr_pattern(self._h))
+
+    def CalcMassMatrix(self):
+        check(self._lib.tlfea_t10_calc_mass_matrix(self._h))
+
+    def CalcConstraintData(self):
+        check(self._lib.tlfea_t10_calc_constraint_data(self._h))
+
+    def ConvertToCSR_ConstraintJac(self):
+        check(self._lib.tlfea_t10_convert_to_csr_constraint_jac(self._h))
+
+    def ConvertToCSR_ConstraintJacT(self):
+        check(self._lib.tlfea_t10_convert_to_csr_constraint_jact(self._h))
+
+    BuildConstraintJacobianCSR = ConvertToCSR_ConstraintJac
+    BuildConstraintJacobianTransposeCSR = ConvertToCSR_ConstraintJacT
+
+    def CalcP(self):
+        check(self._lib.tlfea_t10_calc_p(self._h))
+
+    def CalcInternalForce(self):
+        check(self._lib.tlfea_t10_calc_internal_force(self._h))
+
+    # -- getters ----------------------------------------------------------------------------------
+    def get_n_elem(self):
+        return self.n_elem
+
+    def get_n_beam(self):
+        return self.n_elem
+
+    def get_n_coef(self):
+        return self.n_coef
+
+    def get_n_constraint(self):
+        return self._lib.tlfea_t10_get_n_constraint(self._h)
+
+    def Get_Is_Constraint_Setup(self):
+        return bool(self._lib.tlfea_t10_is_constraint_setup(self._h))
+
+    def GetX12DevicePtr(self):
+        return self._lib.tlfea_t10_x12_device_ptr(self._h)
+
+    def GetY12DevicePtr(self):
+        return self._lib.tlfea_t10_y12_device_ptr(self._h)
+
+    def GetZ12DevicePtr(self):
+        return self._lib.tlfea_t10_z12_device_ptr(self._h)
+
+    def GetExternalForceDevicePtr(self):
+        return self._lib.tlfea_t10_external_force_device_ptr(self._h)
+
+    def Get_Constraint_Ptr(self):
+        return self._lib.tlfea_t10_constraint_device_ptr(self._h)
+
+    # -- retrieval (reference layouts) ----------------------------------------------------------------
+    def RetrieveMassCSRToCPU(self):
+        nnz = C.c_int()
+        check(self._lib.tlfea_t10_mass_csr_nnz(self._h, C.byref(nnz)))
+        off = np.zeros(self.n_coef + 1, dtype=np.int32)
+        col = np.zeros(nnz.value, dtype=np.int32)
+        val = np.zeros(nnz.value)
+        check(self._lib.tlfea_t10_retrieve_mass_csr(self._h, ip(off), ip(col), dp(val)))
+        return off, col, val
+
+    def RetrieveInternalForceToCPU(self):
+        f = np.zeros(3 * self.n_coef)
+        check(self._lib.tlfea_t10_retrieve_internal_force(self._h, dp(f)))
+        return f
+
+    def RetrieveExternalForceToCPU(self):
+        f = np.zeros(3 * self.n_coef)
+        check(self._lib.tlfea_t10_retrieve_external_force(self._h, dp(f)))
+        return f
+
+    def RetrievePositionToCPU(self):
+        x, y, z = (np.zeros(self.n_coef) for _ in range(3))
+        check(self._lib.tlfea_t10_retrieve_position(self._h, dp(x), dp(y), dp(z)))
+        return x, y, z
+
+    def RetrievePFromFToCPU(self):
+        """[E][5] 3x3 matrices; flat storage is column-major per matrix like the reference."""
+        P = np.zeros((self.n_elem, 5, 9))
+        check(self._lib.tlfea_t10_retrieve_p_from_f(self._h, dp(P)))
+        return P.reshape(self.n_elem, 5, 3, 3).transpose(0, 1, 3, 2)
+
+    def RetrieveDeformationGradientToCPU(self):
+        F = np.zeros((self.n_elem, 5, 9))
+        check(self._lib.tlfea_t10_retrieve_deformation_gradient(self._h, dp(F)))
+        return F.reshape(self.n_elem, 5, 3, 3).transpose(0, 1, 3, 2)
+
+    def RetrieveDnDuPreToCPU(self):
+        """[E][5] 10x3 matrices (node, direction)."""
+        g = np.zeros((self.n_elem, 5, 3, 10))
+        check(self._lib.tlfea_t10_retrieve_dndu_pre(self._h, dp(g)))
+        return g.transpose(0, 1, 3, 2)
+
+    def RetrieveDetJToCPU(self):
+        d = np.zeros((self.n_elem, 5))
+        check(self._lib.tlfea_t10_retrieve_detj(self._h, dp(d)))
+        return d
+
+    def RetrieveConnectivityToCPU(self):
+        c = np.zeros((10, self.n_elem), dtype=np.int32)
+        check(self._lib.tlfea_t10_retrieve_connectivity(self._h, ip(c)))
+        return np.ascontiguousarray(c.T)
+
+    def RetrieveConstraintDataToCPU(self):
+        c = np.zeros(self.get_n_constraint())
+        check(self._lib.tlfea_t10_retrieve_constraint_data(self._h, dp(c)))
+        return c
+
+    def RetrieveConstraintJacobianCSRToCPU(self):
+        nc = self.get_n_constraint()
+        off, col, val = np.zeros(nc + 1, dtype=np.int32), np.zeros(nc, dtype=np.int32), np.zeros(nc)
+        check(self._lib.tlfea_t10_retrieve_constraint_jac_csr(self._h, ip(off), ip(col), dp(val)))
+        return off, col, val
+
+    def RetrieveConstraintJacobianTransposeCSRToCPU(self):
+        nc = self.get_n_constraint()
+        off, col, val = np.zeros(3 * self.n_coef + 1, dtype=np.int32), np.zeros(nc, dtype=np.int32), np.zeros(nc)
+        check(self._lib.tlfea_t10_retrieve_constraint_jact_csr(self._h, ip(off), ip(col), dp(val)))
+        return off, col, val
+
+    def WriteOutputVTK(self, filename):
+        check(self._lib.tlfea_t10_write_output_vtk(self._h, str(filename).encode()))

@@ -1,0 +1,85 @@
+"""Host plumbing of the T10 path: TetGen readers (reference: lib_utils/cpu_utils.cc:607-754) and the
+structured T10 generators used for the BASELINE configs.  Integer outputs are
+bit-exact with the reference readers (tests/test_host_plumbing.py)."""
+import numpy as np
+
+TETGEN_TO_STANDARD = (0, 1, 2, 3, 6, 7, 9, 5, 8, 4)  # cpu_utils.cc:619
+EDGES = ((0, 1), (1, 2), (0, 2), (0, 3), (1, 3), (2, 3))  # FEAT10Data.cu:143
+
+
+def FEAT10_remap_tetgen_indices(tetgen_elem):
+    t = np.asarray(tetgen_elem)
+    if t.shape[-1] != 10:
+        raise ValueError("Element arrays must have size 10 for T10 elements")
+    return t[..., list(TETGEN_TO_STANDARD)]
+
+
+def FEAT10_read_nodes(filename):
+    """-> (n_nodes, nodes[n,3]); node ids are shifted by 1 unless the file's smallest id is 0."""
+    with open(filename) as f:
+        hdr = f.readline().split()
+        n, dim = int(hdr[0]), int(hdr[1])
+        if dim != 3:
+            raise ValueError(f"Only 3D nodes are supported, found {dim}D")
+        rows = []
+        for _ in range(n):
+            p = f.readline().split()
+            if len(p) >= 4:
+                rows.append((int(p[0]), float(p[1]), float(p[2]), float(p[3])))
+    off = 0 if min(r[0] for r in rows) == 0 else 1
+    nodes = np.zeros((n, 3))
+    for i, x, y, z in rows:
+        if 0 <= i - off < n:
+            nodes[i - off] = (x, y, z)
+    return n, nodes
+
+
+def FEAT10_read_elements(filename):
+    """-> (n_elems, elements[n,10] int32) in the standard mid-node order."""
+    with open(filename) as f:
+        hdr = f.readline().split()
+        m, k = int(hdr[0]), int(hdr[1])
+        if k != 10:
+            raise ValueError(f"Only T10 elements (10 nodes) are supported, found {k}")
+        rows = [[int(p) for p in line.split()[:11]] for line in (f.readline() for _ in range(m)) if line.strip()]
+    rows = np.asarray(rows, dtype=np.int64)
+    eoff = 0 if rows[:, 0].min() == 0 else 1
+    noff = 0 if rows[:, 1:].min() == 0 else 1
+    elements = np.zeros((m, 10), dtype=np.int32)
+    ids = rows[:, 0] - eoff
+    ok = (ids >= 0) & (ids < m)
+    elements[ids[ok]] = FEAT10_remap_tetgen_indices(rows[ok, 1:] - noff)
+    return m, elements
+
+
+# 6 tetrahedra per hexahedral cell, all sharing the main diagonal v0-v6 (conforming across cells)
+_HEX_TETS = ((0, 1, 2, 6), (0, 2, 3, 6), (0, 3, 7, 6), (0, 7, 4, 6), (0, 4, 5, 6), (0, 5, 1, 6))
+_HEX_CORNERS = ((0, 0, 0), (1, 0, 0), (1, 1, 0), (0, 1, 0), (0, 0, 1), (1, 0, 1), (1, 1, 1), (0, 1, 1))
+
+
+def structured_t10_box(nx, ny, nz, lx=1.0, ly=1.0, lz=1.0):
+    """nx*ny*nz cells x 6 T10 tets on a (2nx+1)(2ny+1)(2nz+1) lattice (corner + mid-edge nodes).
+    Returns (nodes[N,3] float64, elements[E,10] int32); unused lattice points are dropped and nodes are
+    numbered in lattice (z-major) order, so neighbouring nodes stay close in memory."""
+    gx, gy, gz = 2 * nx + 1, 2 * ny + 1, 2 * nz + 1
+    ii, jj, kk = np.meshgrid(np.arange(nx), np.arange(ny), np.arange(nz), indexing="ij")
+    base = np.stack([ii.ravel(), jj.ravel(), kk.ravel()], axis=1) * 2  # lattice coords of cell corner 0
+    corners = np.asarray(_HEX_CORNERS) * 2
+    tets = np.asarray(_HEX_TETS)
+    # lattice coordinates of the 4 vertices of every tet: [cells, 6, 4, 3]
+    v = base[:, None, None, :] + corners[tets][None, :, :, :]
+    v = v.reshape(-1, 4, 3)
+    # fix orientation so that det J > 0
+    d1, d2, d3 = v[:, 1] - v[:, 0], v[:, 2] - v[:, 0], v[:, 3] - v[:, 0]
+    vol = np.einsum("ij,ij->i", d1, np.cross(d2, d3))
+    flip = vol < 0
+    v[flip, 1], v[flip, 2] = v[flip, 2].copy(), v[flip, 1].copy()
+    mids = np.stack([(v[:, a] + v[:, b]) // 2 for a, b in EDGES], axis=1)
+    lat = np.concatenate([v, mids], axis=1)  # [E,10,3]
+    lin = (lat[..., 2] * gy + lat[..., 1]) * gx + lat[..., 0]
+    used, inv = np.unique(lin.ravel(), return_inverse=True)
+    elements = inv.reshape(-1, 10).astype(np.int32)
+    xs = (used % gx) * (lx / (2 * nx))
+    ys = ((used // gx) % gy) * (ly / (2 * ny))
+    zs = (used // (gx * gy)) * (lz / (2 * nz))
+    return np.stack([xs, ys, zs], axis=1).astype(np.float64), elements

@@ -1,0 +1,157 @@
+"""SyncedNewtonSolver -- host mirror of lib_src/solvers/SyncedNewton.cuh:35-405 on the C-ABI."""
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from .binding import ALLREDUCE_FN, LinSolveOptsC, NewtonParams, check, dp, ip, load_library
+
+
+@dataclass
+class SyncedNewtonParams:  # SyncedNewton.cuh:29-33 (same field order)
+    inner_atol: float = 1e-4
+    inner_rtol: float = 1e-4
+    outer_tol: float = 1e-4
+    rho: float = 1e14
+    max_outer: int = 5
+    max_inner: int = 10
+    time_step: float = 1e-3
+
+
+@dataclass
+class LinSolveOpts:
+    rel_tol: float = 1e-12
+    max_iter: int = 20000
+    check_every: int = 25
+
+
+class SyncedNewtonSolver:
+    def __init__(self, data, n_constraints):
+        self._lib = load_library()
+        self._data = data  # the data object must outlive the solver (SyncedNewton.cuh:37-46)
+        self.n_coef = data.get_n_coef()
+        self.n_constraints = int(n_constraints)
+        self._h = C.c_void_p()
+        check(self._lib.tlfea_newton_create(data._h, self.n_constraints, C.byref(self._h)))
+        self._cb = None
+
+    def __del__(self):
+        try:
+            if self._h:
+                self._lib.tlfea_newton_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def Setup(self):
+        check(self._lib.tlfea_newton_setup(self._h))
+
+    def SetParameters(self, params):
+        p = NewtonParams(params.inner_atol, params.inner_rtol, params.outer_tol, params.rho, params.max_outer,
+                         params.max_inner, params.time_step)
+        check(self._lib.tlfea_newton_set_parameters(self._h, C.byref(p)))
+
+    def SetLinSolveOpts(self, o):
+        c = LinSolveOptsC(o.rel_tol, o.max_iter, o.check_every)
+        check(self._lib.tlfea_newton_set_linsolve_opts(self._h, C.byref(c)))
+
+    def AnalyzeHessianSparsity(self):
+        check(self._lib.tlfea_newton_analyze_hessian_sparsity(self._h))
+
+    def SetFixedSparsityPattern(self, fixed):
+        check(self._lib.tlfea_newton_set_fixed_sparsity_pattern(self._h, int(bool(fixed))))
+
+    def Solve(self):
+        check(self._lib.tlfea_newton_solve(self._h))
+
+    OneStepNewtonCuDSS = Solve  # reference name of the same step (SyncedNewton.cuh:345-349)
+
+    def GetVelocityGuessDevicePtr(self):
+        return self._lib.tlfea_newton_velocity_guess_device_ptr(self._h)
+
+    def compute_l2_norm_cublas(self, d_vec, n_dofs):
+        out = C.c_double()
+        check(self._lib.tlfea_newton_l2_norm(self._h, C.c_void_p(d_vec), int(n_dofs), C.byref(out)))
+        return out.value
+
+    # ---- engine extras ------------------------------------------------------------------------
+    def SetVerbose(self, v):
+        check(self._lib.tlfea_newton_set_verbose(self._h, int(v)))
+
+    def SetProfiling(self, on):
+        check(self._lib.tlfea_newton_set_profiling(self._h, int(bool(on))))
+
+    def RetrieveHessianCSRToCPU(self):
+        nnz = C.c_int()
+        check(self._lib.tlfea_newton_hessian_nnz(self._h, C.byref(nnz)))
+        ro = np.zeros(3 * self.n_coef + 1, dtype=np.int32)
+        ci = np.zeros(nnz.value, dtype=np.int32)
+        val = np.zeros(nnz.value)
+        check(self._lib.tlfea_newton_retrieve_hessian_csr(self._h, ip(ro), ip(ci), dp(val)))
+        return ro, ci, val
+
+    def EvalGradient(self):
+        ng = C.c_double()
+        check(self._lib.tlfea_newton_eval_gradient(self._h, C.byref(ng)))
+        return ng.value
+
+    def AssembleHessian(self):
+        check(self._lib.tlfea_newton_assemble_hessian(self._h))
+
+    def LinearSolve(self, b):
+        b = np.ascontiguousarray(b, dtype=np.float64)
+        x = np.zeros_like(b)
+        it, rel = C.c_int(), C.c_double()
+        check(self._lib.tlfea_newton_linear_solve(self._h, dp(b), dp(x), C.byref(it), C.byref(rel)))
+        return x, it.value, rel.value
+
+    def NewtonIteration(self):
+        ng, it = C.c_double(), C.c_int()
+        check(self._lib.tlfea_newton_iteration(self._h, C.byref(ng), C.byref(it)))
+        return ng.value, it.value
+
+    def RetrieveGradientToCPU(self):
+        g = np.zeros(3 * self.n_coef)
+        check(self._lib.tlfea_newton_retrieve_gradient(self._h, dp(g)))
+        return g
+
+    def RetrieveVelocityToCPU(self):
+        v = np.zeros(3 * self.n_coef)
+        check(self._lib.tlfea_newton_retrieve_velocity(self._h, dp(v)))
+        return v
+
+    def SetVelocity(self, v, v_prev=None):
+        v = np.ascontiguousarray(v, dtype=np.float64)
+        vp = np.ascontiguousarray(v_prev, dtype=np.float64) if v_prev is not None else None
+        check(self._lib.tlfea_newton_set_velocity(self._h, dp(v), dp(vp)))
+
+    def RetrieveLambdaToCPU(self):
+        lam = np.zeros(self.n_constraints)
+        check(self._lib.tlfea_newton_retrieve_lambda(self._h, dp(lam)))
+        return lam
+
+    def GetStats(self):
+        st = np.zeros(6)
+        check(self._lib.tlfea_newton_get_stats(self._h, dp(st)))
+        return dict(outer=int(st[0]), newton=int(st[1]), norm_g=st[2], norm_c=st[3], pcg_iters=int(st[4]), ms=st[5])
+
+    def GetStageMs(self, reset=False):
+        ms = np.zeros(6)
+        check(self._lib.tlfea_newton_get_stage_ms(self._h, dp(ms), int(reset)))
+        return dict(zip(["residual", "grad", "tangent_blocks", "assemble_rows", "pcg", "update"], ms.tolist()))
+
+    def SetInterface(self, iface_dofs, dof_weight, allreduce):
+        """allreduce(ptr:int, n:int) -> None sums a device buffer of n doubles over ranks in place."""
+        idx = np.ascontiguousarray(iface_dofs, dtype=np.int32)
+        w = np.ascontiguousarray(dof_weight, dtype=np.float64)
+
+        def _cb(_user, ptr, n):
+            try:
+                allreduce(ptr, n)
+                return 0
+            except Exception as exc:  # pragma: no cover
+                print("allreduce callback failed:", exc)
+                return 1
+
+        self._cb = ALLREDUCE_FN(_cb)
+        check(self._lib.tlfea_newton_set_interface(self._h, ip(idx), int(idx.size), dp(w), self._cb, None))
