@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""bench.py -- T10 element-updates/s per Newton iteration on MI355X (BASELINE.json metric).
+
+One "step" = ONE full Newton iteration of the implicit step on the workload, inputs resident in HBM:
+  residual (F,P,f_int) -> gradient + norm -> tangent blocks -> row assembly of H -> PCG solve of H dv = -g
+  -> v += dv, x = x_prev + h v         (SyncedNewton.cu:1046-1119); every 3rd iteration starts a new time step.
+value = elements * steps / seconds (whole job, max over ranks).  The JSON line also carries
+  roofline     : dominant kernel, algorithmic bytes per launch / mean launch duration (hipEvents on the launch stream)
+  roofline_all : the same for every hot kernel
+  cpu_baseline : the CPU oracle (C restatement of the reference, OpenMP) on the same workload, rank 0, N=1 only.
+
+Launch:  python bench.py [--gpus N --steps K --warmup W --config B|C]
+         python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (one rank per GPU)
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s, ~6.3 achievable)
+
+
+def alg_bytes(E, N, nnz_coef):
+    """Algorithmic (compulsory) bytes per launch of each hot kernel, see DESIGN.md section 4."""
+    npair = 55
+    return {
+        # conn + x gather (unique nodes) + gradN + detJ -> 30 force components per element
+        "residual": E * (40 + 1200 + 40 + 240) + N * 24,
+        # + element-major symmetric block buffer (55 blocks x 72 B)
+        "tangent_blocks": E * (40 + 1200 + 40) + N * 24 + E * npair * 72,
+        # block buffer in, scatter map in, mass in, H (9 doubles per node pair) out once
+        "assemble_rows": E * npair * 72 + E * 400 + nnz_coef * 8 + nnz_coef * 72,
+        # H values + node-level columns + p gather + q
+        "spmv": nnz_coef * 72 + nnz_coef * 4 + N * 48,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=6)
+    ap.add_argument("--config", default="B")
+    ap.add_argument("--rel-tol", type=float, default=1e-12)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    tl = importlib.import_module("total-lagrangian-fea_amd")
+    from importlib import import_module
+    wl = import_module("total-lagrangian-fea_amd.workloads")
+    par = import_module("total-lagrangian-fea_amd.partition")
+
+    cfg = wl.CONFIGS[args.config]
+    nx = cfg["cells"][0]
+    # weak scaling: every rank owns one full-size x-slab of a bar `world` times as long
+    w = wl.build(args.config, cells=cfg["cells"], x_offset_cells=rank * nx)
+    if world > 1:
+        par.restrict_bcs_to_global_ends(w, rank, world, cfg)
+    d, s = wl.make_engine(tl, w)
+    s.SetLinSolveOpts(tl.LinSolveOpts(args.rel_tol, 50000, 25))
+    if world > 1:
+        par.attach_slab_interfaces(tl, s, w, rank, world, torch, dist)
+    d.UpdatePositions(w["x0"][:, 0], w["x0"][:, 1], w["x0"][:, 2])
+    E, N = w["conn"].shape[0], w["X"].shape[0]
+    nnz_coef = int(d.RetrieveMassCSRToCPU()[0][-1])
+
+    def run(k, count_from=0):
+        its = []
+        for i in range(k):
+            if (count_from + i) % 3 == 0:
+                s.BeginStep()
+            ng, it = s.NewtonIteration()
+            its.append(it)
+        return its
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    run(args.warmup)
+    barrier()
+    t0 = time.perf_counter()
+    pcg_its = run(args.steps, args.warmup)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    value = E * world * args.steps / dt
+
+    # ---- per-kernel durations, live, hipEvents on the launch stream (separate pass: adds host syncs) ------
+    s.SetProfiling(True)
+    s.GetStageMs(reset=True)
+    nprof = max(3, min(args.steps, 9))
+    run(nprof, args.warmup + args.steps)
+    torch.cuda.synchronize()
+    st = s.GetStageMs(reset=True)
+    s.SetProfiling(False)
+    ab = alg_bytes(E, N, nnz_coef)
+    roof_all = {}
+    for k in ("residual", "tangent_blocks", "assemble_rows", "spmv"):
+        ms, n = st[k]
+        if n == 0:
+            continue
+        avg_s = ms / n * 1e-3
+        ach = ab[k] / avg_s / 1e9
+        roof_all[k] = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                       "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "avg_us": round(avg_s * 1e6, 2),
+                       "launches": n, "alg_bytes": ab[k], "total_ms": round(ms, 3)}
+    dominant = max(roof_all, key=lambda k: roof_all[k]["total_ms"])
+    roofline = dict(roof_all[dominant], kernel=dominant)
+    elem_ms = sum(st[k][0] for k in ("residual", "grad", "tangent_blocks", "assemble_rows")) / nprof
+    stage_share = {k: round(st[k][0] / nprof, 4) for k in ("residual", "grad", "tangent_blocks", "assemble_rows",
+                                                           "pcg", "update")}
+
+    out = {
+        "metric": "T10-tet element-updates/sec per Newton step", "value": round(value, 1), "unit": "element-updates/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"config {args.config}: {w['desc']}, {E} elements / {N} nodes per GPU, "
+                               f"implicit Newton iteration incl. PCG solve (rel_tol {args.rel_tol:g})",
+                   "elements_per_gpu": E, "nodes_per_gpu": N, "hessian_nnz": 9 * nnz_coef,
+                   "pcg_iters_per_step": round(float(np.mean(pcg_its)), 1)},
+        "element_stage": {"ms_per_step": round(elem_ms, 4), "value": round(E / (elem_ms * 1e-3), 1),
+                          "note": "residual+gradient+tangent+assembly only (no linear solve), profiling pass"},
+        "stage_ms_per_step": stage_share,
+        "roofline": roofline, "roofline_all": roof_all,
+    }
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(w, args)
+    del s
+    d.Destroy()
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(w, args):
+    """The CPU oracle (C restatement of the reference, OpenMP atomics for the scatter, Jacobi-PCG twin of the
+    device solver) on a bounded sample: Newton iterations of the same workload on the host cores."""
+    from oracle import orc
+
+    m = w["material"]
+    mat = (orc.svk(m["E"], m["nu"], rho0=m["rho0"]) if m["kind"] == "svk"
+           else orc.mooney_rivlin(m["mu10"], m["mu01"], m["kappa"], rho0=m["rho0"]))
+    cores = os.cpu_count() or 1
+    X, conn = w["X"], w["conn"]
+    # bounded sample: whole workload when small, else its first ~10k elements' worth of slab
+    o = orc.T10Oracle(X, conn, mat, fixed=w["fixed"], f_ext=w["f_ext"])
+    o.calc_dndu_pre()
+    o.calc_mass()
+    o.x, o.y, o.z = (np.ascontiguousarray(w["x0"][:, i]) for i in range(3))
+    prm = w["params"]
+    h, rho = prm[6], prm[3]
+    t0 = time.perf_counter()
+    n_it = 0
+    while True:
+        f_int = o.internal_force(o.v)
+        g = o.grad_L(f_int, h, rho)
+        ro, ci, val = o.assemble_hessian(h, rho, nthreads=cores)
+        dv, its = orc.solve_pcg(ro, ci, val, -g, rel_tol=args.rel_tol, max_iter=50000, nthreads=cores)
+        o.v += dv
+        xn = w["X"].reshape(-1) * 0  # x = x_prev + h v  (x_prev = x0)
+        o.x = w["x0"][:, 0] + h * o.v[0::3]
+        o.y = w["x0"][:, 1] + h * o.v[1::3]
+        o.z = w["x0"][:, 2] + h * o.v[2::3]
+        n_it += 1
+        el = time.perf_counter() - t0
+        if el > 10.0 or n_it >= 5:
+            break
+    return {"value": round(conn.shape[0] * n_it / el, 1), "unit": "element-updates/s", "cores": cores,
+            "kind": "port", "sample": f"{n_it} Newton iteration(s) of the same workload ({conn.shape[0]} elements, "
+                                      f"PCG rel_tol {args.rel_tol:g}, {its} iterations last solve) in {el:.1f} s"}
+
+
+if __name__ == "__main__":
+    main()

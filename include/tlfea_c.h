@@ -143,9 +143,12 @@ int tlfea_newton_retrieve_lambda(tlfea_newton_t s, double *lam /*n_constraints*/
 /* stats of the last tlfea_newton_solve(): [0] outer iterations, [1] Newton solves, [2] last ||g||,
  * [3] last ||c||, [4] total PCG iterations, [5] device ms of the step (hipEvent) */
 int tlfea_newton_get_stats(tlfea_newton_t s, double *stats6);
-/* per-stage device time (ms, hipEvent on the launch stream) accumulated since the last reset:
- * [0] residual kernel, [1] f_int gather + grad, [2] tangent blocks, [3] row assembly, [4] PCG, [5] updates */
-int tlfea_newton_get_stage_ms(tlfea_newton_t s, double *ms6, int reset);
+/* per-stage device time (ms, hipEvent pairs on the launch stream; profiling mode) and launch counts since
+ * the last reset: [0] residual kernel, [1] gather+grad+norm, [2] tangent-block kernel, [3] row-assembly
+ * kernel, [4] whole PCG solve, [5] update kernel, [6] SpMV kernel alone, [7] unused */
+int tlfea_newton_get_stage_ms(tlfea_newton_t s, double *ms8, double *counts8, int reset);
+/* start of an implicit step when driving Newton iterations by hand: x_prev <- x, v_prev <- v */
+int tlfea_newton_begin_step(tlfea_newton_t s);
 int tlfea_newton_set_verbose(tlfea_newton_t s, int verbose);
 /* per-stage hipEvent timing for tlfea_newton_get_stage_ms (one host sync per stage; off by default) */
 int tlfea_newton_set_profiling(tlfea_newton_t s, int on);

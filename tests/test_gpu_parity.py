@@ -15,6 +15,14 @@ TOL_ELEM = 1e-12   # element-level quantities, relative to the largest entry
 TOL_DISP = 1e-10   # nodal displacement after Newton steps, relative to the largest displacement
 
 
+def disp_err_ok(xg, xo, X):
+    """|x_gpu - x_oracle| <= 1e-10 * max displacement, plus the representation floor of the positions
+    themselves (x = x_prev + h v is stored as a coordinate: 1 ulp of |x| ~ 1e-15 can exceed 1e-10 of a
+    micrometre displacement)."""
+    floor = 8 * np.finfo(np.float64).eps * np.max(np.abs(xo))
+    return np.max(np.abs(xg - xo)) <= TOL_DISP * np.max(np.abs(xo - X)) + floor
+
+
 @pytest.fixture(scope="module", params=["cube", "beam_3x2x1", "res2", "bunny"])
 def mesh(request):
     return (request.param,) + load_mesh(request.param)
@@ -62,7 +70,7 @@ def test_calc_p_and_internal_force(mesh, mat):
     Fg, Pg = d.RetrieveDeformationGradientToCPU(), d.RetrievePFromFToCPU()
     Fo = F.reshape(-1, 5, 3, 3).transpose(0, 1, 3, 2)
     Po = P.reshape(-1, 5, 3, 3).transpose(0, 1, 3, 2)
-    assert relerr(Fg, Fo) < 1e-13
+    assert relerr(Fg, Fo) < TOL_ELEM  # F = sum x_a (x) h_a cancels ~|x||h| (bunny: coordinates ~5)
     assert relerr(Pg, Po) < TOL_ELEM
     f_o = o.internal_force(None)
     f_g = d.RetrieveInternalForceToCPU()
@@ -186,7 +194,7 @@ def test_newton_steps_beam_vs_oracle_and_prototype(golden_dir):
     out, vg, vo, lam_g, lam_o = _run_steps(X, conn, m, g["fixed"], g["f_ext"], prm, 3)
     for step, (xg, xo, st_g, st_o) in enumerate(out):
         disp = np.max(np.abs(xo - X))
-        assert np.max(np.abs(xg - xo)) / disp < TOL_DISP, (step, st_g, st_o)
+        assert disp_err_ok(xg, xo, X), (step, st_g, st_o)
         assert st_g["outer"] == st_o[0] and st_g["newton"] == st_o[1]
         # reference prototype (dense Cholesky, converged to round-off)
         assert np.max(np.abs(xg - g["x_steps"][step])) / disp < 1e-8
@@ -205,8 +213,7 @@ def test_newton_steps_res4_driver_parameters():
     prm = tl.SyncedNewtonParams(1e-4, 1e-4, 1e-4, 1e14, 5, 10, 1e-3)
     out, *_ = _run_steps(X, conn, MATERIALS["svk"], fixed, f_ext, prm, 2)
     for xg, xo, st_g, st_o in out:
-        disp = np.max(np.abs(xo - X))
-        assert np.max(np.abs(xg - xo)) / disp < TOL_DISP
+        assert disp_err_ok(xg, xo, X)
         assert st_g["outer"] == st_o[0] and st_g["newton"] == st_o[1]
 
 
@@ -223,8 +230,7 @@ def test_newton_damped_neo_hookean_bunny():
     prm = tl.SyncedNewtonParams(1e-4, 1e-6, 1e-4, 1e14, 5, 10, 1e-3)
     out, *_ = _run_steps(X, conn, m, fixed, f_ext, prm, 2)
     for xg, xo, st_g, st_o in out:
-        disp = np.max(np.abs(xo - X))
-        assert np.max(np.abs(xg - xo)) / disp < TOL_DISP
+        assert disp_err_ok(xg, xo, X)
         assert st_g["outer"] == st_o[0] and st_g["newton"] == st_o[1]
 
 
@@ -243,7 +249,7 @@ def test_no_constraints_runs_all_outer_iterations():
     assert s.GetStats()["outer"] == 3 == st[0]
     xg = np.stack(d.RetrievePositionToCPU(), axis=1)
     xo = np.stack([o.x, o.y, o.z], axis=1)
-    assert np.max(np.abs(xg - xo)) / np.max(np.abs(xo - X)) < TOL_DISP
+    assert disp_err_ok(xg, xo, X)
     del s
     d.Destroy()
 

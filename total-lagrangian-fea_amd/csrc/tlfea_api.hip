@@ -507,7 +507,8 @@ struct tlfea_newton_s {
   int h_nnz = 0;
   std::vector<int> h_row_offsets, h_col_indices;  // reference DOF-level CSR index arrays (host)
   double stats[6] = {0, 0, 0, 0, 0, 0};
-  double stage_ms[6] = {0, 0, 0, 0, 0, 0};
+  double stage_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  double stage_n[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   hipEvent_t ev[8] = {nullptr};
   // multi-GPU interface
   int n_iface = 0;
@@ -697,6 +698,7 @@ struct StageTimer {  // hipEvent pair on the launch stream around one stage (pro
     float ms = 0.f;
     (void)hipEventElapsedTime(&ms, s->ev[0], s->ev[1]);
     s->stage_ms[stage] += ms;
+    s->stage_n[stage] += 1;
   }
 };
 
@@ -767,7 +769,16 @@ static int pcg(tlfea_newton_t s, const double* d_b, double* d_x, int* iters_out,
     const double target = s->lin.rel_tol * s->lin.rel_tol * bb;
     int cur = 0;  // which rz partial buffer is "old"
     while (it < s->lin.max_iter) {
+      if (s->profiling) (void)hipEventRecord(s->ev[4], s->stream);
       launch_spmv_dot(s->stream, N, d->inc(), s->d_H, s->d_p, w, s->d_q, part(s, 2));
+      if (s->profiling) {
+        (void)hipEventRecord(s->ev[5], s->stream);
+        (void)hipEventSynchronize(s->ev[5]);
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, s->ev[4], s->ev[5]);
+        s->stage_ms[6] += ms;
+        s->stage_n[6] += 1;
+      }
       if (s->ar) {
         TRY(iface_sum(s, s->d_q));
         TRY(parts_sum(s, part(s, 2), kNPart));
@@ -919,8 +930,18 @@ extern "C" int tlfea_newton_get_stats(tlfea_newton_t s, double* st) {
   std::copy(s->stats, s->stats + 6, st);
   return 0;
 }
-extern "C" int tlfea_newton_get_stage_ms(tlfea_newton_t s, double* ms, int reset) {
-  std::copy(s->stage_ms, s->stage_ms + 6, ms);
-  if (reset) std::fill(s->stage_ms, s->stage_ms + 6, 0.0);
+extern "C" int tlfea_newton_get_stage_ms(tlfea_newton_t s, double* ms, double* counts, int reset) {
+  std::copy(s->stage_ms, s->stage_ms + 8, ms);
+  if (counts) std::copy(s->stage_n, s->stage_n + 8, counts);
+  if (reset) {
+    std::fill(s->stage_ms, s->stage_ms + 8, 0.0);
+    std::fill(s->stage_n, s->stage_n + 8, 0.0);
+  }
+  return 0;
+}
+// Start of an implicit step outside Solve(): x_prev <- x (SyncedNewton.cu:1035) and v_prev <- v (:1122)
+extern "C" int tlfea_newton_begin_step(tlfea_newton_t s) {
+  TRY(begin_step(s));
+  HIP_TRY(hipMemcpyAsync(s->d_vprev, s->d_v, 3 * (size_t)s->N * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
   return 0;
 }

@@ -135,10 +135,16 @@ class SyncedNewtonSolver:
         check(self._lib.tlfea_newton_get_stats(self._h, dp(st)))
         return dict(outer=int(st[0]), newton=int(st[1]), norm_g=st[2], norm_c=st[3], pcg_iters=int(st[4]), ms=st[5])
 
+    STAGES = ["residual", "grad", "tangent_blocks", "assemble_rows", "pcg", "update", "spmv", "_"]
+
     def GetStageMs(self, reset=False):
-        ms = np.zeros(6)
-        check(self._lib.tlfea_newton_get_stage_ms(self._h, dp(ms), int(reset)))
-        return dict(zip(["residual", "grad", "tangent_blocks", "assemble_rows", "pcg", "update"], ms.tolist()))
+        """-> {stage: (total_ms, launches)} measured with hipEvents on the launch stream (profiling mode)."""
+        ms, cnt = np.zeros(8), np.zeros(8)
+        check(self._lib.tlfea_newton_get_stage_ms(self._h, dp(ms), dp(cnt), int(reset)))
+        return {k: (ms[i], int(cnt[i])) for i, k in enumerate(self.STAGES) if k != "_"}
+
+    def BeginStep(self):
+        check(self._lib.tlfea_newton_begin_step(self._h))
 
     def SetInterface(self, iface_dofs, dof_weight, allreduce):
         """allreduce(ptr:int, n:int) -> None sums a device buffer of n doubles over ranks in place."""
