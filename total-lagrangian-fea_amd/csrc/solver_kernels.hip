@@ -11,10 +11,10 @@ namespace tlfea {
 
 // ---- deterministic reductions -------------------------------------------------------------------
 // sum of kNPart partials by one workgroup of 256 threads, identical order everywhere
-__device__ __forceinline__ double block_sum_parts(const double* __restrict__ part, double* sh) {
+__device__ __forceinline__ double block_sum_parts(const double* __restrict__ part, double* sh, int n = kNPart) {
   const int t = threadIdx.x;
   double s = 0.0;
-  for (int k = t; k < kNPart; k += 256) s += part[k];
+  for (int k = t; k < n; k += 256) s += part[k];
   sh[t] = s;
   __syncthreads();
   for (int w = 128; w > 0; w >>= 1) {
@@ -132,22 +132,38 @@ void launch_pcg_init(hipStream_t s, int N, const double* b, const double* Dinv, 
   hipLaunchKernelGGL(pcg_init_kernel, dim3(kNPart), dim3(256), 0, s, N, b, Dinv, w, x, r, z, p, rz_part, bb_part);
 }
 
-// q = H p with one node row (3 CSR rows) per wavefront; lane t walks the 3*deg (k,e) columns so the
-// three value rows and the column-node list are read coalesced.  Also the partial of p.q.
-__global__ __launch_bounds__(256) void spmv_dot_kernel(int N, Incidence inc, const double* __restrict__ Hval,
-                                                      const double* __restrict__ p, const double* __restrict__ w,
-                                                      double* __restrict__ q, double* __restrict__ pq_part) {
+// q = H p_new with p_new = z + beta p_old formed on the fly (beta = rz_new/rz_old re-summed from the
+// partials; first iteration: p_new = z), so CG needs no separate direction kernel: 2 launches/iteration.
+// One node row (3 CSR rows) per wavefront pass; lane t walks the 3*deg (k,e) columns so the three value
+// rows and the column-node list are read coalesced.  Each workgroup owns a contiguous chunk of rows
+// (neighbouring rows share most of their column nodes -> the p/z gathers hit L1/L2).
+__global__ __launch_bounds__(256) void spmv_dir_dot_kernel(int N, Incidence inc, const double* __restrict__ Hval,
+                                                          const double* __restrict__ z,
+                                                          const double* __restrict__ p_old, int first,
+                                                          const double* __restrict__ rz_part_old,
+                                                          const double* __restrict__ rz_part_new,
+                                                          const double* __restrict__ w, double* __restrict__ p_new,
+                                                          double* __restrict__ q, double* __restrict__ pq_part) {
   __shared__ double sh[256];
+  double beta = 0.0;
+  if (!first) {
+    const double rz_old = block_sum_parts(rz_part_old, sh);
+    const double rz_new = block_sum_parts(rz_part_new, sh);
+    beta = rz_new / rz_old;
+  }
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int wave_global = blockIdx.x * 4 + wv, n_waves = gridDim.x * 4;
+  const int rows_per_block = (N + gridDim.x - 1) / gridDim.x;
+  const int r0 = blockIdx.x * rows_per_block;
+  const int r1 = min(N, r0 + rows_per_block);
   double pq = 0.0;
-  for (int i = wave_global; i < N; i += n_waves) {
+  for (int i = r0 + wv; i < r1; i += 4) {
     const int off0 = inc.off[i], deg = inc.off[i + 1] - off0, row = 3 * deg;
     const double* Hi = Hval + (size_t)9 * off0;
     double s0 = 0.0, s1 = 0.0, s2 = 0.0;
     for (int t = lane; t < row; t += 64) {
       const int k = t / 3, e = t - 3 * k;
-      const double pv = p[3 * inc.cols[off0 + k] + e];
+      const int c = 3 * inc.cols[off0 + k] + e;
+      const double pv = first ? z[c] : (z[c] + beta * p_old[c]);
       s0 += Hi[t] * pv;
       s1 += Hi[row + t] * pv;
       s2 += Hi[2 * row + t] * pv;
@@ -158,23 +174,24 @@ __global__ __launch_bounds__(256) void spmv_dot_kernel(int N, Incidence inc, con
       s1 += __shfl_xor(s1, o);
       s2 += __shfl_xor(s2, o);
     }
-    if (lane == 0) {
-      q[3 * i] = s0;
-      q[3 * i + 1] = s1;
-      q[3 * i + 2] = s2;
-      if (w)
-        pq += w[3 * i] * p[3 * i] * s0 + w[3 * i + 1] * p[3 * i + 1] * s1 + w[3 * i + 2] * p[3 * i + 2] * s2;
-      else
-        pq += p[3 * i] * s0 + p[3 * i + 1] * s1 + p[3 * i + 2] * s2;
+    if (lane < 3) {
+      const int c = 3 * i + lane;
+      const double pv = first ? z[c] : (z[c] + beta * p_old[c]);
+      const double sv = (lane == 0) ? s0 : ((lane == 1) ? s1 : s2);
+      p_new[c] = pv;
+      q[c] = sv;
+      pq += (w ? w[c] : 1.0) * pv * sv;
     }
   }
   const double r = block_reduce(pq, sh);
   if (threadIdx.x == 0) pq_part[blockIdx.x] = r;
 }
 
-void launch_spmv_dot(hipStream_t s, int N, const Incidence& inc, const double* Hval, const double* p,
-                     const double* w, double* q, double* pq_part) {
-  hipLaunchKernelGGL(spmv_dot_kernel, dim3(kNPart), dim3(256), 0, s, N, inc, Hval, p, w, q, pq_part);
+void launch_spmv_dir_dot(hipStream_t s, int N, int n_blocks, const Incidence& inc, const double* Hval,
+                         const double* z, const double* p_old, int first, const double* rz_part_old,
+                         const double* rz_part_new, const double* w, double* p_new, double* q, double* pq_part) {
+  hipLaunchKernelGGL(spmv_dir_dot_kernel, dim3(n_blocks), dim3(256), 0, s, N, inc, Hval, z, p_old, first, rz_part_old,
+                     rz_part_new, w, p_new, q, pq_part);
 }
 
 // x += alpha p ; r -= alpha q ; z = Dinv r ; partials of r.z and r.r
@@ -182,13 +199,13 @@ __global__ __launch_bounds__(256) void pcg_update_kernel(int N, const double* __
                                                         const double* __restrict__ w, const double* __restrict__ p,
                                                         const double* __restrict__ q,
                                                         const double* __restrict__ rz_part_old,
-                                                        const double* __restrict__ pq_part, double* __restrict__ x,
-                                                        double* __restrict__ r, double* __restrict__ z,
-                                                        double* __restrict__ rz_part_new,
+                                                        const double* __restrict__ pq_part, int n_pq,
+                                                        double* __restrict__ x, double* __restrict__ r,
+                                                        double* __restrict__ z, double* __restrict__ rz_part_new,
                                                         double* __restrict__ rr_part) {
   __shared__ double sh[256];
   const double rz_old = block_sum_parts(rz_part_old, sh);
-  const double pq = block_sum_parts(pq_part, sh);
+  const double pq = block_sum_parts(pq_part, sh, n_pq);
   const double alpha = rz_old / pq;
   double rz = 0.0, rr = 0.0;
   for (int i = blockIdx.x * 256 + threadIdx.x; i < N; i += gridDim.x * 256) {
@@ -218,26 +235,10 @@ __global__ __launch_bounds__(256) void pcg_update_kernel(int N, const double* __
 }
 
 void launch_pcg_update(hipStream_t s, int N, const double* Dinv, const double* w, const double* p, const double* q,
-                       const double* rz_part_old, const double* pq_part, double* x, double* r, double* z,
+                       const double* rz_part_old, const double* pq_part, int n_pq, double* x, double* r, double* z,
                        double* rz_part_new, double* rr_part) {
-  hipLaunchKernelGGL(pcg_update_kernel, dim3(kNPart), dim3(256), 0, s, N, Dinv, w, p, q, rz_part_old, pq_part, x, r,
-                     z, rz_part_new, rr_part);
-}
-
-__global__ __launch_bounds__(256) void pcg_direction_kernel(int N, const double* __restrict__ z,
-                                                           const double* __restrict__ rz_part_old,
-                                                           const double* __restrict__ rz_part_new,
-                                                           double* __restrict__ p) {
-  __shared__ double sh[256];
-  const double rz_old = block_sum_parts(rz_part_old, sh);
-  const double rz_new = block_sum_parts(rz_part_new, sh);
-  const double beta = rz_new / rz_old;
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < 3 * N; i += gridDim.x * 256) p[i] = z[i] + beta * p[i];
-}
-
-void launch_pcg_direction(hipStream_t s, int N, const double* z, const double* rz_part_old,
-                          const double* rz_part_new, double* p) {
-  hipLaunchKernelGGL(pcg_direction_kernel, dim3(kNPart), dim3(256), 0, s, N, z, rz_part_old, rz_part_new, p);
+  hipLaunchKernelGGL(pcg_update_kernel, dim3(kNPart), dim3(256), 0, s, N, Dinv, w, p, q, rz_part_old, pq_part, n_pq,
+                     x, r, z, rz_part_new, rr_part);
 }
 
 // ---- Newton vector updates (SyncedNewton.cu:413-534) ---------------------------------------------

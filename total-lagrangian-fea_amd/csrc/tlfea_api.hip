@@ -501,7 +501,7 @@ struct tlfea_newton_s {
   bool profiling = false;  // per-stage hipEvent timing (adds a host sync per stage)
   double *d_xp = nullptr, *d_yp = nullptr, *d_zp = nullptr;
   double *d_H = nullptr, *d_Kbuf = nullptr, *d_Dinv = nullptr;
-  double *d_p = nullptr, *d_q = nullptr, *d_zv = nullptr;
+  double *d_p = nullptr, *d_p2 = nullptr, *d_q = nullptr, *d_zv = nullptr;
   double* d_parts = nullptr;  // 6 x kNPart: rz[2], pq, rr, bb, norm
   double* d_scal = nullptr;   // 4 scalars
   int h_nnz = 0;
@@ -526,10 +526,10 @@ extern "C" int tlfea_newton_create(tlfea_t10_t data, int n_constraints, tlfea_ne
   s->n_constraints = n_constraints;
   const size_t n = 3 * (size_t)s->N;
   TRY(dmalloc(&s->d_v, n)); TRY(dmalloc(&s->d_vprev, n)); TRY(dmalloc(&s->d_g, n)); TRY(dmalloc(&s->d_dv, n));
-  TRY(dmalloc(&s->d_r, n)); TRY(dmalloc(&s->d_b, n)); TRY(dmalloc(&s->d_p, n)); TRY(dmalloc(&s->d_q, n)); TRY(dmalloc(&s->d_zv, n));
+  TRY(dmalloc(&s->d_r, n)); TRY(dmalloc(&s->d_b, n)); TRY(dmalloc(&s->d_p, n)); TRY(dmalloc(&s->d_p2, n)); TRY(dmalloc(&s->d_q, n)); TRY(dmalloc(&s->d_zv, n));
   TRY(dmalloc(&s->d_lam, (size_t)std::max(1, n_constraints)));
   TRY(dmalloc(&s->d_xp, (size_t)s->N)); TRY(dmalloc(&s->d_yp, (size_t)s->N)); TRY(dmalloc(&s->d_zp, (size_t)s->N));
-  TRY(dmalloc(&s->d_parts, (size_t)6 * kNPart));
+  TRY(dmalloc(&s->d_parts, (size_t)6 * kNPart + kMaxSpmvBlocks));
   TRY(dmalloc(&s->d_scal, (size_t)4));
   TRY(dmalloc(&s->d_Dinv, (size_t)9 * s->N));
   for (auto& e : s->ev) HIP_TRY(hipEventCreate(&e));
@@ -540,7 +540,7 @@ extern "C" int tlfea_newton_create(tlfea_t10_t data, int n_constraints, tlfea_ne
 extern "C" int tlfea_newton_destroy(tlfea_newton_t s) {
   if (!s) return 0;
   void* ptrs[] = {s->d_v, s->d_vprev, s->d_lam, s->d_g, s->d_dv, s->d_r, s->d_b, s->d_xp, s->d_yp, s->d_zp, s->d_H,
-                  s->d_Kbuf, s->d_Dinv, s->d_p, s->d_q, s->d_zv, s->d_parts, s->d_scal, s->d_iface, s->d_ibuf, s->d_w};
+                  s->d_Kbuf, s->d_Dinv, s->d_p, s->d_p2, s->d_q, s->d_zv, s->d_parts, s->d_scal, s->d_iface, s->d_ibuf, s->d_w};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   for (auto& e : s->ev)
@@ -767,10 +767,16 @@ static int pcg(tlfea_newton_t s, const double* d_b, double* d_x, int* iters_out,
   double rr = bb;
   if (bb > 0.0) {
     const double target = s->lin.rel_tol * s->lin.rel_tol * bb;
+    const int n_blk = std::min(kMaxSpmvBlocks, (N + 3) / 4);
+    double* pq_part = s->d_parts + (size_t)6 * kNPart;
     int cur = 0;  // which rz partial buffer is "old"
+    double *p_old = s->d_p, *p_new = s->d_p2;
+    // state entering iteration k: z, r, rz partials in part(cur) [and part(1-cur) = previous, for beta]
     while (it < s->lin.max_iter) {
       if (s->profiling) (void)hipEventRecord(s->ev[4], s->stream);
-      launch_spmv_dot(s->stream, N, d->inc(), s->d_H, s->d_p, w, s->d_q, part(s, 2));
+      // beta = rz(cur)/rz(1-cur); p_new = z + beta p_old; q = H p_new; partials of p_new.q
+      launch_spmv_dir_dot(s->stream, N, n_blk, d->inc(), s->d_H, s->d_zv, p_old, it == 0, part(s, 1 - cur),
+                          part(s, cur), w, p_new, s->d_q, pq_part);
       if (s->profiling) {
         (void)hipEventRecord(s->ev[5], s->stream);
         (void)hipEventSynchronize(s->ev[5]);
@@ -781,14 +787,17 @@ static int pcg(tlfea_newton_t s, const double* d_b, double* d_x, int* iters_out,
       }
       if (s->ar) {
         TRY(iface_sum(s, s->d_q));
-        TRY(parts_sum(s, part(s, 2), kNPart));
+        TRY(parts_sum(s, pq_part, n_blk));
       }
-      launch_pcg_update(s->stream, N, s->d_Dinv, w, s->d_p, s->d_q, part(s, cur), part(s, 2), d_x, s->d_r, s->d_zv,
-                        part(s, 1 - cur), part(s, 3));
+      // alpha = rz(cur)/pq; x += alpha p; r -= alpha q; z = Dinv r; new rz partials into part(1-cur)
+      launch_pcg_update(s->stream, N, s->d_Dinv, w, p_new, s->d_q, part(s, cur), pq_part, n_blk, d_x, s->d_r,
+                        s->d_zv, part(s, 1 - cur), part(s, 3));
       if (s->ar) {
         TRY(parts_sum(s, part(s, 1 - cur), kNPart));
         TRY(parts_sum(s, part(s, 3), kNPart));
       }
+      cur = 1 - cur;
+      std::swap(p_old, p_new);
       it++;
       if (it % s->lin.check_every == 0 || it == s->lin.max_iter) {
         launch_sum_parts(s->stream, part(s, 3), s->d_scal + 2);
@@ -796,8 +805,6 @@ static int pcg(tlfea_newton_t s, const double* d_b, double* d_x, int* iters_out,
         HIP_TRY(hipStreamSynchronize(s->stream));
         if (!(rr > target)) break;  // also leaves on NaN
       }
-      launch_pcg_direction(s->stream, N, s->d_zv, part(s, cur), part(s, 1 - cur), s->d_p);
-      cur = 1 - cur;
     }
   } else {
     HIP_TRY(hipMemsetAsync(d_x, 0, 3 * (size_t)N * sizeof(double), s->stream));
