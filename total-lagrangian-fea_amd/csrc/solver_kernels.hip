@@ -7,50 +7,77 @@
 // reference's atomics are not).
 #include "tlfea_internal.h"
 
+#include <algorithm>
+
 namespace tlfea {
 
 // ---- deterministic reductions -------------------------------------------------------------------
-// sum of kNPart partials by one workgroup of 256 threads, identical order everywhere
-__device__ __forceinline__ double block_sum_parts(const double* __restrict__ part, double* sh, int n = kNPart) {
-  const int t = threadIdx.x;
-  double s = 0.0;
-  for (int k = t; k < n; k += 256) s += part[k];
-  sh[t] = s;
+// wave64 butterfly + one LDS hop: 1-2 barriers per workgroup sum instead of a 9-barrier tree (these
+// kernels are latency-, not bandwidth-bound on small meshes).  Orders are fixed -> bitwise reproducible.
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// sum over the workgroup (blockDim.x/64 waves <= 16); sh needs 16 doubles
+__device__ __forceinline__ double block_sum(double v, double* sh) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  if (lane == 0) sh[wv] = v;
   __syncthreads();
-  for (int w = 128; w > 0; w >>= 1) {
-    if (t < w) sh[t] += sh[t + w];
-    __syncthreads();
-  }
-  const double r = sh[0];
+  double r = 0.0;
+  for (int k = 0; k < nw; k++) r += sh[k];
   __syncthreads();
   return r;
 }
 
-__device__ __forceinline__ double block_reduce(double v, double* sh) {
-  const int t = threadIdx.x;
-  sh[t] = v;
-  __syncthreads();
-  for (int w = 128; w > 0; w >>= 1) {
-    if (t < w) sh[t] += sh[t + w];
-    __syncthreads();
+__device__ __forceinline__ void block_sum2(double& a, double& b, double* sh) {
+  a = wave_sum(a);
+  b = wave_sum(b);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  if (lane == 0) {
+    sh[wv] = a;
+    sh[16 + wv] = b;
   }
-  const double r = sh[0];
   __syncthreads();
-  return r;
+  double ra = 0.0, rb = 0.0;
+  for (int k = 0; k < nw; k++) {
+    ra += sh[k];
+    rb += sh[16 + k];
+  }
+  __syncthreads();
+  a = ra;
+  b = rb;
+}
+
+// totals of two kNPart-slot partial arrays, identical in every workgroup of every kernel
+__device__ __forceinline__ void sum_slots2(const double* __restrict__ pa, const double* __restrict__ pb, double& a,
+                                           double& b, double* sh) {
+  double va = 0.0, vb = 0.0;
+  for (int k = threadIdx.x; k < kNPart; k += blockDim.x) {
+    va += pa[k];
+    vb += pb[k];
+  }
+  block_sum2(va, vb, sh);
+  a = va;
+  b = vb;
 }
 
 __global__ __launch_bounds__(256) void norm2_part_kernel(const double* __restrict__ a, const double* __restrict__ w,
                                                         int n, double* __restrict__ part) {
-  __shared__ double sh[256];
+  __shared__ double sh[32];
   double s = 0.0;
   for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) s += (w ? w[i] : 1.0) * a[i] * a[i];
-  const double r = block_reduce(s, sh);
+  const double r = block_sum(s, sh);
   if (threadIdx.x == 0) part[blockIdx.x] = r;
 }
 
 __global__ __launch_bounds__(256) void sum_parts_kernel(const double* __restrict__ part, double* __restrict__ out) {
-  __shared__ double sh[256];
-  const double r = block_sum_parts(part, sh);
+  __shared__ double sh[32];
+  double v = 0.0;
+  for (int k = threadIdx.x; k < kNPart; k += 256) v += part[k];
+  const double r = block_sum(v, sh);
   if (threadIdx.x == 0) out[0] = r;
 }
 
@@ -98,12 +125,14 @@ void launch_extract_dinv(hipStream_t s, int N, const Incidence& inc, const doubl
 // ---- PCG --------------------------------------------------------------------------------------
 // `w` (optional) weights each DOF in the dot products: 1/multiplicity of partition-interface DOFs,
 // so that the sum over ranks of the local dots is the global dot.
+// Every reduction lands in a kNPart-slot partial array (workgroups that do not exist leave their slot 0);
+// every consumer re-adds the slots in the same order.
 __global__ __launch_bounds__(256) void pcg_init_kernel(int N, const double* __restrict__ b,
                                                       const double* __restrict__ Dinv, const double* __restrict__ w,
                                                       double* __restrict__ x, double* __restrict__ r,
-                                                      double* __restrict__ z, double* __restrict__ p,
-                                                      double* __restrict__ rz_part, double* __restrict__ bb_part) {
-  __shared__ double sh[256];
+                                                      double* __restrict__ z, double* __restrict__ rz_part,
+                                                      double* __restrict__ bb_part) {
+  __shared__ double sh[32];
   double rz = 0.0, bb = 0.0;
   for (int i = blockIdx.x * 256 + threadIdx.x; i < N; i += gridDim.x * 256) {
     const double r0 = b[3 * i], r1 = b[3 * i + 1], r2 = b[3 * i + 2];
@@ -114,84 +143,100 @@ __global__ __launch_bounds__(256) void pcg_init_kernel(int N, const double* __re
     x[3 * i] = x[3 * i + 1] = x[3 * i + 2] = 0.0;
     r[3 * i] = r0; r[3 * i + 1] = r1; r[3 * i + 2] = r2;
     z[3 * i] = z0; z[3 * i + 1] = z1; z[3 * i + 2] = z2;
-    p[3 * i] = z0; p[3 * i + 1] = z1; p[3 * i + 2] = z2;
     const double w0 = w ? w[3 * i] : 1.0, w1 = w ? w[3 * i + 1] : 1.0, w2 = w ? w[3 * i + 2] : 1.0;
     rz += w0 * r0 * z0 + w1 * r1 * z1 + w2 * r2 * z2;
     bb += w0 * r0 * r0 + w1 * r1 * r1 + w2 * r2 * r2;
   }
-  const double a = block_reduce(rz, sh);
-  const double c = block_reduce(bb, sh);
+  block_sum2(rz, bb, sh);
   if (threadIdx.x == 0) {
-    rz_part[blockIdx.x] = a;
-    bb_part[blockIdx.x] = c;
+    rz_part[blockIdx.x] = rz;
+    bb_part[blockIdx.x] = bb;
   }
 }
 
 void launch_pcg_init(hipStream_t s, int N, const double* b, const double* Dinv, const double* w, double* x,
-                     double* r, double* z, double* p, double* rz_part, double* bb_part) {
-  hipLaunchKernelGGL(pcg_init_kernel, dim3(kNPart), dim3(256), 0, s, N, b, Dinv, w, x, r, z, p, rz_part, bb_part);
+                     double* r, double* z, double* rz_part, double* bb_part) {
+  hipLaunchKernelGGL(pcg_init_kernel, dim3(kNPart), dim3(256), 0, s, N, b, Dinv, w, x, r, z, rz_part, bb_part);
 }
 
-// q = H p_new with p_new = z + beta p_old formed on the fly (beta = rz_new/rz_old re-summed from the
-// partials; first iteration: p_new = z), so CG needs no separate direction kernel: 2 launches/iteration.
-// One node row (3 CSR rows) per wavefront pass; lane t walks the 3*deg (k,e) columns so the three value
-// rows and the column-node list are read coalesced.  Each workgroup owns a contiguous chunk of rows
-// (neighbouring rows share most of their column nodes -> the p/z gathers hit L1/L2).
-__global__ __launch_bounds__(256) void spmv_dir_dot_kernel(int N, Incidence inc, const double* __restrict__ Hval,
-                                                          const double* __restrict__ z,
-                                                          const double* __restrict__ p_old, int first,
-                                                          const double* __restrict__ rz_part_old,
-                                                          const double* __restrict__ rz_part_new,
-                                                          const double* __restrict__ w, double* __restrict__ p_new,
-                                                          double* __restrict__ q, double* __restrict__ pq_part) {
-  __shared__ double sh[256];
+// q = H p_new with p_new = z + beta p_old formed on the fly (beta = rz_new/rz_old from the partial slots;
+// first iteration: p_new = z), so CG needs no separate direction kernel: 2 launches per iteration.
+// Two node rows (6 CSR rows) per wavefront at a time: a 32-lane half-wave walks the 3*deg (k,e) columns of
+// one node row, so the three value rows and the column-node list are read coalesced; the value loads are
+// issued ahead of the dependent cols -> z/p gather chain.  Workgroups of 1024 threads own contiguous row
+// chunks (neighbouring rows share most column nodes -> the gathers hit L1/L2) and the grid never exceeds
+// kNPart workgroups, so the p.q partials fit the common slot array.
+__global__ __launch_bounds__(1024) void spmv_dir_dot_kernel(int N, Incidence inc, const double* __restrict__ Hval,
+                                                           const double* __restrict__ z,
+                                                           const double* __restrict__ p_old, int first,
+                                                           const double* __restrict__ rz_part_old,
+                                                           const double* __restrict__ rz_part_new,
+                                                           const double* __restrict__ w, double* __restrict__ p_new,
+                                                           double* __restrict__ q, double* __restrict__ pq_part) {
+  __shared__ double sh[32];
   double beta = 0.0;
   if (!first) {
-    const double rz_old = block_sum_parts(rz_part_old, sh);
-    const double rz_new = block_sum_parts(rz_part_new, sh);
+    double rz_old, rz_new;
+    sum_slots2(rz_part_old, rz_part_new, rz_old, rz_new, sh);
     beta = rz_new / rz_old;
   }
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int l32 = threadIdx.x & 31, hw = threadIdx.x >> 5;  // 32 half-waves per workgroup
   const int rows_per_block = (N + gridDim.x - 1) / gridDim.x;
   const int r0 = blockIdx.x * rows_per_block;
   const int r1 = min(N, r0 + rows_per_block);
   double pq = 0.0;
-  for (int i = r0 + wv; i < r1; i += 4) {
+  for (int i = r0 + hw; i < r1; i += 32) {
     const int off0 = inc.off[i], deg = inc.off[i + 1] - off0, row = 3 * deg;
     const double* Hi = Hval + (size_t)9 * off0;
     double s0 = 0.0, s1 = 0.0, s2 = 0.0;
-    for (int t = lane; t < row; t += 64) {
+    // two column rounds in flight per pass (the loads of both rounds are issued before either gather returns)
+    for (int t = l32; t < row; t += 64) {
+      const int t2 = t + 32;
+      const bool has2 = t2 < row;
+      const double h0 = Hi[t], h1 = Hi[row + t], h2 = Hi[2 * row + t];
       const int k = t / 3, e = t - 3 * k;
-      const int c = 3 * inc.cols[off0 + k] + e;
-      const double pv = first ? z[c] : (z[c] + beta * p_old[c]);
-      s0 += Hi[t] * pv;
-      s1 += Hi[row + t] * pv;
-      s2 += Hi[2 * row + t] * pv;
+      const int ca = 3 * inc.cols[off0 + k] + e;
+      double g0 = 0.0, g1 = 0.0, g2 = 0.0;
+      int cb = ca;
+      if (has2) {
+        g0 = Hi[t2];
+        g1 = Hi[row + t2];
+        g2 = Hi[2 * row + t2];
+        const int kb = t2 / 3, eb = t2 - 3 * kb;
+        cb = 3 * inc.cols[off0 + kb] + eb;
+      }
+      const double pa = first ? z[ca] : (z[ca] + beta * p_old[ca]);
+      const double pb = first ? z[cb] : (z[cb] + beta * p_old[cb]);
+      s0 += h0 * pa + g0 * pb;
+      s1 += h1 * pa + g1 * pb;
+      s2 += h2 * pa + g2 * pb;
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
+    for (int o = 16; o > 0; o >>= 1) {
       s0 += __shfl_xor(s0, o);
       s1 += __shfl_xor(s1, o);
       s2 += __shfl_xor(s2, o);
     }
-    if (lane < 3) {
-      const int c = 3 * i + lane;
+    if (l32 < 3) {
+      const int c = 3 * i + l32;
       const double pv = first ? z[c] : (z[c] + beta * p_old[c]);
-      const double sv = (lane == 0) ? s0 : ((lane == 1) ? s1 : s2);
+      const double sv = (l32 == 0) ? s0 : ((l32 == 1) ? s1 : s2);
       p_new[c] = pv;
       q[c] = sv;
       pq += (w ? w[c] : 1.0) * pv * sv;
     }
   }
-  const double r = block_reduce(pq, sh);
+  const double r = block_sum(pq, sh);
   if (threadIdx.x == 0) pq_part[blockIdx.x] = r;
 }
 
-void launch_spmv_dir_dot(hipStream_t s, int N, int n_blocks, const Incidence& inc, const double* Hval,
-                         const double* z, const double* p_old, int first, const double* rz_part_old,
-                         const double* rz_part_new, const double* w, double* p_new, double* q, double* pq_part) {
-  hipLaunchKernelGGL(spmv_dir_dot_kernel, dim3(n_blocks), dim3(256), 0, s, N, inc, Hval, z, p_old, first, rz_part_old,
-                     rz_part_new, w, p_new, q, pq_part);
+int spmv_grid(int N) { return std::max(1, std::min(kNPart, (N + 31) / 32)); }  // small meshes: one row per half-wave
+
+void launch_spmv_dir_dot(hipStream_t s, int N, const Incidence& inc, const double* Hval, const double* z,
+                         const double* p_old, int first, const double* rz_part_old, const double* rz_part_new,
+                         const double* w, double* p_new, double* q, double* pq_part) {
+  hipLaunchKernelGGL(spmv_dir_dot_kernel, dim3(spmv_grid(N)), dim3(1024), 0, s, N, inc, Hval, z, p_old, first,
+                     rz_part_old, rz_part_new, w, p_new, q, pq_part);
 }
 
 // x += alpha p ; r -= alpha q ; z = Dinv r ; partials of r.z and r.r
@@ -199,13 +244,13 @@ __global__ __launch_bounds__(256) void pcg_update_kernel(int N, const double* __
                                                         const double* __restrict__ w, const double* __restrict__ p,
                                                         const double* __restrict__ q,
                                                         const double* __restrict__ rz_part_old,
-                                                        const double* __restrict__ pq_part, int n_pq,
-                                                        double* __restrict__ x, double* __restrict__ r,
-                                                        double* __restrict__ z, double* __restrict__ rz_part_new,
+                                                        const double* __restrict__ pq_part, double* __restrict__ x,
+                                                        double* __restrict__ r, double* __restrict__ z,
+                                                        double* __restrict__ rz_part_new,
                                                         double* __restrict__ rr_part) {
-  __shared__ double sh[256];
-  const double rz_old = block_sum_parts(rz_part_old, sh);
-  const double pq = block_sum_parts(pq_part, sh, n_pq);
+  __shared__ double sh[32];
+  double rz_old, pq;
+  sum_slots2(rz_part_old, pq_part, rz_old, pq, sh);
   const double alpha = rz_old / pq;
   double rz = 0.0, rr = 0.0;
   for (int i = blockIdx.x * 256 + threadIdx.x; i < N; i += gridDim.x * 256) {
@@ -226,19 +271,19 @@ __global__ __launch_bounds__(256) void pcg_update_kernel(int N, const double* __
       rr += wd * rv[d] * rv[d];
     }
   }
-  const double a = block_reduce(rz, sh);
-  const double c = block_reduce(rr, sh);
+  block_sum2(rz, rr, sh);
   if (threadIdx.x == 0) {
-    rz_part_new[blockIdx.x] = a;
-    rr_part[blockIdx.x] = c;
+    rz_part_new[blockIdx.x] = rz;
+    rr_part[blockIdx.x] = rr;
   }
 }
 
 void launch_pcg_update(hipStream_t s, int N, const double* Dinv, const double* w, const double* p, const double* q,
-                       const double* rz_part_old, const double* pq_part, int n_pq, double* x, double* r, double* z,
+                       const double* rz_part_old, const double* pq_part, double* x, double* r, double* z,
                        double* rz_part_new, double* rr_part) {
-  hipLaunchKernelGGL(pcg_update_kernel, dim3(kNPart), dim3(256), 0, s, N, Dinv, w, p, q, rz_part_old, pq_part, n_pq,
-                     x, r, z, rz_part_new, rr_part);
+  const int n_blocks = std::max(1, std::min(kNPart, (N + 255) / 256));
+  hipLaunchKernelGGL(pcg_update_kernel, dim3(n_blocks), dim3(256), 0, s, N, Dinv, w, p, q, rz_part_old, pq_part, x, r,
+                     z, rz_part_new, rr_part);
 }
 
 // ---- Newton vector updates (SyncedNewton.cu:413-534) ---------------------------------------------

@@ -529,7 +529,7 @@ extern "C" int tlfea_newton_create(tlfea_t10_t data, int n_constraints, tlfea_ne
   TRY(dmalloc(&s->d_r, n)); TRY(dmalloc(&s->d_b, n)); TRY(dmalloc(&s->d_p, n)); TRY(dmalloc(&s->d_p2, n)); TRY(dmalloc(&s->d_q, n)); TRY(dmalloc(&s->d_zv, n));
   TRY(dmalloc(&s->d_lam, (size_t)std::max(1, n_constraints)));
   TRY(dmalloc(&s->d_xp, (size_t)s->N)); TRY(dmalloc(&s->d_yp, (size_t)s->N)); TRY(dmalloc(&s->d_zp, (size_t)s->N));
-  TRY(dmalloc(&s->d_parts, (size_t)6 * kNPart + kMaxSpmvBlocks));
+  TRY(dmalloc(&s->d_parts, (size_t)6 * kNPart));
   TRY(dmalloc(&s->d_scal, (size_t)4));
   TRY(dmalloc(&s->d_Dinv, (size_t)9 * s->N));
   for (auto& e : s->ev) HIP_TRY(hipEventCreate(&e));
@@ -756,7 +756,8 @@ static int pcg(tlfea_newton_t s, const double* d_b, double* d_x, int* iters_out,
     // the host layer passes weights and pre-sums H's boundary diagonal via tlfea_newton_iface_diag)
   }
   launch_extract_dinv(s->stream, N, d->inc(), s->d_H, s->d_Dinv);
-  launch_pcg_init(s->stream, N, d_b, s->d_Dinv, w, d_x, s->d_r, s->d_zv, s->d_p, part(s, 0), part(s, 4));
+  HIP_TRY(hipMemsetAsync(s->d_parts, 0, (size_t)5 * kNPart * sizeof(double), s->stream));
+  launch_pcg_init(s->stream, N, d_b, s->d_Dinv, w, d_x, s->d_r, s->d_zv, part(s, 0), part(s, 4));
   TRY(parts_sum(s, part(s, 0), kNPart));
   TRY(parts_sum(s, part(s, 4), kNPart));
   launch_sum_parts(s->stream, part(s, 4), s->d_scal + 1);
@@ -767,16 +768,15 @@ static int pcg(tlfea_newton_t s, const double* d_b, double* d_x, int* iters_out,
   double rr = bb;
   if (bb > 0.0) {
     const double target = s->lin.rel_tol * s->lin.rel_tol * bb;
-    const int n_blk = std::min(kMaxSpmvBlocks, (N + 3) / 4);
-    double* pq_part = s->d_parts + (size_t)6 * kNPart;
+    double* pq_part = part(s, 2);
     int cur = 0;  // which rz partial buffer is "old"
     double *p_old = s->d_p, *p_new = s->d_p2;
     // state entering iteration k: z, r, rz partials in part(cur) [and part(1-cur) = previous, for beta]
     while (it < s->lin.max_iter) {
       if (s->profiling) (void)hipEventRecord(s->ev[4], s->stream);
       // beta = rz(cur)/rz(1-cur); p_new = z + beta p_old; q = H p_new; partials of p_new.q
-      launch_spmv_dir_dot(s->stream, N, n_blk, d->inc(), s->d_H, s->d_zv, p_old, it == 0, part(s, 1 - cur),
-                          part(s, cur), w, p_new, s->d_q, pq_part);
+      launch_spmv_dir_dot(s->stream, N, d->inc(), s->d_H, s->d_zv, p_old, it == 0, part(s, 1 - cur), part(s, cur), w,
+                          p_new, s->d_q, pq_part);
       if (s->profiling) {
         (void)hipEventRecord(s->ev[5], s->stream);
         (void)hipEventSynchronize(s->ev[5]);
@@ -787,11 +787,11 @@ static int pcg(tlfea_newton_t s, const double* d_b, double* d_x, int* iters_out,
       }
       if (s->ar) {
         TRY(iface_sum(s, s->d_q));
-        TRY(parts_sum(s, pq_part, n_blk));
+        TRY(parts_sum(s, pq_part, kNPart));
       }
       // alpha = rz(cur)/pq; x += alpha p; r -= alpha q; z = Dinv r; new rz partials into part(1-cur)
-      launch_pcg_update(s->stream, N, s->d_Dinv, w, p_new, s->d_q, part(s, cur), pq_part, n_blk, d_x, s->d_r,
-                        s->d_zv, part(s, 1 - cur), part(s, 3));
+      launch_pcg_update(s->stream, N, s->d_Dinv, w, p_new, s->d_q, part(s, cur), pq_part, d_x, s->d_r, s->d_zv,
+                        part(s, 1 - cur), part(s, 3));
       if (s->ar) {
         TRY(parts_sum(s, part(s, 1 - cur), kNPart));
         TRY(parts_sum(s, part(s, 3), kNPart));

@@ -76,14 +76,13 @@ void launch_norm2(hipStream_t s, const double* a, const double* w /*weights or n
                   double* out /*device scalar: sum of squares*/);
 void launch_extract_dinv(hipStream_t s, int N, const Incidence& inc, const double* Hval, double* Dinv);
 void launch_pcg_init(hipStream_t s, int N, const double* b, const double* Dinv, const double* w, double* x,
-                     double* r, double* z, double* p, double* rz_part, double* bb_part);
-constexpr int kMaxSpmvBlocks = 1024;
-void launch_spmv_dir_dot(hipStream_t s, int N, int n_blocks, const Incidence& inc, const double* Hval,
-                         const double* z, const double* p_old, int first, const double* rz_part_old,
-                         const double* rz_part_new, const double* w, double* p_new, double* q, double* pq_part);
-void launch_pcg_update(hipStream_t s, int N, const double* Dinv, const double* w, const double* p,
-                       const double* q, const double* rz_part_old, const double* pq_part, int n_pq, double* x,
-                       double* r, double* z, double* rz_part_new, double* rr_part);
+                     double* r, double* z, double* rz_part, double* bb_part);
+void launch_spmv_dir_dot(hipStream_t s, int N, const Incidence& inc, const double* Hval, const double* z,
+                         const double* p_old, int first, const double* rz_part_old, const double* rz_part_new,
+                         const double* w, double* p_new, double* q, double* pq_part);
+void launch_pcg_update(hipStream_t s, int N, const double* Dinv, const double* w, const double* p, const double* q,
+                       const double* rz_part_old, const double* pq_part, double* x, double* r, double* z,
+                       double* rz_part_new, double* rr_part);
 void launch_sum_parts(hipStream_t s, const double* part, double* out);
 void launch_newton_update(hipStream_t s, int N, const double* dv, double* v, const double* xp, const double* yp,
                           const double* zp, double h, double* x, double* y, double* z);
