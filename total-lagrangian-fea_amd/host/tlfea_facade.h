@@ -1,0 +1,328 @@
+// tlfea_facade.h -- header-only C++ facade re-creating the reference's class surface on the C-ABI
+// (include/tlfea_c.h): ElementBase / GPU_FEAT10_Data (lib_src/elements/ElementBase.h:20-50,
+// FEAT10Data.cuh:306-852), SolverBase / SyncedNewtonParams / SyncedNewtonSolver
+// (lib_src/solvers/SolverBase.h:16-23, SyncedNewton.cuh:29-405), Quadrature::tet5pt_*
+// (lib_utils/quadrature_utils.h:134-158) and ANCFCPUUtils::FEAT10_read_* (lib_utils/cpu_utils.cc:607-754).
+// Same method names, argument order and call-order contract; Eigen types become tlfea::VectorXd etc.
+// Error convention of the reference (lib_utils/cuda_utils.h:12-18): device/library failure -> message + exit.
+#pragma once
+#include <algorithm>
+#include <climits>
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <iostream>
+#include <sstream>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "../../include/tlfea_c.h"
+#include "tlfea_containers.h"
+
+#define TLFEA_HANDLE_ERROR(call)                                                              \
+  do {                                                                                        \
+    if ((call) != 0) {                                                                        \
+      std::fprintf(stderr, "%s in %s at line %d\n", tlfea_last_error(), __FILE__, __LINE__);  \
+      std::exit(EXIT_FAILURE);                                                                \
+    }                                                                                         \
+  } while (0)
+// API misuse: the reference prints and returns (e.g. FEAT10Data.cuh:442-445); the C-ABI already printed.
+#define TLFEA_SOFT(call) (void)(call)
+
+namespace Quadrature {  // quadrature_utils.h:134-158
+constexpr int N_QP_T10_5 = 5;
+constexpr int N_NODE_T10_10 = 10;
+inline tlfea::VectorXd make5(const double (&a)[5]) {
+  tlfea::VectorXd v(5);
+  for (int i = 0; i < 5; i++) v(i) = a[i];
+  return v;
+}
+static const double kB = 1.0 / 6.0;
+static const tlfea::VectorXd tet5pt_x = make5({0.25, kB, 0.5, kB, kB});
+static const tlfea::VectorXd tet5pt_y = make5({0.25, kB, kB, 0.5, kB});
+static const tlfea::VectorXd tet5pt_z = make5({0.25, kB, kB, kB, 0.5});
+static const tlfea::VectorXd tet5pt_weights =
+    make5({-4.0 / 5.0 * kB, 9.0 / 20.0 * kB, 9.0 / 20.0 * kB, 9.0 / 20.0 * kB, 9.0 / 20.0 * kB});
+}  // namespace Quadrature
+
+namespace ANCFCPUUtils {  // cpu_utils.cc:607-754
+inline void FEAT10_remap_tetgen_indices(const tlfea::VectorXi& tetgen_elem, tlfea::VectorXi& standard_elem) {
+  if (tetgen_elem.size() != 10 || standard_elem.size() != 10) {
+    std::cerr << "Error: Element arrays must have size 10 for T10 elements" << std::endl;
+    return;
+  }
+  static const int map[10] = {0, 1, 2, 3, 6, 7, 9, 5, 8, 4};
+  for (int i = 0; i < 10; i++) standard_elem(i) = tetgen_elem(map[i]);
+}
+
+inline int FEAT10_read_nodes(const std::string& filename, tlfea::MatrixXd& nodes) {
+  std::ifstream file(filename);
+  if (!file.is_open()) {
+    std::cerr << "Error: Could not open node file " << filename << std::endl;
+    return 0;
+  }
+  std::string line;
+  if (!std::getline(file, line)) return 0;
+  std::istringstream header(line);
+  int n_nodes = 0, dim = 0;
+  header >> n_nodes >> dim;
+  if (dim != 3) {
+    std::cerr << "Error: Only 3D nodes are supported, found " << dim << "D" << std::endl;
+    return 0;
+  }
+  nodes.resize(n_nodes, 3);
+  int min_id = INT_MAX;
+  std::vector<std::tuple<int, double, double, double>> rows;
+  for (int i = 0; i < n_nodes; i++) {
+    if (!std::getline(file, line) || line.empty()) continue;
+    std::istringstream iss(line);
+    int id;
+    double x, y, z;
+    if (iss >> id >> x >> y >> z) {
+      min_id = std::min(min_id, id);
+      rows.emplace_back(id, x, y, z);
+    }
+  }
+  const int off = (min_id == 0) ? 0 : 1;  // adaptive 0/1-based ids
+  for (const auto& r : rows) {
+    const int idx = std::get<0>(r) - off;
+    if (idx >= 0 && idx < n_nodes) {
+      nodes(idx, 0) = std::get<1>(r);
+      nodes(idx, 1) = std::get<2>(r);
+      nodes(idx, 2) = std::get<3>(r);
+    }
+  }
+  return n_nodes;
+}
+
+inline int FEAT10_read_elements(const std::string& filename, tlfea::MatrixXi& elements) {
+  std::ifstream file(filename);
+  if (!file.is_open()) {
+    std::cerr << "Error: Could not open element file " << filename << std::endl;
+    return 0;
+  }
+  std::string line;
+  if (!std::getline(file, line)) return 0;
+  std::istringstream header(line);
+  int n_elements = 0, npe = 0;
+  header >> n_elements >> npe;
+  if (npe != 10) {
+    std::cerr << "Error: Only T10 elements (10 nodes) are supported, found " << npe << std::endl;
+    return 0;
+  }
+  elements.resize(n_elements, 10);
+  int min_e = INT_MAX, min_n = INT_MAX;
+  std::vector<std::vector<int>> rows;
+  for (int i = 0; i < n_elements; i++) {
+    if (!std::getline(file, line) || line.empty()) continue;
+    std::istringstream iss(line);
+    std::vector<int> r(11, 0);
+    iss >> r[0];
+    min_e = std::min(min_e, r[0]);
+    for (int j = 0; j < 10; j++)
+      if (iss >> r[1 + j]) min_n = std::min(min_n, r[1 + j]);
+    rows.push_back(r);
+  }
+  const int eoff = (min_e == 0) ? 0 : 1, noff = (min_n == 0) ? 0 : 1;
+  tlfea::VectorXi t(10), s(10);
+  for (const auto& r : rows) {
+    for (int j = 0; j < 10; j++) t(j) = r[1 + j] - noff;
+    FEAT10_remap_tetgen_indices(t, s);
+    const int e = r[0] - eoff;
+    if (e >= 0 && e < n_elements)
+      for (int j = 0; j < 10; j++) elements(e, j) = s(j);
+  }
+  return n_elements;
+}
+}  // namespace ANCFCPUUtils
+
+enum ElementType { TYPE_3243, TYPE_3443, TYPE_T10 };  // ElementBase.h:20
+
+class ElementBase {  // ElementBase.h:22-50 (host-side virtuals only)
+ public:
+  ElementType type;
+  virtual ~ElementBase() {}
+  virtual int get_n_beam() const = 0;
+  virtual int get_n_coef() const = 0;
+  virtual void CalcMassMatrix() = 0;
+  virtual void CalcInternalForce() = 0;
+  virtual void CalcConstraintData() = 0;
+  virtual void CalcP() = 0;
+  virtual void RetrieveInternalForceToCPU(tlfea::VectorXd& internal_force) = 0;
+  virtual void RetrievePositionToCPU(tlfea::VectorXd& x12, tlfea::VectorXd& y12, tlfea::VectorXd& z12) = 0;
+};
+
+struct GPU_FEAT10_Data : public ElementBase {
+  GPU_FEAT10_Data(int num_elements, int num_nodes) : n_elem(num_elements), n_coef(num_nodes) { type = TYPE_T10; }
+
+  void Initialize() { TLFEA_HANDLE_ERROR(tlfea_t10_create(n_elem, n_coef, &h)); }
+  void Destroy() {
+    TLFEA_HANDLE_ERROR(tlfea_t10_destroy(h));
+    h = nullptr;
+  }
+  void Setup(const tlfea::VectorXd& tet5pt_x_host, const tlfea::VectorXd& tet5pt_y_host,
+             const tlfea::VectorXd& tet5pt_z_host, const tlfea::VectorXd& tet5pt_weights_host,
+             const tlfea::VectorXd& h_x12, const tlfea::VectorXd& h_y12, const tlfea::VectorXd& h_z12,
+             const tlfea::MatrixXi& element_connectivity) {
+    TLFEA_SOFT(tlfea_t10_setup(h, tet5pt_x_host.data(), tet5pt_y_host.data(), tet5pt_z_host.data(),
+                               tet5pt_weights_host.data(), h_x12.data(), h_y12.data(), h_z12.data(),
+                               element_connectivity.data()));  // column-major E x 10, like Eigen::MatrixXi
+  }
+  void SetDensity(double rho0) { TLFEA_SOFT(tlfea_t10_set_density(h, rho0)); }
+  void SetDamping(double eta_damp, double lambda_damp) { TLFEA_SOFT(tlfea_t10_set_damping(h, eta_damp, lambda_damp)); }
+  void SetSVK() { TLFEA_SOFT(tlfea_t10_set_svk_select(h)); }
+  void SetSVK(double E, double nu) { TLFEA_SOFT(tlfea_t10_set_svk(h, E, nu)); }
+  void SetMooneyRivlin(double mu10, double mu01, double kappa) {
+    TLFEA_SOFT(tlfea_t10_set_mooney_rivlin(h, mu10, mu01, kappa));
+  }
+  void SetExternalForce(const tlfea::VectorXd& h_f_ext) {
+    TLFEA_SOFT(tlfea_t10_set_external_force(h, h_f_ext.data(), h_f_ext.size()));
+  }
+  void SetNodalFixed(const tlfea::VectorXi& fixed_nodes) {
+    TLFEA_SOFT(tlfea_t10_set_nodal_fixed(h, fixed_nodes.data(), fixed_nodes.size()));
+    n_constraint = tlfea_t10_get_n_constraint(h);
+  }
+  void UpdateNodalFixed(const tlfea::VectorXi& fixed_nodes) {
+    TLFEA_SOFT(tlfea_t10_update_nodal_fixed(h, fixed_nodes.data(), fixed_nodes.size()));
+    n_constraint = tlfea_t10_get_n_constraint(h);
+  }
+  void UpdatePositions(const tlfea::VectorXd& x, const tlfea::VectorXd& y, const tlfea::VectorXd& z) {
+    TLFEA_SOFT(tlfea_t10_update_positions(h, x.data(), y.data(), z.data(), x.size()));
+  }
+  void UpdateConstraintTargets(const tlfea::VectorXd& x, const tlfea::VectorXd& y, const tlfea::VectorXd& z) {
+    TLFEA_SOFT(tlfea_t10_update_constraint_targets(h, x.data(), y.data(), z.data(), x.size()));
+  }
+
+  void CalcDnDuPre() { TLFEA_HANDLE_ERROR(tlfea_t10_calc_dndu_pre(h)); }
+  void CalcMassMatrix() override { TLFEA_HANDLE_ERROR(tlfea_t10_calc_mass_matrix(h)); }
+  void BuildMassCSRPattern() { TLFEA_HANDLE_ERROR(tlfea_t10_build_mass_csr_pattern(h)); }
+  void ConvertToCSR_ConstraintJacT() { TLFEA_HANDLE_ERROR(tlfea_t10_convert_to_csr_constraint_jact(h)); }
+  void BuildConstraintJacobianTransposeCSR() { ConvertToCSR_ConstraintJacT(); }
+  void ConvertToCSR_ConstraintJac() { TLFEA_HANDLE_ERROR(tlfea_t10_convert_to_csr_constraint_jac(h)); }
+  void BuildConstraintJacobianCSR() { ConvertToCSR_ConstraintJac(); }
+  void CalcInternalForce() override { TLFEA_HANDLE_ERROR(tlfea_t10_calc_internal_force(h)); }
+  void CalcConstraintData() override { TLFEA_SOFT(tlfea_t10_calc_constraint_data(h)); }
+  void CalcP() override { TLFEA_HANDLE_ERROR(tlfea_t10_calc_p(h)); }
+
+  void RetrieveMassCSRToCPU(std::vector<int>& offsets, std::vector<int>& columns, std::vector<double>& values) {
+    int nnz = 0;
+    TLFEA_HANDLE_ERROR(tlfea_t10_mass_csr_nnz(h, &nnz));
+    offsets.assign(static_cast<size_t>(n_coef) + 1, 0);
+    columns.assign(static_cast<size_t>(nnz), 0);
+    values.assign(static_cast<size_t>(nnz), 0.0);
+    TLFEA_HANDLE_ERROR(tlfea_t10_retrieve_mass_csr(h, offsets.data(), columns.data(), values.data()));
+  }
+  void RetrieveInternalForceToCPU(tlfea::VectorXd& f) override {
+    f.resize(3 * n_coef);
+    TLFEA_HANDLE_ERROR(tlfea_t10_retrieve_internal_force(h, f.data()));
+  }
+  void RetrieveExternalForceToCPU(tlfea::VectorXd& f) {
+    f.resize(3 * n_coef);
+    TLFEA_HANDLE_ERROR(tlfea_t10_retrieve_external_force(h, f.data()));
+  }
+  void RetrievePositionToCPU(tlfea::VectorXd& x, tlfea::VectorXd& y, tlfea::VectorXd& z) override {
+    x.resize(n_coef);
+    y.resize(n_coef);
+    z.resize(n_coef);
+    TLFEA_HANDLE_ERROR(tlfea_t10_retrieve_position(h, x.data(), y.data(), z.data()));
+  }
+  void RetrievePFromFToCPU(std::vector<std::vector<tlfea::MatrixXd>>& P) { retrieve33(P, true); }
+  void RetrieveDeformationGradientToCPU(std::vector<std::vector<tlfea::MatrixXd>>& F) { retrieve33(F, false); }
+  void RetrieveDnDuPreToCPU(std::vector<std::vector<tlfea::MatrixXd>>& g) {
+    std::vector<double> flat(static_cast<size_t>(n_elem) * 150);
+    TLFEA_HANDLE_ERROR(tlfea_t10_retrieve_dndu_pre(h, flat.data()));
+    g.assign(n_elem, std::vector<tlfea::MatrixXd>(5));
+    for (int e = 0; e < n_elem; e++)
+      for (int q = 0; q < 5; q++) {
+        g[e][q].resize(10, 3);
+        std::copy_n(flat.data() + (static_cast<size_t>(e) * 5 + q) * 30, 30, g[e][q].data());
+      }
+  }
+  void RetrieveDetJToCPU(std::vector<std::vector<double>>& detJ) {
+    std::vector<double> flat(static_cast<size_t>(n_elem) * 5);
+    TLFEA_HANDLE_ERROR(tlfea_t10_retrieve_detj(h, flat.data()));
+    detJ.assign(n_elem, std::vector<double>(5));
+    for (int e = 0; e < n_elem; e++) std::copy_n(flat.data() + 5 * e, 5, detJ[e].data());
+  }
+  void RetrieveConnectivityToCPU(tlfea::MatrixXi& connectivity) {
+    connectivity.resize(n_elem, 10);
+    TLFEA_HANDLE_ERROR(tlfea_t10_retrieve_connectivity(h, connectivity.data()));
+  }
+  void WriteOutputVTK(const std::string& filename) { TLFEA_HANDLE_ERROR(tlfea_t10_write_output_vtk(h, filename.c_str())); }
+
+  const double* GetX12DevicePtr() const { return tlfea_t10_x12_device_ptr(h); }
+  const double* GetY12DevicePtr() const { return tlfea_t10_y12_device_ptr(h); }
+  const double* GetZ12DevicePtr() const { return tlfea_t10_z12_device_ptr(h); }
+  double* GetExternalForceDevicePtr() { return tlfea_t10_external_force_device_ptr(h); }
+  double* Get_Constraint_Ptr() { return tlfea_t10_constraint_device_ptr(h); }
+  bool Get_Is_Constraint_Setup() { return tlfea_t10_is_constraint_setup(h) != 0; }
+  int get_n_elem() const { return n_elem; }
+  int get_n_coef() const override { return n_coef; }
+  int get_n_constraint() const { return n_constraint; }
+  int get_n_beam() const override { return n_elem; }
+
+  tlfea_t10_t h = nullptr;  // stands where the reference keeps its device mirror `d_data`
+  int n_elem;
+  int n_coef;
+  int n_constraint = 0;  // the reference leaves this uninitialised until SetNodalFixed (FEAT10Data.cuh:793)
+
+ private:
+  void retrieve33(std::vector<std::vector<tlfea::MatrixXd>>& out, bool P) {
+    std::vector<double> flat(static_cast<size_t>(n_elem) * 45);
+    TLFEA_HANDLE_ERROR(P ? tlfea_t10_retrieve_p_from_f(h, flat.data())
+                         : tlfea_t10_retrieve_deformation_gradient(h, flat.data()));
+    out.assign(n_elem, std::vector<tlfea::MatrixXd>(5));
+    for (int e = 0; e < n_elem; e++)
+      for (int q = 0; q < 5; q++) {
+        out[e][q].resize(3, 3);
+        std::copy_n(flat.data() + (static_cast<size_t>(e) * 5 + q) * 9, 9, out[e][q].data());
+      }
+  }
+};
+
+class SolverBase {  // SolverBase.h:16-23
+ public:
+  virtual ~SolverBase() = default;
+  virtual void Solve() = 0;
+  virtual void SetParameters(void* params) = 0;
+};
+
+struct SyncedNewtonParams {  // SyncedNewton.cuh:29-33
+  double inner_atol, inner_rtol, outer_tol, rho;
+  int max_outer, max_inner;
+  double time_step;
+};
+
+class SyncedNewtonSolver : public SolverBase {
+ public:
+  SyncedNewtonSolver(ElementBase* data, int n_constraints) {
+    if (data->type != TYPE_T10) {
+      std::cerr << "Unknown element type!" << std::endl;  // SyncedNewton.cuh:78-81 (3243/3443: next rounds)
+      return;
+    }
+    TLFEA_HANDLE_ERROR(tlfea_newton_create(static_cast<GPU_FEAT10_Data*>(data)->h, n_constraints, &s_));
+  }
+  ~SyncedNewtonSolver() override { tlfea_newton_destroy(s_); }
+  void Setup() { TLFEA_HANDLE_ERROR(tlfea_newton_setup(s_)); }
+  void SetParameters(void* params) override {
+    const SyncedNewtonParams* p = static_cast<SyncedNewtonParams*>(params);
+    tlfea_newton_params c{p->inner_atol, p->inner_rtol, p->outer_tol, p->rho, p->max_outer, p->max_inner, p->time_step};
+    TLFEA_HANDLE_ERROR(tlfea_newton_set_parameters(s_, &c));
+  }
+  void AnalyzeHessianSparsity() { TLFEA_HANDLE_ERROR(tlfea_newton_analyze_hessian_sparsity(s_)); }
+  void SetFixedSparsityPattern(bool fixed) { TLFEA_HANDLE_ERROR(tlfea_newton_set_fixed_sparsity_pattern(s_, fixed)); }
+  void OneStepNewtonCuDSS() { TLFEA_HANDLE_ERROR(tlfea_newton_solve(s_)); }  // name kept for drop-in; solves with PCG
+  void Solve() override { OneStepNewtonCuDSS(); }
+  double* GetVelocityGuessDevicePtr() const { return tlfea_newton_velocity_guess_device_ptr(s_); }
+  double compute_l2_norm_cublas(double* d_vec, int n_dofs) {
+    double out = 0.0;
+    TLFEA_HANDLE_ERROR(tlfea_newton_l2_norm(s_, d_vec, n_dofs, &out));
+    return out;
+  }
+  void SetVerbose(int v) { tlfea_newton_set_verbose(s_, v); }
+  tlfea_newton_t handle() { return s_; }
+
+ private:
+  tlfea_newton_t s_ = nullptr;
+};
