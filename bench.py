@@ -73,12 +73,16 @@ def main():
     nx = cfg["cells"][0]
     # weak scaling: every rank owns one full-size x-slab of a bar `world` times as long
     w = wl.build(args.config, cells=cfg["cells"], x_offset_cells=rank * nx)
+    part = None
     if world > 1:
         par.restrict_bcs_to_global_ends(w, rank, world, cfg)
+        lx = cfg["size"][0]
+        part = par.slab_partition_structured(w["X"], lx * rank, lx * (rank + 1), rank, world)
+        w["f_ext"] = (w["f_ext"].reshape(-1, 3) * part.node_weight[:, None]).reshape(-1)  # this rank's share
     d, s = wl.make_engine(tl, w)
     s.SetLinSolveOpts(tl.LinSolveOpts(args.rel_tol, 50000, 25))
     if world > 1:
-        par.attach_slab_interfaces(tl, s, w, rank, world, torch, dist)
+        par.attach(s, part, torch, dist)
     d.UpdatePositions(w["x0"][:, 0], w["x0"][:, 1], w["x0"][:, 2])
     E, N = w["conn"].shape[0], w["X"].shape[0]
     nnz_coef = int(d.RetrieveMassCSRToCPU()[0][-1])

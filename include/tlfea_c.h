@@ -153,14 +153,20 @@ int tlfea_newton_set_verbose(tlfea_newton_t s, int verbose);
 /* per-stage hipEvent timing for tlfea_newton_get_stage_ms (one host sync per stage; off by default) */
 int tlfea_newton_set_profiling(tlfea_newton_t s, int on);
 
-/* Multi-GPU hook: partition-boundary exchange.  When set, the solver calls `fn(user, d_buf, n)`
- * (device buffer of n doubles, packed interface DOFs) wherever the path needs the sum over ranks:
- * after the f_int gather, after every SpMV, and for the 2-3 scalars of each reduction.  The Python
- * host layer points it at torch.distributed.all_reduce (RCCL over xGMI). */
+/* Multi-GPU hook: partition-boundary exchange (one process per GPU; elements are owned by one rank, nodes on
+ * partition boundaries are replicated).  `iface_nodes[k]` (local node id) sits at `iface_slots[k]` of a GLOBAL
+ * interface list of `n_global` nodes that is identical on every rank; `node_weight[i]` = 1/(number of ranks
+ * holding node i).  The solver then calls `fn(user, d_buf, n)` -- in-place SUM over ranks of a device buffer
+ * of n doubles -- exactly where the path needs it: once for the gradient (boundary DOFs), once for the
+ * boundary diagonal blocks, and twice per CG iteration (boundary rows of H p fused with the p.Hp slots; the
+ * r.z / r.r slots).  The Python host layer points fn at torch.distributed.all_reduce (RCCL over xGMI, or
+ * gloo through a host staging copy).  f_ext must already be this rank's share (weight-scaled on replicated
+ * nodes).  sync_before_callback=1 drains the stream before every call (needed unless fn enqueues on the
+ * null stream, as torch's default stream does). */
 typedef int (*tlfea_allreduce_fn)(void *user, double *d_buf, int n);
-int tlfea_newton_set_interface(tlfea_newton_t s, const int *iface_dofs, int n_iface,
-                               const double *dof_weight /*3N, 1/multiplicity*/,
-                               tlfea_allreduce_fn fn, void *user);
+int tlfea_newton_set_interface(tlfea_newton_t s, const int *iface_nodes, const int *iface_slots, int n_local,
+                               int n_global, const double *node_weight /*N*/, tlfea_allreduce_fn fn,
+                               void *user, int sync_before_callback);
 
 #ifdef __cplusplus
 }

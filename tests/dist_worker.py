@@ -1,0 +1,216 @@
+"""Worker of the world_size>1 tests (launched by tests/test_distributed.py through torch.distributed.run).
+
+  --engine oracle : every rank runs the CPU oracle on its sub-mesh; the partition / interface / weight logic of
+                    total-lagrangian-fea_amd/partition.py and the exchange points of the path are exercised with
+                    gloo on CPU.
+  --engine hip    : every rank drives the product path (libtlfea_hip.so) on cuda:0 with the same partition; the
+                    collectives go through gloo with a host staging copy (one-GPU box), the code path in the
+                    library is the one RCCL uses.
+Rank 0 also solves the un-partitioned problem with the oracle and checks nodal positions."""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from oracle import orc  # noqa: E402
+from tests import helpers  # noqa: E402
+
+par = __import__("importlib").import_module("total-lagrangian-fea_amd.partition")
+tl = helpers.tl
+
+
+def problem(name):
+    if name == "box":
+        X, conn = tl.mesh_utils.structured_t10_box(4, 2, 2, 2.0, 1.0, 1.0)
+        lx = 2.0
+    else:
+        X, conn = helpers.load_mesh(name)
+        lx = X[:, 0].max()
+    fixed = np.where(np.abs(X[:, 0]) < 1e-8)[0].astype(np.int32)
+    f_ext = np.zeros(3 * X.shape[0])
+    face = np.where(np.abs(X[:, 0] - lx) < 1e-8)[0]
+    f_ext[3 * face] = 5000.0 / len(face)
+    f_ext[3 * face + 2] = -1500.0 / len(face)
+    return X, conn, fixed, f_ext
+
+
+class Exchange:
+    def __init__(self, part, torch, dist):
+        self.p, self.torch, self.dist = part, torch, dist
+
+    def iface_sum(self, vec, dim):
+        p = self.p
+        buf = np.zeros(dim * p.n_global_iface)
+        idx_b = (dim * p.iface_slots[:, None] + np.arange(dim)[None, :]).reshape(-1)
+        idx_v = (dim * p.iface_nodes[:, None] + np.arange(dim)[None, :]).reshape(-1)
+        buf[idx_b] = vec[idx_v]
+        t = self.torch.from_numpy(buf)
+        self.dist.all_reduce(t)
+        vec[idx_v] = buf[idx_b]
+
+    def scalar_sum(self, v):
+        t = self.torch.tensor([v], dtype=self.torch.float64)
+        self.dist.all_reduce(t)
+        return float(t[0])
+
+
+def oracle_dist_step(o, part, ex, prm, f_share):
+    """ALM/Newton step of SyncedNewton.cu:1032-1146 on a partitioned mesh, oracle as the local engine."""
+    import ctypes as C
+    import scipy.sparse as sp
+    L = orc.lib()
+    N, h, rho = o.N, prm.time_step, prm.rho
+    w3 = np.repeat(part.node_weight, 3)
+    fixed = o.fixed
+    fdofs = (3 * fixed[:, None] + np.arange(3)[None, :]).reshape(-1)
+    wc = np.repeat(part.node_weight[fixed], 3)
+    none = np.zeros(0, dtype=np.int32)
+    xp = (o.x.copy(), o.y.copy(), o.z.copy())
+    n_outer = n_newton = 0
+    for outer in range(prm.max_outer):
+        n_outer += 1
+        ng0 = -1.0
+        for it in range(prm.max_inner):
+            f_int = o.internal_force(o.v)
+            g = np.zeros(3 * N)
+            L.orc_grad_L(N, orc.ip(o.m_off), orc.ip(o.m_col), orc.dp(o.m_val), orc.dp(o.v), orc.dp(o.v_prev),
+                         orc.dp(f_int), orc.dp(f_share), orc.ip(none), 0, None, None, C.c_double(h), C.c_double(rho),
+                         orc.dp(g))
+            c = o.constraint()
+            g[fdofs] += wc * h * (o.lam + rho * c)
+            ex.iface_sum(g, 3)
+            ng = np.sqrt(ex.scalar_sum(float(np.sum(w3 * g * g))))
+            if ng0 < 0:
+                ng0 = ng
+            if ng < prm.inner_atol or (prm.inner_rtol > 0 and ng0 > 0 and ng <= prm.inner_rtol * ng0):
+                break
+            keep = o.fixed
+            o.fixed = none
+            ro, ci, val = o.assemble_hessian(h, rho)
+            o.fixed = keep
+            H = sp.csr_matrix((val, ci, ro), shape=(3 * N, 3 * N)).tolil()
+            for k, dof in enumerate(fdofs):
+                H[dof, dof] += wc[k] * h * h * rho
+            H = H.tocsr()
+            # block-Jacobi PCG with interface sums (same exchange points as the device solver)
+            D = np.zeros(9 * N)
+            for i in range(N):
+                D[9 * i:9 * i + 9] = H[3 * i:3 * i + 3, 3 * i:3 * i + 3].toarray().reshape(-1)
+            ex.iface_sum(D, 9)
+            Dinv = np.linalg.inv(D.reshape(N, 3, 3))
+            b = -g
+            x = np.zeros(3 * N)
+            r = b.copy()
+            z = np.einsum("nij,nj->ni", Dinv, r.reshape(N, 3)).reshape(-1)
+            p = z.copy()
+            rz = ex.scalar_sum(float(np.sum(w3 * r * z)))
+            bb = ex.scalar_sum(float(np.sum(w3 * b * b)))
+            for _ in range(20000):
+                q = H @ p
+                ex.iface_sum(q, 3)
+                alpha = rz / ex.scalar_sum(float(np.sum(w3 * p * q)))
+                x += alpha * p
+                r -= alpha * q
+                z = np.einsum("nij,nj->ni", Dinv, r.reshape(N, 3)).reshape(-1)
+                rz_new = ex.scalar_sum(float(np.sum(w3 * r * z)))
+                rr = ex.scalar_sum(float(np.sum(w3 * r * r)))
+                if rr <= 1e-26 * bb:
+                    break
+                p = z + (rz_new / rz) * p
+                rz = rz_new
+            n_newton += 1
+            o.v += x
+            o.x, o.y, o.z = xp[0] + h * o.v[0::3], xp[1] + h * o.v[1::3], xp[2] + h * o.v[2::3]
+        o.v_prev = o.v.copy()
+        c = o.constraint()
+        o.lam += rho * c
+        if len(c):
+            nc = np.sqrt(ex.scalar_sum(float(np.sum(wc * c * c))))
+        else:
+            nc = np.sqrt(ex.scalar_sum(0.0))
+        if ex.scalar_sum(float(len(c))) > 0 and nc < prm.outer_tol:
+            break
+    return n_outer, n_newton
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--engine", default="oracle")
+    ap.add_argument("--mesh", default="box")
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--out", default="")
+    args = ap.parse_args()
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    X, conn, fixed, f_ext = problem(args.mesh)
+    m = helpers.MATERIALS["svk"]
+    owner = par.slab_owner(X, conn, world)
+    part = par.partition_from_global(X, conn, owner, rank, world)
+    fixed_loc = part.localize_nodes(fixed)
+    f_share = part.share_of_nodal_vector(f_ext)
+    prm = orc.NewtonParams(1e-6, 0.0, 1e-6, 1e14, 5, 12, 1e-3)
+
+    if args.engine == "oracle":
+        o = helpers.make_oracle(part.X, part.conn, m, fixed_loc, f_share)
+        ex = Exchange(part, torch, dist)
+        counts = [oracle_dist_step(o, part, ex, prm, f_share) for _ in range(args.steps)]
+        x_loc = np.stack([o.x, o.y, o.z], axis=1)
+    else:
+        torch.cuda.set_device(0)
+        d = helpers.make_gpu(part.X, part.conn, m, fixed_loc, f_share)
+        s = tl.SyncedNewtonSolver(d, d.get_n_constraint())
+        s.SetParameters(tl.SyncedNewtonParams(1e-6, 0.0, 1e-6, 1e14, 5, 12, 1e-3))
+        s.SetLinSolveOpts(tl.LinSolveOpts(1e-13, 20000, 10))
+        par.attach(s, part, torch, dist)
+        counts = []
+        for _ in range(args.steps):
+            s.Solve()
+            st = s.GetStats()
+            counts.append((st["outer"], st["newton"]))
+        x_loc = np.stack(d.RetrievePositionToCPU(), axis=1)
+        del s
+        d.Destroy()
+
+    gathered = [None] * world
+    dist.all_gather_object(gathered, (part.l2g, x_loc))
+    ok = True
+    report = {}
+    if rank == 0:
+        xg = np.full_like(X, np.nan)
+        max_dup = 0.0
+        for l2g, xl in gathered:
+            seen = ~np.isnan(xg[l2g, 0])
+            if seen.any():
+                max_dup = max(max_dup, float(np.max(np.abs(xg[l2g][seen] - xl[seen]))))
+            xg[l2g] = xl
+        o1 = helpers.make_oracle(X, conn, m, fixed, f_ext)
+        ref_counts = []
+        for _ in range(args.steps):
+            st = o1.newton_step(prm, solver=0)
+            ref_counts.append((int(st[0]), int(st[1])))
+        xo = np.stack([o1.x, o1.y, o1.z], axis=1)
+        disp = float(np.max(np.abs(xo - X)))
+        err = float(np.max(np.abs(xg - xo)))
+        floor = 8 * np.finfo(np.float64).eps * float(np.max(np.abs(xo)))
+        ok = bool(err <= 1e-10 * disp + floor and max_dup <= floor and not np.isnan(xg).any()
+                  and [tuple(c) for c in counts] == ref_counts)
+        report = dict(err=err, disp=disp, max_dup=max_dup, counts=counts, ref_counts=ref_counts, ok=ok,
+                      n_iface=part.n_global_iface)
+        print(json.dumps(report), flush=True)
+        if args.out:
+            json.dump(report, open(args.out, "w"))
+    flag = torch.tensor([1 if ok else 0])
+    dist.broadcast(flag, 0)
+    dist.destroy_process_group()
+    sys.exit(0 if int(flag[0]) == 1 else 1)
+
+
+if __name__ == "__main__":
+    main()

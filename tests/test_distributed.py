@@ -1,0 +1,90 @@
+"""world_size>1 coverage of the partitioned path.  CPU: gloo + oracle engine.
+GPU box: two ranks on the one GPU driving libtlfea_hip.so, gloo with a host staging copy."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from tests.helpers import load_mesh, tl
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+par = __import__("importlib").import_module("total-lagrangian-fea_amd.partition")
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch(world, extra, tmp_path, timeout=600):
+    out = tmp_path / "report.json"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
+           os.path.join(ROOT, "tests", "dist_worker.py"), "--out", str(out)] + extra
+    env = dict(os.environ, OMP_NUM_THREADS="2", MASTER_ADDR="127.0.0.1")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    return json.load(open(out))
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_partition_bookkeeping(world):
+    X, conn = load_mesh("res2")
+    owner = par.slab_owner(X, conn, world)
+    assert sorted(np.bincount(owner).tolist())[0] >= conn.shape[0] // world - 1
+    parts = [par.partition_from_global(X, conn, owner, r, world) for r in range(world)]
+    assert sum(len(p.elem_ids) for p in parts) == conn.shape[0]
+    wsum = np.zeros(X.shape[0])
+    slot_of = {}
+    for p in parts:
+        assert np.array_equal(p.l2g[p.conn], conn[p.elem_ids])          # local connectivity maps back exactly
+        np.add.at(wsum, p.l2g, p.node_weight)
+        for n, s in zip(p.l2g[p.iface_nodes], p.iface_slots):
+            assert slot_of.setdefault(int(n), int(s)) == int(s)           # same node -> same slot on all ranks
+        assert np.all(p.node_weight[p.iface_nodes] <= 0.5) and p.n_global_iface == parts[0].n_global_iface
+    assert np.allclose(wsum, 1.0)                                         # weights partition unity
+    assert len(slot_of) == parts[0].n_global_iface
+    f = np.random.default_rng(0).normal(size=3 * X.shape[0])
+    tot = np.zeros_like(f).reshape(-1, 3)
+    for p in parts:
+        np.add.at(tot, p.l2g, p.share_of_nodal_vector(f).reshape(-1, 3))
+    assert np.allclose(tot.reshape(-1), f)
+
+
+def test_structured_slab_interfaces_agree():
+    """bench.py's rank-local slab construction: neighbours must agree on slot order without communicating."""
+    wl = __import__("importlib").import_module("total-lagrangian-fea_amd.workloads")
+    world = 3
+    cfg = wl.CONFIGS["S"]
+    nx, lx = cfg["cells"][0], cfg["size"][0]
+    coords = {}
+    for r in range(world):
+        w = wl.build("S", cells=cfg["cells"], x_offset_cells=r * nx)
+        p = par.slab_partition_structured(w["X"], lx * r, lx * (r + 1), r, world)
+        for n, s in zip(p.iface_nodes, p.iface_slots):
+            key = tuple(np.round(w["X"][n], 9))
+            assert coords.setdefault(int(s), key) == key
+        assert np.all(p.node_weight[p.iface_nodes] == 0.5)
+    assert len(coords) == (world - 1) * (2 * cfg["cells"][1] + 1) * (2 * cfg["cells"][2] + 1)
+
+
+def test_two_ranks_gloo_oracle_engine(tmp_path):
+    rep = launch(2, ["--engine", "oracle", "--mesh", "box", "--steps", "2"], tmp_path)
+    assert rep["ok"] and rep["n_iface"] > 0, rep
+
+
+@pytest.mark.gpu
+def test_two_ranks_hip_engine_one_gpu(tmp_path):
+    rep = launch(2, ["--engine", "hip", "--mesh", "res2", "--steps", "2"], tmp_path)
+    assert rep["ok"] and rep["n_iface"] > 0, rep
+
+
+@pytest.mark.gpu
+def test_three_ranks_hip_engine_one_gpu(tmp_path):
+    rep = launch(3, ["--engine", "hip", "--mesh", "box", "--steps", "1"], tmp_path)
+    assert rep["ok"], rep

@@ -325,23 +325,68 @@ void launch_dual_update(hipStream_t s, int nc, const double* cons, double rho, d
 }
 
 // ---- partition-interface pack/unpack (multi-GPU exchange buffers) --------------------------------
-__global__ void pack_kernel(int n, const int* __restrict__ idx, const double* __restrict__ src,
-                            double* __restrict__ buf) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) buf[i] = src[idx[i]];
+// buf[dim*slot + c] <-> field[dim*node + c]; slots index the GLOBAL interface list, identical on all ranks
+__global__ void pack_kernel(int n, int dim, const int* __restrict__ node, const int* __restrict__ slot,
+                            const double* __restrict__ src, double* __restrict__ buf) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n * dim) return;
+  const int k = t / dim, c = t - k * dim;
+  buf[(size_t)dim * slot[k] + c] = src[(size_t)dim * node[k] + c];
 }
-__global__ void unpack_kernel(int n, const int* __restrict__ idx, const double* __restrict__ buf,
-                              double* __restrict__ dst) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) dst[idx[i]] = buf[i];
+__global__ void unpack_kernel(int n, int dim, const int* __restrict__ node, const int* __restrict__ slot,
+                              const double* __restrict__ buf, double* __restrict__ dst) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n * dim) return;
+  const int k = t / dim, c = t - k * dim;
+  dst[(size_t)dim * node[k] + c] = buf[(size_t)dim * slot[k] + c];
 }
-void launch_pack(hipStream_t s, int n, const int* idx, const double* src, double* buf) {
+void launch_pack(hipStream_t s, int n, int dim, const int* node, const int* slot, const double* src, double* buf) {
   if (n <= 0) return;
-  hipLaunchKernelGGL(pack_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, idx, src, buf);
+  hipLaunchKernelGGL(pack_kernel, dim3((n * dim + 255) / 256), dim3(256), 0, s, n, dim, node, slot, src, buf);
 }
-void launch_unpack(hipStream_t s, int n, const int* idx, const double* buf, double* dst) {
+void launch_unpack(hipStream_t s, int n, int dim, const int* node, const int* slot, const double* buf, double* dst) {
   if (n <= 0) return;
-  hipLaunchKernelGGL(unpack_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, idx, buf, dst);
+  hipLaunchKernelGGL(unpack_kernel, dim3((n * dim + 255) / 256), dim3(256), 0, s, n, dim, node, slot, buf, dst);
+}
+
+__global__ void extract_diag_kernel(int N, Incidence inc, const double* __restrict__ Hval, double* __restrict__ D) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const int off0 = inc.off[i], deg = inc.off[i + 1] - off0, dp = inc.diagpos[i];
+  const double* Hi = Hval + (size_t)9 * off0;
+#pragma unroll
+  for (int d = 0; d < 3; d++)
+#pragma unroll
+    for (int e = 0; e < 3; e++) D[(size_t)9 * i + 3 * d + e] = Hi[d * 3 * deg + 3 * dp + e];
+}
+__global__ void invert_diag_kernel(int N, const double* __restrict__ Dm, double* __restrict__ Dinv) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  double D[3][3];
+#pragma unroll
+  for (int d = 0; d < 3; d++)
+#pragma unroll
+    for (int e = 0; e < 3; e++) D[d][e] = Dm[(size_t)9 * i + 3 * d + e];
+  const double det = D[0][0] * (D[1][1] * D[2][2] - D[1][2] * D[2][1]) -
+                     D[0][1] * (D[1][0] * D[2][2] - D[1][2] * D[2][0]) +
+                     D[0][2] * (D[1][0] * D[2][1] - D[1][1] * D[2][0]);
+  const double id = 1.0 / det;
+  double* o = Dinv + (size_t)9 * i;
+  o[0] = (D[1][1] * D[2][2] - D[1][2] * D[2][1]) * id;
+  o[1] = (D[0][2] * D[2][1] - D[0][1] * D[2][2]) * id;
+  o[2] = (D[0][1] * D[1][2] - D[0][2] * D[1][1]) * id;
+  o[3] = (D[1][2] * D[2][0] - D[1][0] * D[2][2]) * id;
+  o[4] = (D[0][0] * D[2][2] - D[0][2] * D[2][0]) * id;
+  o[5] = (D[0][2] * D[1][0] - D[0][0] * D[1][2]) * id;
+  o[6] = (D[1][0] * D[2][1] - D[1][1] * D[2][0]) * id;
+  o[7] = (D[0][1] * D[2][0] - D[0][0] * D[2][1]) * id;
+  o[8] = (D[0][0] * D[1][1] - D[0][1] * D[1][0]) * id;
+}
+void launch_extract_diag(hipStream_t s, int N, const Incidence& inc, const double* Hval, double* D) {
+  hipLaunchKernelGGL(extract_diag_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, inc, Hval, D);
+}
+void launch_invert_diag(hipStream_t s, int N, const double* D, double* Dinv) {
+  hipLaunchKernelGGL(invert_diag_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, D, Dinv);
 }
 
 }  // namespace tlfea

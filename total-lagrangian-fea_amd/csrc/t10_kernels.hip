@@ -404,8 +404,8 @@ __global__ void grad_kernel(int N, Incidence inc, const double* __restrict__ fbu
                             const double* __restrict__ y, const double* __restrict__ z,
                             const double* __restrict__ xt, const double* __restrict__ yt,
                             const double* __restrict__ zt, const int* __restrict__ fixed_slot,
-                            const double* __restrict__ lam, double h, double rho, double* __restrict__ f_int,
-                            double* __restrict__ cons, double* __restrict__ g) {
+                            const double* __restrict__ lam, const double* __restrict__ nw, double h, double rho,
+                            double* __restrict__ f_int, double* __restrict__ cons, double* __restrict__ g) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
   double f[3] = {0.0, 0.0, 0.0};
@@ -436,7 +436,7 @@ __global__ void grad_kernel(int N, Incidence inc, const double* __restrict__ fbu
     double r = res[d] + f[d] - f_ext[3 * i + d];
     if (slot >= 0) {
       cons[3 * slot + d] = cv[d];
-      r += h * (lam[3 * slot + d] + rho * cv[d]);
+      r += (nw ? nw[i] : 1.0) * h * (lam[3 * slot + d] + rho * cv[d]);  // nw: 1/multiplicity across ranks
     }
     g[3 * i + d] = r;
   }
@@ -445,9 +445,9 @@ __global__ void grad_kernel(int N, Incidence inc, const double* __restrict__ fbu
 void launch_grad(hipStream_t s, int N, const Incidence& inc, const double* fbuf, const double* mval, const double* v,
                  const double* vprev, const double* f_ext, const double* x, const double* y, const double* z,
                  const double* xt, const double* yt, const double* zt, const int* fixed_slot, const double* lam,
-                 double h, double rho, double* f_int, double* cons, double* g) {
+                 const double* nw, double h, double rho, double* f_int, double* cons, double* g) {
   hipLaunchKernelGGL(grad_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, inc, fbuf, mval, v, vprev, f_ext, x, y,
-                     z, xt, yt, zt, fixed_slot, lam, h, rho, f_int, cons, g);
+                     z, xt, yt, zt, fixed_slot, lam, nw, h, rho, f_int, cons, g);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -678,7 +678,8 @@ void launch_tangent_blocks(hipStream_t s, const T10View& m, const Material& mat,
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void assemble_rows_kernel(int N, Incidence inc, const double* __restrict__ Kbuf,
                                                           const double* __restrict__ mval, double inv_h,
-                                                          const int* __restrict__ fixed_slot, double penalty,
+                                                          const int* __restrict__ fixed_slot,
+                                                          const double* __restrict__ nw, double penalty,
                                                           double* __restrict__ Hval) {
   extern __shared__ double acc[];
   const int i = blockIdx.x;
@@ -697,7 +698,8 @@ __global__ __launch_bounds__(64) void assemble_rows_kernel(int N, Incidence inc,
   }
   __syncthreads();
   // h^2 rho J^T J: one 1.0 per pinned DOF (SyncedNewton.cu:292-341, FEAT10Data.cu:443-459)
-  if (lane < 3 && fixed_slot && fixed_slot[i] >= 0) acc[lane * row + 3 * inc.diagpos[i] + lane] += penalty;
+  if (lane < 3 && fixed_slot && fixed_slot[i] >= 0)
+    acc[lane * row + 3 * inc.diagpos[i] + lane] += (nw ? nw[i] : 1.0) * penalty;
   __syncthreads();
   const int k0 = inc.n2e_off[i], k1 = inc.n2e_off[i + 1];
   for (int k = k0; k < k1; k++) {
@@ -717,10 +719,11 @@ __global__ __launch_bounds__(64) void assemble_rows_kernel(int N, Incidence inc,
 }
 
 void launch_assemble_rows(hipStream_t s, int N, int maxdeg, const Incidence& inc, const double* Kbuf,
-                          const double* mval, double inv_h, const int* fixed_slot, double penalty, double* Hval) {
+                          const double* mval, double inv_h, const int* fixed_slot, const double* nw, double penalty,
+                          double* Hval) {
   const size_t lds = (size_t)9 * maxdeg * sizeof(double);
-  hipLaunchKernelGGL(assemble_rows_kernel, dim3(N), dim3(64), lds, s, N, inc, Kbuf, mval, inv_h, fixed_slot, penalty,
-                     Hval);
+  hipLaunchKernelGGL(assemble_rows_kernel, dim3(N), dim3(64), lds, s, N, inc, Kbuf, mval, inv_h, fixed_slot, nw,
+                     penalty, Hval);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -511,9 +511,10 @@ struct tlfea_newton_s {
   double stage_n[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   hipEvent_t ev[8] = {nullptr};
   // multi-GPU interface
-  int n_iface = 0;
-  int* d_iface = nullptr;
-  double *d_ibuf = nullptr, *d_w = nullptr;
+  int n_if_loc = 0, n_if_glob = 0;  // local interface nodes / slots of the global exchange buffer
+  int *d_if_node = nullptr, *d_if_slot = nullptr;
+  double *d_ibuf = nullptr, *d_w = nullptr, *d_nw = nullptr, *d_wc = nullptr, *d_D = nullptr;
+  bool sync_before_cb = true;
   tlfea_allreduce_fn ar = nullptr;
   void* ar_user = nullptr;
 };
@@ -540,7 +541,7 @@ extern "C" int tlfea_newton_create(tlfea_t10_t data, int n_constraints, tlfea_ne
 extern "C" int tlfea_newton_destroy(tlfea_newton_t s) {
   if (!s) return 0;
   void* ptrs[] = {s->d_v, s->d_vprev, s->d_lam, s->d_g, s->d_dv, s->d_r, s->d_b, s->d_xp, s->d_yp, s->d_zp, s->d_H,
-                  s->d_Kbuf, s->d_Dinv, s->d_p, s->d_p2, s->d_q, s->d_zv, s->d_parts, s->d_scal, s->d_iface, s->d_ibuf, s->d_w};
+                  s->d_Kbuf, s->d_Dinv, s->d_p, s->d_p2, s->d_q, s->d_zv, s->d_parts, s->d_scal, s->d_if_node, s->d_if_slot, s->d_ibuf, s->d_w, s->d_nw, s->d_wc, s->d_D};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   for (auto& e : s->ev)
@@ -632,37 +633,93 @@ extern "C" int tlfea_newton_retrieve_hessian_csr(tlfea_newton_t s, int* ro, int*
   return 0;
 }
 
-extern "C" int tlfea_newton_set_interface(tlfea_newton_t s, const int* iface_dofs, int n_iface, const double* w,
-                                          tlfea_allreduce_fn fn, void* user) {
-  if (s->d_iface) { (void)hipFree(s->d_iface); s->d_iface = nullptr; }
-  if (s->d_ibuf) { (void)hipFree(s->d_ibuf); s->d_ibuf = nullptr; }
-  if (s->d_w) { (void)hipFree(s->d_w); s->d_w = nullptr; }
-  s->n_iface = n_iface;
+extern "C" int tlfea_newton_set_interface(tlfea_newton_t s, const int* iface_nodes, const int* iface_slots,
+                                          int n_local, int n_global, const double* node_weight,
+                                          tlfea_allreduce_fn fn, void* user, int sync_before_callback) {
+  void** ptrs[] = {(void**)&s->d_if_node, (void**)&s->d_if_slot, (void**)&s->d_ibuf, (void**)&s->d_w,
+                   (void**)&s->d_nw, (void**)&s->d_wc, (void**)&s->d_D};
+  for (void** p : ptrs)
+    if (*p) {
+      (void)hipFree(*p);
+      *p = nullptr;
+    }
+  s->n_if_loc = n_local;
+  s->n_if_glob = n_global;
   s->ar = fn;
   s->ar_user = user;
+  s->sync_before_cb = sync_before_callback != 0;
   if (!fn) return 0;
-  TRY(dmalloc(&s->d_iface, (size_t)std::max(1, n_iface)));
-  TRY(dmalloc(&s->d_ibuf, (size_t)std::max(1, n_iface) + 4 * kNPart));
-  TRY(dmalloc(&s->d_w, 3 * (size_t)s->N));
-  if (n_iface) HIP_TRY(hipMemcpy(s->d_iface, iface_dofs, (size_t)n_iface * sizeof(int), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(s->d_w, w, 3 * (size_t)s->N * sizeof(double), hipMemcpyHostToDevice));
+  tlfea_t10_t d = s->d;
+  const size_t N = s->N;
+  for (int k = 0; k < n_local; k++)
+    if (iface_nodes[k] < 0 || iface_nodes[k] >= s->N || iface_slots[k] < 0 || iface_slots[k] >= n_global)
+      return fail("tlfea_newton_set_interface: index out of range");
+  TRY(dmalloc(&s->d_if_node, (size_t)std::max(1, n_local)));
+  TRY(dmalloc(&s->d_if_slot, (size_t)std::max(1, n_local)));
+  TRY(dmalloc(&s->d_ibuf, (size_t)9 * std::max(1, n_global) + 2 * kNPart));
+  TRY(dmalloc(&s->d_w, 3 * N));
+  TRY(dmalloc(&s->d_nw, N));
+  TRY(dmalloc(&s->d_D, 9 * N));
+  if (n_local) {
+    HIP_TRY(hipMemcpy(s->d_if_node, iface_nodes, (size_t)n_local * sizeof(int), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(s->d_if_slot, iface_slots, (size_t)n_local * sizeof(int), hipMemcpyHostToDevice));
+  }
+  std::vector<double> w3(3 * N);
+  for (size_t i = 0; i < N; i++) w3[3 * i] = w3[3 * i + 1] = w3[3 * i + 2] = node_weight[i];
+  HIP_TRY(hipMemcpy(s->d_w, w3.data(), 3 * N * sizeof(double), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(s->d_nw, node_weight, N * sizeof(double), hipMemcpyHostToDevice));
+  if (d->n_constraint > 0) {
+    std::vector<double> wc((size_t)d->n_constraint);
+    for (int k = 0; k < d->n_constraint; k++) wc[k] = node_weight[d->h_fixed[k / 3]];
+    TRY(dmalloc(&s->d_wc, wc.size()));
+    HIP_TRY(hipMemcpy(s->d_wc, wc.data(), wc.size() * sizeof(double), hipMemcpyHostToDevice));
+  }
   return 0;
 }
 
-// sum over ranks of the interface entries of a nodal vector (partition-boundary DOFs only)
-static int iface_sum(tlfea_newton_t s, double* d_vec) {
-  if (!s->ar || s->n_iface == 0) return 0;
-  launch_pack(s->stream, s->n_iface, s->d_iface, d_vec, s->d_ibuf);
-  HIP_TRY(hipStreamSynchronize(s->stream));
-  if (s->ar(s->ar_user, s->d_ibuf, s->n_iface)) return fail("interface all-reduce failed");
-  launch_unpack(s->stream, s->n_iface, s->d_iface, s->d_ibuf, d_vec);
+static int call_allreduce(tlfea_newton_t s, double* d_buf, int n) {
+  if (s->sync_before_cb) HIP_TRY(hipStreamSynchronize(s->stream));
+  if (s->ar(s->ar_user, d_buf, n)) return fail("interface all-reduce callback failed");
   return 0;
 }
-// sum over ranks of `n` partial-sum slots (element-wise), so every rank re-adds identical partials
-static int parts_sum(tlfea_newton_t s, double* d_parts, int n) {
+
+// Sum over ranks of the partition-boundary entries of a nodal field with `dim` values per node (3 for
+// vectors, 9 for diagonal blocks), optionally fused with `n_extra` reduction slots (one collective).
+static int iface_sum(tlfea_newton_t s, double* d_vec, int dim, double* d_extra = nullptr, int n_extra = 0,
+                     double* d_extra2 = nullptr) {
   if (!s->ar) return 0;
-  HIP_TRY(hipStreamSynchronize(s->stream));
-  if (s->ar(s->ar_user, d_parts, n)) return fail("partials all-reduce failed");
+  const int nb = dim * s->n_if_glob;
+  if (nb) HIP_TRY(hipMemsetAsync(s->d_ibuf, 0, (size_t)nb * sizeof(double), s->stream));
+  launch_pack(s->stream, s->n_if_loc, dim, s->d_if_node, s->d_if_slot, d_vec, s->d_ibuf);
+  int total = nb;
+  if (d_extra) {
+    HIP_TRY(hipMemcpyAsync(s->d_ibuf + total, d_extra, (size_t)n_extra * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
+    total += n_extra;
+  }
+  if (d_extra2) {
+    HIP_TRY(hipMemcpyAsync(s->d_ibuf + total, d_extra2, (size_t)n_extra * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
+    total += n_extra;
+  }
+  if (total == 0) return 0;
+  TRY(call_allreduce(s, s->d_ibuf, total));
+  launch_unpack(s->stream, s->n_if_loc, dim, s->d_if_node, s->d_if_slot, s->d_ibuf, d_vec);
+  int o = nb;
+  if (d_extra) {
+    HIP_TRY(hipMemcpyAsync(d_extra, s->d_ibuf + o, (size_t)n_extra * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
+    o += n_extra;
+  }
+  if (d_extra2)
+    HIP_TRY(hipMemcpyAsync(d_extra2, s->d_ibuf + o, (size_t)n_extra * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
+  return 0;
+}
+// sum over ranks of reduction slots only (element-wise), so every rank re-adds identical partials
+static int parts_sum(tlfea_newton_t s, double* d_a, double* d_b = nullptr) {
+  if (!s->ar) return 0;
+  HIP_TRY(hipMemcpyAsync(s->d_ibuf, d_a, (size_t)kNPart * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
+  if (d_b) HIP_TRY(hipMemcpyAsync(s->d_ibuf + kNPart, d_b, (size_t)kNPart * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
+  TRY(call_allreduce(s, s->d_ibuf, d_b ? 2 * kNPart : kNPart));
+  HIP_TRY(hipMemcpyAsync(d_a, s->d_ibuf, (size_t)kNPart * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
+  if (d_b) HIP_TRY(hipMemcpyAsync(d_b, s->d_ibuf + kNPart, (size_t)kNPart * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
   return 0;
 }
 
@@ -671,7 +728,7 @@ static double* part(tlfea_newton_t s, int k) { return s->d_parts + (size_t)k * k
 static int device_norm(tlfea_newton_t s, const double* d_vec, const double* w, int n, double* out) {
   launch_norm2(s->stream, d_vec, w, n, part(s, 5), s->d_scal);
   if (s->ar) {
-    TRY(parts_sum(s, part(s, 5), kNPart));
+    TRY(parts_sum(s, part(s, 5)));
     launch_sum_parts(s->stream, part(s, 5), s->d_scal);
   }
   double ss = 0.0;
@@ -713,12 +770,12 @@ static int eval_gradient(tlfea_newton_t s, double* norm_g) {
   {
     StageTimer t(s, 1);
     launch_grad(s->stream, s->N, d->inc(), d->d_fbuf, d->d_mval, s->d_v, s->d_vprev, d->d_fext, d->d_x, d->d_y, d->d_z,
-                d->d_xt, d->d_yt, d->d_zt, d->is_constraints_setup ? d->d_fixed_slot : nullptr, s->d_lam, p.time_step,
+                d->d_xt, d->d_yt, d->d_zt, d->is_constraints_setup ? d->d_fixed_slot : nullptr, s->d_lam, s->d_nw, p.time_step,
                 p.rho, d->d_fint, d->d_cons, s->d_g);
     HIP_TRY(hipGetLastError());
     // each rank's g holds only its own elements' forces and its share of M, f_ext, constraints on
     // partition-boundary nodes: sum the boundary entries over ranks (nothing else is exchanged)
-    TRY(iface_sum(s, s->d_g));
+    TRY(iface_sum(s, s->d_g, 3));
     TRY(device_norm(s, s->d_g, s->d_w, 3 * s->N, norm_g));
     t.stop();
   }
@@ -736,8 +793,8 @@ static int assemble(tlfea_newton_t s) {
   {
     StageTimer t(s, 3);
     launch_assemble_rows(s->stream, s->N, d->maxdeg, d->inc(), s->d_Kbuf, d->d_mval, 1.0 / p.time_step,
-                         d->is_constraints_setup ? d->d_fixed_slot : nullptr, p.time_step * p.time_step * p.rho,
-                         s->d_H);
+                         d->is_constraints_setup ? d->d_fixed_slot : nullptr, s->d_nw,
+                         p.time_step * p.time_step * p.rho, s->d_H);
     HIP_TRY(hipGetLastError());
     t.stop();
   }
@@ -752,14 +809,15 @@ static int pcg(tlfea_newton_t s, const double* d_b, double* d_x, int* iters_out,
   const double* w = s->d_w;
   if (s->ar) {
     // diagonal blocks of partition-boundary nodes are partial per rank: sum them before inverting
-    // (done through the generic vector exchange on a scratch copy of the 9 block entries is overkill:
-    // the host layer passes weights and pre-sums H's boundary diagonal via tlfea_newton_iface_diag)
+    launch_extract_diag(s->stream, N, d->inc(), s->d_H, s->d_D);
+    TRY(iface_sum(s, s->d_D, 9));
+    launch_invert_diag(s->stream, N, s->d_D, s->d_Dinv);
+  } else {
+    launch_extract_dinv(s->stream, N, d->inc(), s->d_H, s->d_Dinv);
   }
-  launch_extract_dinv(s->stream, N, d->inc(), s->d_H, s->d_Dinv);
   HIP_TRY(hipMemsetAsync(s->d_parts, 0, (size_t)5 * kNPart * sizeof(double), s->stream));
   launch_pcg_init(s->stream, N, d_b, s->d_Dinv, w, d_x, s->d_r, s->d_zv, part(s, 0), part(s, 4));
-  TRY(parts_sum(s, part(s, 0), kNPart));
-  TRY(parts_sum(s, part(s, 4), kNPart));
+  TRY(parts_sum(s, part(s, 0), part(s, 4)));
   launch_sum_parts(s->stream, part(s, 4), s->d_scal + 1);
   double bb = 0.0;
   HIP_TRY(hipMemcpyAsync(&bb, s->d_scal + 1, sizeof(double), hipMemcpyDeviceToHost, s->stream));
@@ -785,17 +843,11 @@ static int pcg(tlfea_newton_t s, const double* d_b, double* d_x, int* iters_out,
         s->stage_ms[6] += ms;
         s->stage_n[6] += 1;
       }
-      if (s->ar) {
-        TRY(iface_sum(s, s->d_q));
-        TRY(parts_sum(s, pq_part, kNPart));
-      }
+      if (s->ar) TRY(iface_sum(s, s->d_q, 3, pq_part, kNPart));  // boundary rows of q + p.q slots, one collective
       // alpha = rz(cur)/pq; x += alpha p; r -= alpha q; z = Dinv r; new rz partials into part(1-cur)
       launch_pcg_update(s->stream, N, s->d_Dinv, w, p_new, s->d_q, part(s, cur), pq_part, d_x, s->d_r, s->d_zv,
                         part(s, 1 - cur), part(s, 3));
-      if (s->ar) {
-        TRY(parts_sum(s, part(s, 1 - cur), kNPart));
-        TRY(parts_sum(s, part(s, 3), kNPart));
-      }
+      if (s->ar) TRY(parts_sum(s, part(s, 1 - cur), part(s, 3)));  // r.z and r.r slots, one collective
       cur = 1 - cur;
       std::swap(p_old, p_new);
       it++;
@@ -903,10 +955,7 @@ extern "C" int tlfea_newton_solve(tlfea_newton_t s) {
       launch_constraint(s->stream, d->n_fixed, d->d_fixed, d->d_x, d->d_y, d->d_z, d->d_xt, d->d_yt, d->d_zt,
                         d->d_cons);
       launch_dual_update(s->stream, s->n_constraints, d->d_cons, p.rho, s->d_lam);  // lambda += rho c (:470-481)
-      TRY(device_norm(s, d->d_cons, nullptr, s->n_constraints, &norm_c));
-      if (s->ar) {  // constraints on partition-boundary nodes are replicated, not partial: undo the rank sum
-        // (the host layer owns that bookkeeping; single-rank path unaffected)
-      }
+      TRY(device_norm(s, d->d_cons, s->d_wc, s->n_constraints, &norm_c));  // replicated rows weigh 1/multiplicity
       if (s->verbose) std::printf("  outer %d ||c|| = %.6e\n", outer, norm_c);
       if (norm_c < p.outer_tol) break;
     }

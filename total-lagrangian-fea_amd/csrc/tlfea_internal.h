@@ -57,15 +57,15 @@ void launch_residual(hipStream_t s, const T10View& m, const Material& mat, const
 void launch_tangent_blocks(hipStream_t s, const T10View& m, const Material& mat, double h,
                            double* Kbuf /*[E][55][9]*/);
 void launch_assemble_rows(hipStream_t s, int N, int maxdeg, const Incidence& inc, const double* Kbuf,
-                          const double* mval, double inv_h, const int* fixed_slot, double penalty,
-                          double* Hval);
+                          const double* mval, double inv_h, const int* fixed_slot, const double* nw,
+                          double penalty, double* Hval);
 void launch_mass_values(hipStream_t s, const T10View& m, const Incidence& inc, const double* qx,
                         const double* qy, const double* qz, double rho0, double* mval);
 void launch_grad(hipStream_t s, int N, const Incidence& inc, const double* fbuf, const double* mval,
                  const double* v, const double* vprev, const double* f_ext, const double* x,
                  const double* y, const double* z, const double* xt, const double* yt, const double* zt,
-                 const int* fixed_slot, const double* lam, double h, double rho, double* f_int,
-                 double* cons, double* g);
+                 const int* fixed_slot, const double* lam, const double* nw, double h, double rho,
+                 double* f_int, double* cons, double* g);
 void launch_fint_gather(hipStream_t s, int N, const Incidence& inc, const double* fbuf, double* f_int);
 void launch_constraint(hipStream_t s, int n_fixed, const int* fixed_nodes, const double* x, const double* y,
                        const double* z, const double* xt, const double* yt, const double* zt, double* cons);
@@ -88,7 +88,9 @@ void launch_newton_update(hipStream_t s, int N, const double* dv, double* v, con
                           const double* zp, double h, double* x, double* y, double* z);
 void launch_axpy_neg(hipStream_t s, int n, const double* g, double* r);
 void launch_dual_update(hipStream_t s, int nc, const double* cons, double rho, double* lam);
-void launch_pack(hipStream_t s, int n, const int* idx, const double* src, double* buf);
-void launch_unpack(hipStream_t s, int n, const int* idx, const double* buf, double* dst);
+void launch_pack(hipStream_t s, int n, int dim, const int* node, const int* slot, const double* src, double* buf);
+void launch_unpack(hipStream_t s, int n, int dim, const int* node, const int* slot, const double* buf, double* dst);
+void launch_extract_diag(hipStream_t s, int N, const Incidence& inc, const double* Hval, double* D);
+void launch_invert_diag(hipStream_t s, int N, const double* D, double* Dinv);
 
 }  // namespace tlfea

@@ -146,18 +146,22 @@ class SyncedNewtonSolver:
     def BeginStep(self):
         check(self._lib.tlfea_newton_begin_step(self._h))
 
-    def SetInterface(self, iface_dofs, dof_weight, allreduce):
-        """allreduce(ptr:int, n:int) -> None sums a device buffer of n doubles over ranks in place."""
-        idx = np.ascontiguousarray(iface_dofs, dtype=np.int32)
-        w = np.ascontiguousarray(dof_weight, dtype=np.float64)
+    def SetInterface(self, iface_nodes, iface_slots, n_global_iface, node_weight, allreduce, sync_before_callback=1):
+        """allreduce(ptr:int, n:int) sums a device buffer of n doubles over ranks in place (see partition.py)."""
+        nodes = np.ascontiguousarray(iface_nodes, dtype=np.int32)
+        slots = np.ascontiguousarray(iface_slots, dtype=np.int32)
+        w = np.ascontiguousarray(node_weight, dtype=np.float64)
+        assert w.size == self.n_coef and nodes.size == slots.size
 
         def _cb(_user, ptr, n):
             try:
                 allreduce(ptr, n)
                 return 0
             except Exception as exc:  # pragma: no cover
-                print("allreduce callback failed:", exc)
+                print("allreduce callback failed:", repr(exc), flush=True)
                 return 1
 
         self._cb = ALLREDUCE_FN(_cb)
-        check(self._lib.tlfea_newton_set_interface(self._h, ip(idx), int(idx.size), dp(w), self._cb, None))
+        check(self._lib.tlfea_newton_set_interface(self._h, ip(nodes), ip(slots), int(nodes.size),
+                                                   int(n_global_iface), dp(w), self._cb, None,
+                                                   int(sync_before_callback)))
