@@ -133,6 +133,8 @@ int tlfea_newton_eval_gradient(tlfea_newton_t s, double *norm_g);
 int tlfea_newton_assemble_hessian(tlfea_newton_t s);
 /* Solve H x = b for host vectors (b,x length 3N) with the current H; iterations returned. */
 int tlfea_newton_linear_solve(tlfea_newton_t s, const double *b, double *x, int *iters, double *rel_res);
+/* y = H x with the current H, host vectors of 3N (partition-boundary rows summed over ranks). */
+int tlfea_newton_apply_hessian(tlfea_newton_t s, const double *x, double *y);
 /* One full Newton iteration without the convergence test (gradient, assembly, solve, update):
  * the unit bench.py times.  iters = PCG iterations used. */
 int tlfea_newton_iteration(tlfea_newton_t s, double *norm_g, int *iters);

@@ -28,6 +28,9 @@ def problem(name):
     if name == "box":
         X, conn = tl.mesh_utils.structured_t10_box(4, 2, 2, 2.0, 1.0, 1.0)
         lx = 2.0
+    elif name == "box6":
+        X, conn = tl.mesh_utils.structured_t10_box(6, 2, 2, 3.0, 1.0, 1.0)
+        lx = 3.0
     else:
         X, conn = helpers.load_mesh(name)
         lx = X[:, 0].max()
@@ -155,7 +158,7 @@ def main():
     part = par.partition_from_global(X, conn, owner, rank, world)
     fixed_loc = part.localize_nodes(fixed)
     f_share = part.share_of_nodal_vector(f_ext)
-    prm = orc.NewtonParams(1e-6, 0.0, 1e-6, 1e14, 5, 12, 1e-3)
+    prm = orc.NewtonParams(1e-4, 0.0, 1e-6, 1e14, 5, 12, 1e-3)
 
     if args.engine == "oracle":
         o = helpers.make_oracle(part.X, part.conn, m, fixed_loc, f_share)
@@ -166,9 +169,11 @@ def main():
         torch.cuda.set_device(0)
         d = helpers.make_gpu(part.X, part.conn, m, fixed_loc, f_share)
         s = tl.SyncedNewtonSolver(d, d.get_n_constraint())
-        s.SetParameters(tl.SyncedNewtonParams(1e-6, 0.0, 1e-6, 1e14, 5, 12, 1e-3))
+        s.SetParameters(tl.SyncedNewtonParams(1e-4, 0.0, 1e-6, 1e14, 5, 12, 1e-3))
         s.SetLinSolveOpts(tl.LinSolveOpts(1e-13, 20000, 10))
         par.attach(s, part, torch, dist)
+        if os.environ.get("TLFEA_VERBOSE"):
+            s.SetVerbose(1)
         counts = []
         for _ in range(args.steps):
             s.Solve()

@@ -80,7 +80,7 @@ def test_two_ranks_gloo_oracle_engine(tmp_path):
 
 @pytest.mark.gpu
 def test_two_ranks_hip_engine_one_gpu(tmp_path):
-    rep = launch(2, ["--engine", "hip", "--mesh", "res2", "--steps", "2"], tmp_path)
+    rep = launch(2, ["--engine", "hip", "--mesh", "res2", "--steps", "1"], tmp_path)
     assert rep["ok"] and rep["n_iface"] > 0, rep
 
 

@@ -223,11 +223,15 @@ __global__ __launch_bounds__(1024) void spmv_dir_dot_kernel(int N, Incidence inc
       const double sv = (l32 == 0) ? s0 : ((l32 == 1) ? s1 : s2);
       p_new[c] = pv;
       q[c] = sv;
-      pq += (w ? w[c] : 1.0) * pv * sv;
+      pq += pv * sv;  // sv is this rank's partial (H_r p)_c: sum_r p.(H_r p) = p.Hp, so no interface weight here
     }
   }
   const double r = block_sum(pq, sh);
   if (threadIdx.x == 0) pq_part[blockIdx.x] = r;
+  // slots of workgroups that do not exist on THIS rank must read 0: after a cross-rank sum they hold other
+  // ranks' partials of the previous iteration (ranks differ in grid size)
+  if (blockIdx.x == 0)
+    for (int k = gridDim.x + threadIdx.x; k < kNPart; k += blockDim.x) pq_part[k] = 0.0;
 }
 
 int spmv_grid(int N) { return std::max(1, std::min(kNPart, (N + 31) / 32)); }  // small meshes: one row per half-wave
@@ -276,6 +280,11 @@ __global__ __launch_bounds__(256) void pcg_update_kernel(int N, const double* __
     rz_part_new[blockIdx.x] = rz;
     rr_part[blockIdx.x] = rr;
   }
+  if (blockIdx.x == 0)
+    for (int k = gridDim.x + threadIdx.x; k < kNPart; k += blockDim.x) {
+      rz_part_new[k] = 0.0;
+      rr_part[k] = 0.0;
+    }
 }
 
 void launch_pcg_update(hipStream_t s, int N, const double* Dinv, const double* w, const double* p, const double* q,

@@ -491,6 +491,7 @@ extern "C" double* tlfea_t10_constraint_device_ptr(tlfea_t10_t h) { return h->d_
 struct tlfea_newton_s {
   tlfea_t10_t d = nullptr;
   int N = 0, n_constraints = 0;
+  int n_constraints_global = 0;  // over all ranks (control flow must be identical on every rank)
   tlfea_newton_params prm{1e-4, 1e-4, 1e-4, 1e14, 5, 10, 1e-3};
   tlfea_linsolve_opts lin{1e-12, 20000, 25};
   bool fixed_pattern = false, sparsity_done = false;
@@ -525,6 +526,7 @@ extern "C" int tlfea_newton_create(tlfea_t10_t data, int n_constraints, tlfea_ne
   s->d = data;
   s->N = data->N;
   s->n_constraints = n_constraints;
+  s->n_constraints_global = n_constraints;
   const size_t n = 3 * (size_t)s->N;
   TRY(dmalloc(&s->d_v, n)); TRY(dmalloc(&s->d_vprev, n)); TRY(dmalloc(&s->d_g, n)); TRY(dmalloc(&s->d_dv, n));
   TRY(dmalloc(&s->d_r, n)); TRY(dmalloc(&s->d_b, n)); TRY(dmalloc(&s->d_p, n)); TRY(dmalloc(&s->d_p2, n)); TRY(dmalloc(&s->d_q, n)); TRY(dmalloc(&s->d_zv, n));
@@ -648,6 +650,7 @@ extern "C" int tlfea_newton_set_interface(tlfea_newton_t s, const int* iface_nod
   s->ar = fn;
   s->ar_user = user;
   s->sync_before_cb = sync_before_callback != 0;
+  s->n_constraints_global = s->n_constraints;
   if (!fn) return 0;
   tlfea_t10_t d = s->d;
   const size_t N = s->N;
@@ -674,6 +677,12 @@ extern "C" int tlfea_newton_set_interface(tlfea_newton_t s, const int* iface_nod
     TRY(dmalloc(&s->d_wc, wc.size()));
     HIP_TRY(hipMemcpy(s->d_wc, wc.data(), wc.size() * sizeof(double), hipMemcpyHostToDevice));
   }
+  // every rank must take the same branches of the ALM loop: agree on whether ANY rank has constraints
+  double cnt = d->n_constraint;
+  HIP_TRY(hipMemcpy(s->d_ibuf, &cnt, sizeof(double), hipMemcpyHostToDevice));
+  if (fn(user, s->d_ibuf, 1)) return fail("interface all-reduce callback failed");
+  HIP_TRY(hipMemcpy(&cnt, s->d_ibuf, sizeof(double), hipMemcpyDeviceToHost));
+  s->n_constraints_global = (int)(cnt + 0.5);
   return 0;
 }
 
@@ -887,6 +896,19 @@ extern "C" int tlfea_newton_linear_solve(tlfea_newton_t s, const double* b, doub
   return 0;
 }
 
+// y = H x for host vectors with the current H (partition-boundary rows summed over ranks)
+extern "C" int tlfea_newton_apply_hessian(tlfea_newton_t s, const double* x, double* y) {
+  const size_t n = 3 * (size_t)s->N;
+  HIP_TRY(hipMemcpy(s->d_zv, x, n * sizeof(double), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemsetAsync(s->d_parts, 0, (size_t)5 * kNPart * sizeof(double), s->stream));
+  launch_spmv_dir_dot(s->stream, s->N, s->d->inc(), s->d_H, s->d_zv, s->d_p, 1, part(s, 1), part(s, 0), s->d_w, s->d_p2,
+                      s->d_q, part(s, 2));
+  if (s->ar) TRY(iface_sum(s, s->d_q, 3, part(s, 2), kNPart));
+  HIP_TRY(hipGetLastError());
+  D2H(y, s->d_q, n);
+  return 0;
+}
+
 static int newton_update(tlfea_newton_t s) {
   tlfea_t10_t d = s->d;
   StageTimer t(s, 5);
@@ -951,7 +973,7 @@ extern "C" int tlfea_newton_solve(tlfea_newton_t s) {
     }
     HIP_TRY(hipMemcpyAsync(s->d_vprev, s->d_v, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice,
                            s->stream));                                    // every OUTER iteration (:1122)
-    if (s->n_constraints > 0) {
+    if (s->n_constraints_global > 0) {
       launch_constraint(s->stream, d->n_fixed, d->d_fixed, d->d_x, d->d_y, d->d_z, d->d_xt, d->d_yt, d->d_zt,
                         d->d_cons);
       launch_dual_update(s->stream, s->n_constraints, d->d_cons, p.rho, s->d_lam);  // lambda += rho c (:470-481)

@@ -105,6 +105,12 @@ class SyncedNewtonSolver:
         check(self._lib.tlfea_newton_linear_solve(self._h, dp(b), dp(x), C.byref(it), C.byref(rel)))
         return x, it.value, rel.value
 
+    def ApplyHessian(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        y = np.zeros_like(x)
+        check(self._lib.tlfea_newton_apply_hessian(self._h, dp(x), dp(y)))
+        return y
+
     def NewtonIteration(self):
         ng, it = C.c_double(), C.c_int()
         check(self._lib.tlfea_newton_iteration(self._h, C.byref(ng), C.byref(it)))
