@@ -132,6 +132,13 @@ def main():
         roof_all[k] = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                        "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "avg_us": round(avg_s * 1e6, 2),
                        "launches": n, "alg_bytes": ab[k], "total_ms": round(ms, 3)}
+    pmc = load_pmc_traffic() if args.config == "B" and world == 1 else {}
+    for k, v in roof_all.items():
+        if k in pmc:
+            v["traffic"] = pmc[k]
+            v["traffic_note"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, profiles/r01_configB_pmc_hbm.csv): "
+                                 "(2*FETCH_SIZE + WRITE_SIZE)*1024 B per launch; the x2 is the guide's gfx950 streaming-read "
+                                 "correction, uncalibrated for 8-B-per-lane loads")
     dominant = max(roof_all, key=lambda k: roof_all[k]["total_ms"])
     roofline = dict(roof_all[dominant], kernel=dominant)
     elem_ms = sum(st[k][0] for k in ("residual", "grad", "tangent_blocks", "assemble_rows")) / nprof
@@ -160,6 +167,26 @@ def main():
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+def load_pmc_traffic():
+    """HBM bytes per launch from the committed PMC summary (collected with the same command, config B)."""
+    path = os.path.join(ROOT, "profiles", "r01_configB_pmc_hbm.csv")
+    names = {"t10_residual_kernel": "residual", "t10_tangent_blocks_kernel": "tangent_blocks",
+             "assemble_rows_kernel": "assemble_rows", "spmv_dir_dot_kernel": "spmv"}
+    out = {}
+    if not os.path.exists(path):
+        return out
+    import csv
+    acc = {}
+    for r in csv.DictReader(open(path)):
+        for frag, key in names.items():
+            if frag in r["kernel"]:
+                acc.setdefault(key, {})[r["counter"]] = float(r["mean_KB"])
+    for key, c in acc.items():
+        if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+            out[key] = int((2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024)
+    return out
 
 
 def cpu_baseline(w, args):
