@@ -166,16 +166,25 @@ void launch_pcg_init(hipStream_t s, int N, const double* b, const double* Dinv, 
 // issued ahead of the dependent cols -> z/p gather chain.  Workgroups of 1024 threads own contiguous row
 // chunks (neighbouring rows share most column nodes -> the gathers hit L1/L2) and the grid never exceeds
 // kNPart workgroups, so the p.q partials fit the common slot array.
+template <bool NT>
+__device__ __forceinline__ double ld_stream(const double* p) {
+  // H is streamed once per CG iteration: a non-temporal load keeps it from evicting the gathered vectors
+  return NT ? __builtin_nontemporal_load(p) : *p;
+}
+
+// FUSED: p_new = z + beta p_old is formed on the fly (small meshes: one launch fewer per iteration).
+// !FUSED: p was written by pcg_direction_kernel; only p is gathered (large meshes: half the gather traffic).
+template <bool FUSED, bool NT>
 __global__ __launch_bounds__(1024) void spmv_dir_dot_kernel(int N, Incidence inc, const double* __restrict__ Hval,
                                                            const double* __restrict__ z,
                                                            const double* __restrict__ p_old, int first,
                                                            const double* __restrict__ rz_part_old,
                                                            const double* __restrict__ rz_part_new,
-                                                           const double* __restrict__ w, double* __restrict__ p_new,
-                                                           double* __restrict__ q, double* __restrict__ pq_part) {
+                                                           double* __restrict__ p_new, double* __restrict__ q,
+                                                           double* __restrict__ pq_part) {
   __shared__ double sh[32];
   double beta = 0.0;
-  if (!first) {
+  if (FUSED && !first) {
     double rz_old, rz_new;
     sum_slots2(rz_part_old, rz_part_new, rz_old, rz_new, sh);
     beta = rz_new / rz_old;
@@ -193,20 +202,26 @@ __global__ __launch_bounds__(1024) void spmv_dir_dot_kernel(int N, Incidence inc
     for (int t = l32; t < row; t += 64) {
       const int t2 = t + 32;
       const bool has2 = t2 < row;
-      const double h0 = Hi[t], h1 = Hi[row + t], h2 = Hi[2 * row + t];
+      const double h0 = ld_stream<NT>(Hi + t), h1 = ld_stream<NT>(Hi + row + t), h2 = ld_stream<NT>(Hi + 2 * row + t);
       const int k = t / 3, e = t - 3 * k;
       const int ca = 3 * inc.cols[off0 + k] + e;
       double g0 = 0.0, g1 = 0.0, g2 = 0.0;
       int cb = ca;
       if (has2) {
-        g0 = Hi[t2];
-        g1 = Hi[row + t2];
-        g2 = Hi[2 * row + t2];
+        g0 = ld_stream<NT>(Hi + t2);
+        g1 = ld_stream<NT>(Hi + row + t2);
+        g2 = ld_stream<NT>(Hi + 2 * row + t2);
         const int kb = t2 / 3, eb = t2 - 3 * kb;
         cb = 3 * inc.cols[off0 + kb] + eb;
       }
-      const double pa = first ? z[ca] : (z[ca] + beta * p_old[ca]);
-      const double pb = first ? z[cb] : (z[cb] + beta * p_old[cb]);
+      double pa, pb;
+      if (FUSED) {
+        pa = first ? z[ca] : (z[ca] + beta * p_old[ca]);
+        pb = first ? z[cb] : (z[cb] + beta * p_old[cb]);
+      } else {
+        pa = p_old[ca];
+        pb = p_old[cb];
+      }
       s0 += h0 * pa + g0 * pb;
       s1 += h1 * pa + g1 * pb;
       s2 += h2 * pa + g2 * pb;
@@ -219,9 +234,14 @@ __global__ __launch_bounds__(1024) void spmv_dir_dot_kernel(int N, Incidence inc
     }
     if (l32 < 3) {
       const int c = 3 * i + l32;
-      const double pv = first ? z[c] : (z[c] + beta * p_old[c]);
+      double pv;
+      if (FUSED) {
+        pv = first ? z[c] : (z[c] + beta * p_old[c]);
+        p_new[c] = pv;
+      } else {
+        pv = p_old[c];
+      }
       const double sv = (l32 == 0) ? s0 : ((l32 == 1) ? s1 : s2);
-      p_new[c] = pv;
       q[c] = sv;
       pq += pv * sv;  // sv is this rank's partial (H_r p)_c: sum_r p.(H_r p) = p.Hp, so no interface weight here
     }
@@ -238,9 +258,37 @@ int spmv_grid(int N) { return std::max(1, std::min(kNPart, (N + 31) / 32)); }  /
 
 void launch_spmv_dir_dot(hipStream_t s, int N, const Incidence& inc, const double* Hval, const double* z,
                          const double* p_old, int first, const double* rz_part_old, const double* rz_part_new,
-                         const double* w, double* p_new, double* q, double* pq_part) {
-  hipLaunchKernelGGL(spmv_dir_dot_kernel, dim3(spmv_grid(N)), dim3(1024), 0, s, N, inc, Hval, z, p_old, first,
-                     rz_part_old, rz_part_new, w, p_new, q, pq_part);
+                         double* p_new, double* q, double* pq_part, bool fused, bool nt) {
+  const dim3 g(spmv_grid(N)), b(1024);
+#define TLFEA_SPMV(F, T)                                                                                          \
+  hipLaunchKernelGGL((spmv_dir_dot_kernel<F, T>), g, b, 0, s, N, inc, Hval, z, p_old, first, rz_part_old, rz_part_new, \
+                     p_new, q, pq_part)
+  if (fused && nt) TLFEA_SPMV(true, true);
+  else if (fused) TLFEA_SPMV(true, false);
+  else if (nt) TLFEA_SPMV(false, true);
+  else TLFEA_SPMV(false, false);
+#undef TLFEA_SPMV
+}
+
+// p = z + beta p (beta from the partial slots; first iteration p = z) -- large meshes only
+__global__ __launch_bounds__(256) void pcg_direction_kernel(int n, const double* __restrict__ z, int first,
+                                                           const double* __restrict__ rz_part_old,
+                                                           const double* __restrict__ rz_part_new,
+                                                           double* __restrict__ p) {
+  __shared__ double sh[32];
+  double beta = 0.0;
+  if (!first) {
+    double rz_old, rz_new;
+    sum_slots2(rz_part_old, rz_part_new, rz_old, rz_new, sh);
+    beta = rz_new / rz_old;
+  }
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) p[i] = first ? z[i] : (z[i] + beta * p[i]);
+}
+
+void launch_pcg_direction(hipStream_t s, int n, const double* z, int first, const double* rz_part_old,
+                          const double* rz_part_new, double* p) {
+  hipLaunchKernelGGL(pcg_direction_kernel, dim3(std::min(2048, (n + 255) / 256)), dim3(256), 0, s, n, z, first,
+                     rz_part_old, rz_part_new, p);
 }
 
 // x += alpha p ; r -= alpha q ; z = Dinv r ; partials of r.z and r.r

@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <string>
@@ -499,7 +500,9 @@ struct tlfea_newton_s {
   hipStream_t stream = nullptr;
   double *d_v = nullptr, *d_vprev = nullptr, *d_lam = nullptr, *d_g = nullptr, *d_dv = nullptr, *d_r = nullptr,
          *d_b = nullptr;
-  bool profiling = false;  // per-stage hipEvent timing (adds a host sync per stage)
+  bool profiling = false;
+  int pcg_fused = -1;  // -1 auto (fused direction update below 200k nodes), 0/1 forced (TLFEA_PCG_FUSED)
+  bool spmv_nt = false; // non-temporal loads of H in the SpMV (TLFEA_SPMV_NT): measured slower at config C  // per-stage hipEvent timing (adds a host sync per stage)
   double *d_xp = nullptr, *d_yp = nullptr, *d_zp = nullptr;
   double *d_H = nullptr, *d_Kbuf = nullptr, *d_Dinv = nullptr;
   double *d_p = nullptr, *d_p2 = nullptr, *d_q = nullptr, *d_zv = nullptr;
@@ -536,6 +539,8 @@ extern "C" int tlfea_newton_create(tlfea_t10_t data, int n_constraints, tlfea_ne
   TRY(dmalloc(&s->d_scal, (size_t)4));
   TRY(dmalloc(&s->d_Dinv, (size_t)9 * s->N));
   for (auto& e : s->ev) HIP_TRY(hipEventCreate(&e));
+  if (const char* e = std::getenv("TLFEA_PCG_FUSED")) s->pcg_fused = std::atoi(e);
+  if (const char* e = std::getenv("TLFEA_SPMV_NT")) s->spmv_nt = std::atoi(e) != 0;
   *out = s;
   return tlfea_newton_setup(s);
 }
@@ -836,14 +841,21 @@ static int pcg(tlfea_newton_t s, const double* d_b, double* d_x, int* iters_out,
   if (bb > 0.0) {
     const double target = s->lin.rel_tol * s->lin.rel_tol * bb;
     double* pq_part = part(s, 2);
+    const bool fused = s->pcg_fused < 0 ? (N <= 200000) : (s->pcg_fused != 0);
     int cur = 0;  // which rz partial buffer is "old"
     double *p_old = s->d_p, *p_new = s->d_p2;
     // state entering iteration k: z, r, rz partials in part(cur) [and part(1-cur) = previous, for beta]
     while (it < s->lin.max_iter) {
       if (s->profiling) (void)hipEventRecord(s->ev[4], s->stream);
       // beta = rz(cur)/rz(1-cur); p_new = z + beta p_old; q = H p_new; partials of p_new.q
-      launch_spmv_dir_dot(s->stream, N, d->inc(), s->d_H, s->d_zv, p_old, it == 0, part(s, 1 - cur), part(s, cur), w,
-                          p_new, s->d_q, pq_part);
+      if (fused) {
+        launch_spmv_dir_dot(s->stream, N, d->inc(), s->d_H, s->d_zv, p_old, it == 0, part(s, 1 - cur), part(s, cur),
+                            p_new, s->d_q, pq_part, true, s->spmv_nt);
+      } else {
+        launch_pcg_direction(s->stream, 3 * N, s->d_zv, it == 0, part(s, 1 - cur), part(s, cur), p_old);
+        launch_spmv_dir_dot(s->stream, N, d->inc(), s->d_H, s->d_zv, p_old, it == 0, part(s, 1 - cur), part(s, cur),
+                            p_old, s->d_q, pq_part, false, s->spmv_nt);
+      }
       if (s->profiling) {
         (void)hipEventRecord(s->ev[5], s->stream);
         (void)hipEventSynchronize(s->ev[5]);
@@ -854,11 +866,11 @@ static int pcg(tlfea_newton_t s, const double* d_b, double* d_x, int* iters_out,
       }
       if (s->ar) TRY(iface_sum(s, s->d_q, 3, pq_part, kNPart));  // boundary rows of q + p.q slots, one collective
       // alpha = rz(cur)/pq; x += alpha p; r -= alpha q; z = Dinv r; new rz partials into part(1-cur)
-      launch_pcg_update(s->stream, N, s->d_Dinv, w, p_new, s->d_q, part(s, cur), pq_part, d_x, s->d_r, s->d_zv,
-                        part(s, 1 - cur), part(s, 3));
+      launch_pcg_update(s->stream, N, s->d_Dinv, w, fused ? p_new : p_old, s->d_q, part(s, cur), pq_part, d_x, s->d_r,
+                        s->d_zv, part(s, 1 - cur), part(s, 3));
       if (s->ar) TRY(parts_sum(s, part(s, 1 - cur), part(s, 3)));  // r.z and r.r slots, one collective
       cur = 1 - cur;
-      std::swap(p_old, p_new);
+      if (fused) std::swap(p_old, p_new);
       it++;
       if (it % s->lin.check_every == 0 || it == s->lin.max_iter) {
         launch_sum_parts(s->stream, part(s, 3), s->d_scal + 2);
@@ -901,8 +913,8 @@ extern "C" int tlfea_newton_apply_hessian(tlfea_newton_t s, const double* x, dou
   const size_t n = 3 * (size_t)s->N;
   HIP_TRY(hipMemcpy(s->d_zv, x, n * sizeof(double), hipMemcpyHostToDevice));
   HIP_TRY(hipMemsetAsync(s->d_parts, 0, (size_t)5 * kNPart * sizeof(double), s->stream));
-  launch_spmv_dir_dot(s->stream, s->N, s->d->inc(), s->d_H, s->d_zv, s->d_p, 1, part(s, 1), part(s, 0), s->d_w, s->d_p2,
-                      s->d_q, part(s, 2));
+  launch_spmv_dir_dot(s->stream, s->N, s->d->inc(), s->d_H, s->d_zv, s->d_p, 1, part(s, 1), part(s, 0), s->d_p2,
+                      s->d_q, part(s, 2), true, s->spmv_nt);
   if (s->ar) TRY(iface_sum(s, s->d_q, 3, part(s, 2), kNPart));
   HIP_TRY(hipGetLastError());
   D2H(y, s->d_q, n);

@@ -79,7 +79,9 @@ void launch_pcg_init(hipStream_t s, int N, const double* b, const double* Dinv, 
                      double* r, double* z, double* rz_part, double* bb_part);
 void launch_spmv_dir_dot(hipStream_t s, int N, const Incidence& inc, const double* Hval, const double* z,
                          const double* p_old, int first, const double* rz_part_old, const double* rz_part_new,
-                         const double* w, double* p_new, double* q, double* pq_part);
+                         double* p_new, double* q, double* pq_part, bool fused, bool nt);
+void launch_pcg_direction(hipStream_t s, int n, const double* z, int first, const double* rz_part_old,
+                          const double* rz_part_new, double* p);
 void launch_pcg_update(hipStream_t s, int N, const double* Dinv, const double* w, const double* p, const double* q,
                        const double* rz_part_old, const double* pq_part, double* x, double* r, double* z,
                        double* rz_part_new, double* rr_part);
