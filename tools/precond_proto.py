@@ -257,3 +257,40 @@ def run_pmg(config="B", cells=None):
     Mc, _ = block_jacobi(Ac)
     bc = P.T @ b
     _, itc = pcg(Ac, bc, Mc); print("P1 coarse problem alone, block-Jacobi PCG iterations:", itc)
+
+
+def run_patch(config="B", cells=None):
+    """additive Schwarz over vertex patches (vertex + the mid-edge nodes of its incident edges)"""
+    w, H, b = build(config, cells)
+    X, conn = w["X"], w["conn"]; N = X.shape[0]
+    Minv, _ = block_jacobi(H)
+    _, it0 = pcg(H, b, Minv); print("block-Jacobi:", it0)
+    verts = np.unique(conn[:, :4])
+    patch = {v: {v} for v in verts}
+    for k, (a, b_) in enumerate(tl_mesh.EDGES):
+        for e in range(conn.shape[0]):
+            m_ = conn[e, 4 + k]; patch[conn[e, a]].add(m_); patch[conn[e, b_]].add(m_)
+    Hc = H.tocsc()
+    invs = []
+    cover = np.zeros(N)
+    for v in verts:
+        nodes = np.array(sorted(patch[v])); cover[nodes] += 1
+        dofs = (3 * nodes[:, None] + np.arange(3)[None, :]).reshape(-1)
+        A = H[dofs][:, dofs].toarray()
+        invs.append((dofs, np.linalg.inv(A)))
+    print("patches", len(invs), "avg size", np.mean([len(d) for d, _ in invs]), "cover min/max", cover.min(), cover.max())
+    wgt = np.repeat(1.0 / np.sqrt(cover), 3)
+    def M_as(r):
+        z = np.zeros_like(r)
+        for dofs, Ai in invs: z[dofs] += Ai @ r[dofs]
+        return z
+    def M_ras(r):  # symmetric weighted (partition of unity split as sqrt)
+        z = np.zeros_like(r); rw = wgt * r
+        for dofs, Ai in invs: z[dofs] += Ai @ rw[dofs]
+        return wgt * z
+    _, it = pcg(H, b, M_as); print("additive Schwarz vertex patches: iters", it)
+    _, it = pcg(H, b, M_ras); print("weighted additive Schwarz: iters", it)
+    # two-level: patches + exact P1 coarse
+    P, _ = p1_prolongation(conn, N); Ac = (P.T @ H @ P).tocsc(); lu = spla.splu(Ac)
+    def M2(r): return M_as(r) + P @ lu.solve(P.T @ r)
+    _, it = pcg(H, b, M2); print("additive Schwarz + exact P1 coarse: iters", it)

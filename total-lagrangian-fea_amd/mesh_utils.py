@@ -83,3 +83,79 @@ def structured_t10_box(nx, ny, nz, lx=1.0, ly=1.0, lz=1.0):
     ys = ((used // gx) % gy) * (ly / (2 * ny))
     zs = (used // (gx * gy)) * (lz / (2 * nz))
     return np.stack([xs, ys, zs], axis=1).astype(np.float64), elements
+
+
+class GridMeshGenerator:
+    """ANCF-3243 beam/net mesh generator (reference: lib_utils/mesh_utils.cc:13-167).  Nodes on an
+    (nx+1) x (ny+1) grid with id = j*(nx+1)+i, horizontal elements first; per node 4 coefficient vectors with
+    x=[x,1,0,0], y=[1,0,1,0], z=[0,0,0,1] (the beam lies at y=1, as in the reference)."""
+
+    def __init__(self, X, Y, L, include_horizontal=True, include_vertical=True):
+        if L <= 0:
+            raise ValueError("L must be > 0")
+        if abs(round(X / L) * L - X) > 1e-12 or abs(round(Y / L) * L - Y) > 1e-12:
+            raise ValueError("X and Y must be exact multiples of L")
+        self.X, self.Y, self.L = X, Y, L
+        self.nx, self.ny = int(round(X / L)), int(round(Y / L))
+        self.include_horizontal = include_horizontal and self.nx > 0
+        self.include_vertical = include_vertical and self.ny > 0
+        self.nodes, self.elements = [], []
+
+    def node_id(self, i, j):
+        if i < 0 or i > self.nx or j < 0 or j > self.ny:
+            raise IndexError("(i,j) out of range")
+        return j * (self.nx + 1) + i
+
+    def generate_mesh(self):
+        self.nodes = [(self.node_id(i, j), i * self.L, j * self.L) for j in range(self.ny + 1)
+                      for i in range(self.nx + 1)]
+        self.elements = []
+        if self.include_horizontal:
+            self.elements += [(self.node_id(i, j), self.node_id(i + 1, j)) for j in range(self.ny + 1)
+                              for i in range(self.nx)]
+        if self.include_vertical:
+            self.elements += [(self.node_id(i, j), self.node_id(i, j + 1)) for i in range(self.nx + 1)
+                              for j in range(self.ny)]
+
+    def get_num_nodes(self):
+        return len(self.nodes)
+
+    def get_num_elements(self):
+        return len(self.elements)
+
+    def get_coordinates(self):
+        n = len(self.nodes)
+        x, y, z = np.zeros(4 * n), np.zeros(4 * n), np.zeros(4 * n)
+        for nid, xv, _yv in self.nodes:
+            x[4 * nid:4 * nid + 4] = (xv, 1.0, 0.0, 0.0)
+            y[4 * nid:4 * nid + 4] = (1.0, 0.0, 1.0, 0.0)
+            z[4 * nid:4 * nid + 4] = (0.0, 0.0, 0.0, 1.0)
+        return x, y, z
+
+    def get_element_connectivity(self):
+        return np.asarray(self.elements, dtype=np.int32).reshape(-1, 2)
+
+
+def ANCF3443_generate_beam_coordinates(n_beam):
+    """Strip of n_beam ANCF-3443 shells, 2 x 1 each (reference: lib_utils/cpu_utils.cc:476-595; the arrays are
+    pinned by lib_utest/utest_utils.cc:124-221).  -> (x12, y12, z12, connectivity[n_beam,4])"""
+    n_nodes = 4 + 2 * (n_beam - 1)
+    x, y, z = np.zeros(4 * n_nodes), np.zeros(4 * n_nodes), np.zeros(4 * n_nodes)
+    pos = [(0.0, 0.0), (2.0, 0.0), (2.0, 1.0), (0.0, 1.0)]
+    for i in range(1, n_beam):
+        pos += [(2.0 * (i + 1), 0.0), (2.0 * (i + 1), 1.0)]
+    for nid, (xv, yv) in enumerate(pos):
+        x[4 * nid:4 * nid + 4] = (xv, 1.0, 0.0, 0.0)
+        y[4 * nid:4 * nid + 4] = (yv, 0.0, 1.0, 0.0)
+        z[4 * nid:4 * nid + 4] = (0.0, 0.0, 0.0, 1.0)
+    conn = np.zeros((n_beam, 4), dtype=np.int32)
+    conn[0] = (0, 1, 2, 3)
+    for i in range(1, n_beam):
+        conn[i] = (1, 4, 5, 2) if i == 1 else (4 + (i - 2) * 2, 4 + (i - 1) * 2, 4 + (i - 1) * 2 + 1, 5 + (i - 2) * 2)
+    return x, y, z, conn
+
+
+def ANCF3243_calculate_offsets(n_beam):
+    """cpu_utils.cc:597-605"""
+    start = np.arange(n_beam, dtype=np.int32) * 4
+    return start, start + 7
