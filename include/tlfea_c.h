@@ -109,6 +109,26 @@ const double *tlfea_t10_z12_device_ptr(tlfea_t10_t h);
 double *tlfea_t10_external_force_device_ptr(tlfea_t10_t h);
 double *tlfea_t10_constraint_device_ptr(tlfea_t10_t h);
 
+/* ---- GPU_ANCF3243_Data / GPU_ANCF3443_Data -------------------------------------------------------------
+ * The ANCF element types share the handle type and every `tlfea_t10_*` entry point above that is not
+ * T10-specific (material setters, SetExternalForce, SetNodalFixed -- which takes COEFFICIENT indices for these
+ * types, ANCF3243Data.cuh:778-808 --, CalcMassMatrix, CalcP, CalcInternalForce, CalcConstraintData, Retrieve*,
+ * Destroy, and the whole SyncedNewtonSolver block below).  "Nodes" there means coefficient vectors
+ * (n_coef = 4 * n_nodes; coefficient index = 4*node + slot, DOF = 3*coef + xyz).  Array sizes follow
+ * tlfea_elem_dims(): gradients [E][Q][3][S], F/P [E][Q][9], connectivity [S][E] coefficient ids. */
+int tlfea_ancf_create(int kind /*3243|3443*/, int n_nodes, int n_elements, tlfea_t10_t *out); /* ANCF3243Data.cuh:434-509, ANCF3443Data.cuh:445-520 */
+/* Setup(L,W,H, mass rule, force rule, x12,y12,z12, connectivity) (ANCF3243Data.cuh:511-670, ANCF3443Data.cuh:522-670);
+ * L,W,H per element; nqm/nq = {n_xi, n_eta, n_zeta}; conn_nodes E x nn (row-major unless conn_is_colmajor) */
+int tlfea_ancf_setup(tlfea_t10_t h, const double *L, const double *W, const double *H, const double *gauss_xi_m,
+                     const double *gauss_eta_m, const double *gauss_zeta_m, const double *weight_xi_m,
+                     const double *weight_eta_m, const double *weight_zeta_m, const int *nqm,
+                     const double *gauss_xi, const double *gauss_eta, const double *gauss_zeta,
+                     const double *weight_xi, const double *weight_eta, const double *weight_zeta, const int *nq,
+                     const double *x12, const double *y12, const double *z12, const int *conn_nodes,
+                     int conn_is_colmajor);
+int tlfea_ancf_calc_dsdu_pre(tlfea_t10_t h); /* CalcDsDuPre  ANCF3243Data.cu:290-300, ANCF3443Data.cu:256-266 */
+int tlfea_elem_dims(tlfea_t10_t h, int *S /*shape functions*/, int *Q /*force quadrature points*/);
+
 /* ---- SyncedNewtonSolver --------------------------------------------------------------------- */
 int tlfea_newton_create(tlfea_t10_t data, int n_constraints, tlfea_newton_t *out); /* SyncedNewton.cuh:37-149 */
 int tlfea_newton_destroy(tlfea_newton_t s);                                        /* dtor :151-204 */

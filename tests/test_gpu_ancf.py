@@ -1,0 +1,184 @@
+"""GPU parity of the ANCF-3243 beam and ANCF-3443 shell through the C-ABI
+against the oracle (which is pinned by the reference's NumPy prototypes, CSV mass fixtures and FD tangents)."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import orc
+from tests.helpers import relerr, tl
+from tests.test_gpu_parity import TOL_ELEM, disp_err_ok
+
+pytestmark = pytest.mark.gpu
+Q = tl.quadrature
+
+
+def beam_problem(n_elem=6, L=0.5, W=0.1, H=0.1):
+    """lib_bin/beam_sag/test_ancf3243.cc:242-292 flow (30 elements there): cantilever along x, coefficients 0-3
+    pinned, tip force on the position coefficient of the last node."""
+    gen = tl.mesh_utils.GridMeshGenerator(n_elem * L, 0.0, L, True, False)
+    gen.generate_mesh()
+    x, y, z = gen.get_coordinates()
+    conn = gen.get_element_connectivity()
+    fixed = np.array([0, 1, 2, 3], dtype=np.int32)
+    f_ext = np.zeros(3 * len(x))
+    f_ext[(conn[-1, 1] * 4) * 3 + 2] = 3100.0
+    return 3243, x, y, z, conn, (L, W, H), fixed, f_ext
+
+
+def shell_problem(n_elem=3, L=2.0, W=1.0, H=0.1):
+    """lib_bin/beam_sag/test_ancf3443.cc:240-323 flow: strip of shells, the 8 coefficients of the two left nodes
+    pinned, tip load split over the two end nodes."""
+    x, y, z, conn = tl.mesh_utils.ANCF3443_generate_beam_coordinates(n_elem)
+    fixed = np.array([0, 1, 2, 3, 12, 13, 14, 15], dtype=np.int32)
+    f_ext = np.zeros(3 * len(x))
+    for node in (conn[-1, 1], conn[-1, 2]):
+        f_ext[(node * 4) * 3 + 2] = -500.0
+    return 3443, x, y, z, conn, (L, W, H), fixed, f_ext
+
+
+def make_pair(prob, mat_kw, with_constraints=True):
+    kind, x, y, z, conn, (L, W, H), fixed, f_ext = prob
+    if mat_kw["kind"] == "svk":
+        mat = orc.svk(mat_kw["E"], mat_kw["nu"], rho0=mat_kw["rho0"], eta=mat_kw["eta"], lamd=mat_kw["lamd"])
+    else:
+        mat = orc.mooney_rivlin(mat_kw["mu10"], mat_kw["mu01"], mat_kw["kappa"], rho0=mat_kw["rho0"], eta=mat_kw["eta"],
+                                lamd=mat_kw["lamd"])
+    o = orc.AncfOracle(kind, x, y, z, conn, L, W, H, mat, fixed if with_constraints else None, f_ext)
+    o.calc_dsdu_pre()
+    o.calc_mass()
+    n_nodes = len(x) // 4
+    if kind == 3243:
+        d = tl.GPU_ANCF3243_Data(n_nodes, conn.shape[0])
+    else:
+        d = tl.GPU_ANCF3443_Data(n_nodes, conn.shape[0])
+    d.Initialize()
+    if with_constraints:
+        d.SetNodalFixed(fixed)
+    d.SetExternalForce(f_ext)
+    if kind == 3243:
+        d.Setup(L, W, H, Q.gauss_xi_m_6, Q.gauss_xi_3, Q.gauss_eta_2, Q.gauss_zeta_2, Q.weight_xi_m_6, Q.weight_xi_3,
+                Q.weight_eta_2, Q.weight_zeta_2, x, y, z, conn)
+    else:
+        d.Setup(L, W, H, Q.gauss_xi_m_7, Q.gauss_eta_m_7, Q.gauss_zeta_m_3, Q.gauss_xi_4, Q.gauss_eta_4, Q.gauss_zeta_3,
+                Q.weight_xi_m_7, Q.weight_eta_m_7, Q.weight_zeta_m_3, Q.weight_xi_4, Q.weight_eta_4, Q.weight_zeta_3,
+                x, y, z, conn)
+    d.SetDensity(mat_kw["rho0"])
+    d.SetDamping(mat_kw["eta"], mat_kw["lamd"])
+    if mat_kw["kind"] == "svk":
+        d.SetSVK(mat_kw["E"], mat_kw["nu"])
+    else:
+        d.SetMooneyRivlin(mat_kw["mu10"], mat_kw["mu01"], mat_kw["kappa"])
+    d.CalcDsDuPre()
+    d.CalcMassMatrix()
+    if with_constraints:
+        d.CalcConstraintData()
+        d.ConvertToCSR_ConstraintJacT()
+        d.BuildConstraintJacobianCSR()
+    return o, d
+
+
+SVK = dict(kind="svk", E=7e8, nu=0.33, rho0=2700.0, eta=0.0, lamd=0.0)
+SVK_D = dict(SVK, eta=1e5, lamd=1e5)  # test_ancf3243.cc:287-291
+MR_D = dict(kind="mr", mu10=4e7, mu01=1e7, kappa=5e8, rho0=920.0, eta=2e4, lamd=3e4)
+PROBLEMS = {"beam3243": beam_problem, "shell3443": shell_problem}
+
+
+def perturb(o, d, sigma=1e-3, seed=5):
+    rng = np.random.default_rng(seed)
+    xs = [a + rng.normal(0, sigma, a.shape) for a in (o.xt, o.yt, o.zt)]
+    o.x, o.y, o.z = (a.copy() for a in xs)
+    d.UpdatePositions(*xs)
+    return rng.normal(0, 0.1, 3 * o.N)
+
+
+@pytest.mark.parametrize("pname", sorted(PROBLEMS))
+def test_reference_gradients_mass_and_pattern(pname):
+    o, d = make_pair(PROBLEMS[pname](), SVK)
+    assert np.array_equal(d.RetrieveConnectivityToCPU(), o.conn)
+    assert relerr(d.RetrieveDetJToCPU(), o.detJ) < 1e-13
+    assert relerr(d.RetrieveDsDuPreToCPU(), o.gradN_a_d()) < 1e-12
+    off, col, val = d.RetrieveMassCSRToCPU()
+    assert np.array_equal(off, o.m_off) and np.array_equal(col, o.m_col)
+    assert relerr(val, o.m_val) < 1e-12
+    d.Destroy()
+
+
+def test_3243_mass_reference_csv(mesh_dir):
+    """lib_utest/utest_3243.cc:34-115 on the GPU path: 2 beams, L=2, W=H=1, rho=2700 vs data/utest CSV, 1e-4."""
+    gen = tl.mesh_utils.GridMeshGenerator(4.0, 0.0, 2.0, True, False)
+    gen.generate_mesh()
+    x, y, z = gen.get_coordinates()
+    prob = (3243, x, y, z, gen.get_element_connectivity(), (2.0, 1.0, 1.0), np.array([0], dtype=np.int32), np.zeros(3 * len(x)))
+    o, d = make_pair(prob, SVK)
+    off, col, val = d.RetrieveMassCSRToCPU()
+    M = np.zeros((len(x), len(x)))
+    for i in range(len(x)):
+        M[i, col[off[i]:off[i + 1]]] = val[off[i]:off[i + 1]]
+    ref = np.loadtxt(os.path.join(mesh_dir, "mass_matrix_2_beam.csv"), delimiter=",")
+    assert np.abs(M - ref).max() < 1e-4
+    d.Destroy()
+
+
+@pytest.mark.parametrize("pname", sorted(PROBLEMS))
+@pytest.mark.parametrize("mat", [SVK, SVK_D, MR_D], ids=["svk", "svk_damped", "mr_damped"])
+def test_gradient_and_hessian(pname, mat):
+    o, d = make_pair(PROBLEMS[pname](), mat)
+    v = perturb(o, d)
+    vp = 0.3 * v
+    h, rho = 1e-3, 1e12
+    s = tl.SyncedNewtonSolver(d, d.get_n_constraint())
+    s.SetParameters(tl.SyncedNewtonParams(1e-4, 0.0, 1e-6, rho, 5, 10, h))
+    s.SetVelocity(v, vp)
+    ng = s.EvalGradient()
+    o.v, o.v_prev = v.copy(), vp.copy()
+    f_int = o.internal_force(v)
+    g_o = o.grad_L(f_int, h, rho)
+    assert relerr(s.RetrieveGradientToCPU(), g_o) < TOL_ELEM
+    assert abs(ng - np.linalg.norm(g_o)) < 1e-12 * np.linalg.norm(g_o)
+    assert relerr(d.RetrieveInternalForceToCPU(), f_int) < TOL_ELEM
+    s.AssembleHessian()
+    ro, ci, val = s.RetrieveHessianCSRToCPU()
+    ro_o, ci_o, val_o = o.assemble_hessian(h, rho)
+    assert np.array_equal(ro, ro_o) and np.array_equal(ci, ci_o)
+    assert relerr(val, val_o) < TOL_ELEM
+    s.AssembleHessian()
+    assert np.array_equal(val, s.RetrieveHessianCSRToCPU()[2])  # bitwise reproducible
+    del s
+    d.Destroy()
+
+
+@pytest.mark.parametrize("pname", sorted(PROBLEMS))
+def test_calc_p(pname):
+    o, d = make_pair(PROBLEMS[pname](), SVK)
+    perturb(o, d)
+    F, P = o.compute_p(None)
+    d.CalcP()
+    S, Qn = o.S, o.Q
+    assert relerr(d.RetrieveDeformationGradientToCPU(), F.reshape(-1, Qn, 3, 3).transpose(0, 1, 3, 2)) < TOL_ELEM
+    assert relerr(d.RetrievePFromFToCPU(), P.reshape(-1, Qn, 3, 3).transpose(0, 1, 3, 2)) < TOL_ELEM
+    d.Destroy()
+
+
+@pytest.mark.parametrize("pname,steps", [("beam3243", 3), ("shell3443", 2)])
+def test_newton_steps(pname, steps):
+    """Driver parameters of lib_bin/beam_sag/test_ancf3243.cc:329 / test_ancf3443.cc:357: {1e-4,0,1e-6,1e14,5,10,dt},
+    Kelvin-Voigt damping 1e5/1e5 (:287-291)."""
+    o, d = make_pair(PROBLEMS[pname](), SVK_D)
+    s = tl.SyncedNewtonSolver(d, d.get_n_constraint())
+    s.Setup()
+    s.SetParameters(tl.SyncedNewtonParams(1e-4, 0.0, 1e-6, 1e14, 5, 10, 1e-3))
+    s.SetLinSolveOpts(tl.LinSolveOpts(1e-13, 50000, 10))
+    s.AnalyzeHessianSparsity()
+    oprm = orc.NewtonParams(1e-4, 0.0, 1e-6, 1e14, 5, 10, 1e-3)
+    X0 = np.stack([o.xt, o.yt, o.zt], axis=1)
+    for _ in range(steps):
+        s.Solve()
+        st_o = o.newton_step(oprm)
+        st_g = s.GetStats()
+        xg = np.stack(d.RetrievePositionToCPU(), axis=1)
+        xo = np.stack([o.x, o.y, o.z], axis=1)
+        assert disp_err_ok(xg, xo, X0), (st_g, st_o)
+        assert st_g["outer"] == st_o[0] and st_g["newton"] == st_o[1]
+    del s
+    d.Destroy()

@@ -9,9 +9,9 @@ Import with importlib (the directory name carries a hyphen):
     tl = importlib.import_module("total-lagrangian-fea_amd")
 """
 from .binding import (LIB_PATH, TlfeaError, load_library, device_count, exported_symbols)  # noqa: F401
-from .elements import GPU_FEAT10_Data  # noqa: F401
+from .elements import GPU_ANCF3243_Data, GPU_ANCF3443_Data, GPU_FEAT10_Data  # noqa: F401
 from .solvers import SyncedNewtonParams, SyncedNewtonSolver, LinSolveOpts  # noqa: F401
 from . import mesh_utils, quadrature  # noqa: F401
 
-__all__ = ["GPU_FEAT10_Data", "SyncedNewtonSolver", "SyncedNewtonParams", "LinSolveOpts", "mesh_utils",
+__all__ = ["GPU_FEAT10_Data", "GPU_ANCF3243_Data", "GPU_ANCF3443_Data", "SyncedNewtonSolver", "SyncedNewtonParams", "LinSolveOpts", "mesh_utils",
            "quadrature", "load_library", "device_count", "TlfeaError", "LIB_PATH", "exported_symbols"]

@@ -1,4 +1,6 @@
-// t10_kernels.hip -- hand-written gfx950 kernels for the 10-node tetrahedron hot path.
+// elem_kernels.hip -- hand-written gfx950 kernels of the element hot path, templated on the element type
+// <S shape functions, Q quadrature points>: T10 tetrahedron <10,5>, ANCF-3243 beam <8,12>, ANCF-3443 shell <16,48>
+// (FEAT10DataFunc.cuh, ANCF3243DataFunc.cuh, ANCF3443DataFunc.cuh share one formulation: F = sum_a x_a (x) grad N_a).
 //
 // What the reference does with four kernels, HBM round trips of F/P and ~4500 double atomics +
 // binary searches per element (FEAT10DataFunc.cuh:85-293,397-458,513-791) is done here as
@@ -240,37 +242,37 @@ void launch_dndu_pre(hipStream_t s, int E, int Epad, const int* conn, const doub
 // residual: fused compute_p + compute_internal_force (FEAT10DataFunc.cuh:85-293,397-458)
 // thread per element; fbuf[e][a][d] = sum_q (P_q grad N_a) detJ_q w_q
 // ------------------------------------------------------------------------------------------------
-template <bool STORE>
-__global__ __launch_bounds__(128) void t10_residual_kernel(T10View m, Material mat, const double* __restrict__ v,
-                                                          double* __restrict__ fbuf, double* __restrict__ Fo,
-                                                          double* __restrict__ Po, double* __restrict__ Fdo,
-                                                          double* __restrict__ Pvo) {
+template <int S, int Q, bool STORE>
+__global__ __launch_bounds__(128) void residual_kernel(ElemView m, Material mat, const double* __restrict__ v,
+                                                      double* __restrict__ fbuf, double* __restrict__ Fo,
+                                                      double* __restrict__ Po, double* __restrict__ Fdo,
+                                                      double* __restrict__ Pvo) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= m.E) return;
   const bool damp = (v != nullptr) && (mat.eta != 0.0 || mat.lamd != 0.0);  // FEAT10DataFunc.cuh:137
-  int gn[kNN];
-  double xn[kNN][3];
+  int gn[S];
+  double xn[S][3];
 #pragma unroll
-  for (int a = 0; a < kNN; a++) {
-    gn[a] = m.conn[a * m.E + e];
+  for (int a = 0; a < S; a++) {
+    gn[a] = m.conn[(size_t)a * m.E + e];
     xn[a][0] = m.x[gn[a]];
     xn[a][1] = m.y[gn[a]];
     xn[a][2] = m.z[gn[a]];
   }
-  double f[kNN][3];
+  double f[S][3];
 #pragma unroll
-  for (int a = 0; a < kNN; a++) f[a][0] = f[a][1] = f[a][2] = 0.0;
+  for (int a = 0; a < S; a++) f[a][0] = f[a][1] = f[a][2] = 0.0;
 
 #pragma unroll 1
-  for (int q = 0; q < kNQ; q++) {
-    double hq[kNN][3];
+  for (int q = 0; q < Q; q++) {
+    double hq[S][3];
 #pragma unroll
     for (int d = 0; d < 3; d++)
 #pragma unroll
-      for (int a = 0; a < kNN; a++) hq[a][d] = m.gradN_t[((size_t)(q * 3 + d) * kNN + a) * m.Epad + e];
+      for (int a = 0; a < S; a++) hq[a][d] = m.gradN_t[((size_t)(q * 3 + d) * S + a) * m.Epad + e];
     double F[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
 #pragma unroll
-    for (int a = 0; a < kNN; a++)
+    for (int a = 0; a < S; a++)
 #pragma unroll
       for (int i = 0; i < 3; i++)
 #pragma unroll
@@ -281,7 +283,7 @@ __global__ __launch_bounds__(128) void t10_residual_kernel(T10View m, Material m
     if (damp) {
       // Fdot = sum v_a (x) h_a ; Edot = sym(Fdot^T F) ; S = 2 eta Edot + lamd tr(Edot) I ; P_vis = F S
 #pragma unroll
-      for (int a = 0; a < kNN; a++) {
+      for (int a = 0; a < S; a++) {
         const double va[3] = {v[3 * gn[a] + 0], v[3 * gn[a] + 1], v[3 * gn[a] + 2]};
 #pragma unroll
         for (int i = 0; i < 3; i++)
@@ -302,24 +304,24 @@ __global__ __launch_bounds__(128) void t10_residual_kernel(T10View m, Material m
           Ed[i][j] = 0.5 * (a1 + a2);
         }
       const double trEd = Ed[0][0] + Ed[1][1] + Ed[2][2];
-      double S[3][3];
+      double Sv[3][3];
 #pragma unroll
       for (int i = 0; i < 3; i++)
 #pragma unroll
-        for (int j = 0; j < 3; j++) S[i][j] = 2.0 * mat.eta * Ed[i][j] + (i == j ? mat.lamd * trEd : 0.0);
+        for (int j = 0; j < 3; j++) Sv[i][j] = 2.0 * mat.eta * Ed[i][j] + (i == j ? mat.lamd * trEd : 0.0);
 #pragma unroll
       for (int i = 0; i < 3; i++)
 #pragma unroll
         for (int j = 0; j < 3; j++) {
           double s = 0.0;
 #pragma unroll
-          for (int k = 0; k < 3; k++) s += F[i][k] * S[k][j];
+          for (int k = 0; k < 3; k++) s += F[i][k] * Sv[k][j];
           Pv[i][j] = s;
           P[i][j] += s;
         }
     }
     if (STORE) {  // CalcP keeps the reference's F/P buffers (col-major 3x3 per (e,q)) for Retrieve*
-      const size_t o = ((size_t)e * kNQ + q) * 9;
+      const size_t o = ((size_t)e * Q + q) * 9;
 #pragma unroll
       for (int i = 0; i < 3; i++)
 #pragma unroll
@@ -330,30 +332,38 @@ __global__ __launch_bounds__(128) void t10_residual_kernel(T10View m, Material m
           Pvo[o + i + 3 * j] = Pv[i][j];
         }
     }
-    const double dV = m.detJ[e * kNQ + q] * m.qw[q];
+    const double dV = m.detJ[(size_t)e * Q + q] * m.qw[q];
 #pragma unroll
-    for (int a = 0; a < kNN; a++)
+    for (int a = 0; a < S; a++)
 #pragma unroll
       for (int i = 0; i < 3; i++) {
         const double c = P[i][0] * hq[a][0] + P[i][1] * hq[a][1] + P[i][2] * hq[a][2];
         f[a][i] += c * dV;
       }
   }
-  double* out = fbuf + (size_t)e * 30;
+  double* out = fbuf + (size_t)e * (3 * S);
 #pragma unroll
-  for (int a = 0; a < kNN; a++)
+  for (int a = 0; a < S; a++)
 #pragma unroll
     for (int i = 0; i < 3; i++) out[a * 3 + i] = f[a][i];
 }
 
-void launch_residual(hipStream_t s, const T10View& m, const Material& mat, const double* v, double* fbuf, double* F,
-                     double* P, double* Fdot, double* Pvis) {
+template <int S, int Q>
+static void launch_residual_t(hipStream_t s, const ElemView& m, const Material& mat, const double* v, double* fbuf,
+                              double* F, double* P, double* Fdot, double* Pvis) {
   const dim3 grid((m.E + 127) / 128), block(128);
   if (F)
-    hipLaunchKernelGGL(t10_residual_kernel<true>, grid, block, 0, s, m, mat, v, fbuf, F, P, Fdot, Pvis);
+    hipLaunchKernelGGL((residual_kernel<S, Q, true>), grid, block, 0, s, m, mat, v, fbuf, F, P, Fdot, Pvis);
   else
-    hipLaunchKernelGGL(t10_residual_kernel<false>, grid, block, 0, s, m, mat, v, fbuf, nullptr, nullptr, nullptr,
+    hipLaunchKernelGGL((residual_kernel<S, Q, false>), grid, block, 0, s, m, mat, v, fbuf, nullptr, nullptr, nullptr,
                        nullptr);
+}
+
+void launch_residual(hipStream_t s, const ElemView& m, const Material& mat, const double* v, double* fbuf, double* F,
+                     double* P, double* Fdot, double* Pvis) {
+  if (m.S == 10) launch_residual_t<10, 5>(s, m, mat, v, fbuf, F, P, Fdot, Pvis);
+  else if (m.S == 8) launch_residual_t<8, 12>(s, m, mat, v, fbuf, F, P, Fdot, Pvis);
+  else launch_residual_t<16, 48>(s, m, mat, v, fbuf, F, P, Fdot, Pvis);
 }
 
 // f_int[3i+d] = sum over the node's elements of their force rows (fixed order: ascending element id)
@@ -451,224 +461,260 @@ void launch_grad(hipStream_t s, int N, const Incidence& inc, const double* fbuf,
 }
 
 // ------------------------------------------------------------------------------------------------
-// tangent: one element per wavefront, lane p < 55 owns node pair (i <= j)
+// tangent: one element per wavefront; lane p (+64, +128) owns the node-pair blocks (i <= j)
 // ------------------------------------------------------------------------------------------------
-__device__ __constant__ unsigned char kPairI[kNPair] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 1, 1,
-                                                        2, 2, 2, 2, 2, 2, 2, 2, 3, 3, 3, 3, 3, 3, 3, 4, 4, 4, 4,
-                                                        4, 4, 5, 5, 5, 5, 5, 6, 6, 6, 6, 7, 7, 7, 8, 8, 9};
-__device__ __constant__ unsigned char kPairJ[kNPair] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 1, 2, 3, 4, 5, 6, 7, 8, 9,
-                                                        2, 3, 4, 5, 6, 7, 8, 9, 3, 4, 5, 6, 7, 8, 9, 4, 5, 6, 7,
-                                                        8, 9, 5, 6, 7, 8, 9, 6, 7, 8, 9, 7, 8, 9, 8, 9, 9};
-__host__ __device__ __forceinline__ int pair_index(int i, int j) { return i * 10 - (i * (i - 1)) / 2 + (j - i); }
+__host__ __device__ __forceinline__ int pair_index(int S, int i, int j) { return i * S - (i * (i - 1)) / 2 + (j - i); }
 
-// LDS map (doubles).  One 64-thread workgroup == one wavefront, so __syncthreads() is a wave-local
-// fence; the staging area for the coalesced write-out aliases the whole array after the last read.
-constexpr int kOffX = 0;      // xs[3][10]
-constexpr int kOffH = 32;     // hs[5][3][10]   (same order as the global reference layout)
-constexpr int kOffF = 184;    // Fs[5][9]
-constexpr int kOffU = 232;    // SVK: Fh[5][10][3] | FFT[5][6] | sc[5][4] ; MR: st[5][64] | At[5][81]
-constexpr int kLdsDoubles = 232 + 5 * 64 + 5 * 81;  // 957
+// lane -> (i,j) of pair p for S shape functions (row-major upper triangle)
+__device__ __forceinline__ void pair_of(int S, int p, int& i, int& j) {
+  int row = 0, rem = p;
+  while (rem >= S - row) {
+    rem -= S - row;
+    row++;
+  }
+  i = row;
+  j = row + rem;
+}
 
-template <int MODEL>
-__global__ __launch_bounds__(64) void t10_tangent_blocks_kernel(T10View m, Material mat, double h,
-                                                               double* __restrict__ Kbuf) {
-  __shared__ double lds[kLdsDoubles];
-  double* xs = lds + kOffX;
-  double* hs = lds + kOffH;
-  double* Fs = lds + kOffF;
-  double* U = lds + kOffU;
+// One 64-thread workgroup == one wavefront, so __syncthreads() is a wave-local fence.  The Q points are staged
+// through LDS in chunks of QC (all 5 for T10, 6 for the ANCF types), the write-out stage aliases the whole array.
+template <int S, int Q, int QC, int MODEL>
+struct TangentLds {
+  static constexpr int kX = 0;                                   // xs[3][S]
+  static constexpr int kH = ((3 * S + 1) / 2) * 2;               // hs[QC][3][S]  (global order)
+  static constexpr int kF = kH + ((QC * 3 * S + 1) / 2) * 2;     // Fs[QC][9]
+  static constexpr int kU = kF + ((QC * 9 + 1) / 2) * 2;         // SVK: Fh | FFT | sc ; MR: st | At
+  static constexpr int kUsize = (MODEL == kSVK) ? (QC * 3 * S + QC * 6 + QC * 4) : (QC * 64 + QC * 81);
+  static constexpr int kPairs = S * (S + 1) / 2;
+  static constexpr int kTotal = (kU + kUsize > kPairs * 9) ? (kU + kUsize) : (kPairs * 9);
+};
+
+template <int S, int Q, int QC, int MODEL>
+__global__ __launch_bounds__(64) void tangent_blocks_kernel(ElemView m, Material mat, double h,
+                                                           double* __restrict__ Kbuf) {
+  using LD = TangentLds<S, Q, QC, MODEL>;
+  constexpr int P = LD::kPairs;
+  constexpr int NPL = (P + 63) / 64;  // pairs per lane
+  __shared__ double lds[LD::kTotal];
+  double* xs = lds + LD::kX;
+  double* hs = lds + LD::kH;
+  double* Fs = lds + LD::kF;
+  double* U = lds + LD::kU;
   const int e = blockIdx.x;
   const int lane = threadIdx.x;
   const int E = m.E;
 
-  if (lane < 30) {
-    const int a = lane % 10, d = lane / 10;
-    const int g = m.conn[a * E + e];
+  for (int t = lane; t < 3 * S; t += 64) {
+    const int a = t % S, d = t / S;
+    const int g = m.conn[(size_t)a * E + e];
     const double* src = (d == 0) ? m.x : ((d == 1) ? m.y : m.z);
-    xs[d * 10 + a] = src[g];
+    xs[d * S + a] = src[g];
   }
-  {
-    const double* gsrc = m.gradN + (size_t)e * 150;
-    hs[lane] = gsrc[lane];
-    hs[lane + 64] = gsrc[lane + 64];
-    if (lane < 22) hs[lane + 128] = gsrc[lane + 128];
-  }
-  __syncthreads();
-  if (lane < 45) {  // F_q[r][c] = sum_a x_a[r] h_a^q[c]
-    const int q = lane / 9, r = (lane % 9) / 3, c = lane % 3;
-    double s = 0.0;
+  int pi[NPL], pj[NPL];
+  double acc[NPL][9];
 #pragma unroll
-    for (int a = 0; a < kNN; a++) s += xs[r * 10 + a] * hs[q * 30 + c * 10 + a];
-    Fs[lane] = s;
+  for (int n = 0; n < NPL; n++) {
+    const int p = lane + 64 * n;
+    pi[n] = pj[n] = 0;
+    if (p < P) pair_of(S, p, pi[n], pj[n]);
+#pragma unroll
+    for (int k = 0; k < 9; k++) acc[n][k] = 0.0;
   }
-  __syncthreads();
 
-  double acc[9];
+#pragma unroll 1
+  for (int q0 = 0; q0 < Q; q0 += QC) {
+    __syncthreads();  // previous chunk fully consumed (also orders the xs stage)
+    const double* gsrc = m.gradN + ((size_t)e * Q + q0) * (3 * S);
+    for (int t = lane; t < QC * 3 * S; t += 64) hs[t] = gsrc[t];
+    __syncthreads();
+    for (int t = lane; t < QC * 9; t += 64) {  // F_q[r][c] = sum_a x_a[r] h_a^q[c]
+      const int q = t / 9, r = (t % 9) / 3, c = t % 3;
+      double s = 0.0;
 #pragma unroll
-  for (int k = 0; k < 9; k++) acc[k] = 0.0;
-  const int pi = (lane < kNPair) ? kPairI[lane] : 0;
-  const int pj = (lane < kNPair) ? kPairJ[lane] : 0;
-
-  if (MODEL == kSVK) {
-    double* Fh = U;         // [5][10][3]
-    double* FFT = U + 150;  // [5][6]  (00,01,02,11,12,22)
-    double* sc = U + 180;   // [5][4]
-    for (int t = lane; t < 150; t += 64) {  // Fh_a^q[r] = sum_c F_q[r][c] h_a^q[c]
-      const int q = t / 30, a = (t % 30) / 3, r = t % 3;
-      Fh[t] = Fs[q * 9 + r * 3 + 0] * hs[q * 30 + 0 + a] + Fs[q * 9 + r * 3 + 1] * hs[q * 30 + 10 + a] +
-              Fs[q * 9 + r * 3 + 2] * hs[q * 30 + 20 + a];
-    }
-    if (lane < 30) {
-      const int q = lane / 6, k = lane % 6;
-      const int i = (k < 3) ? 0 : ((k < 5) ? 1 : 2);
-      const int j = (k < 3) ? k : ((k < 5) ? k - 2 : 2);
-      const double* F = Fs + q * 9;
-      FFT[lane] = F[i * 3 + 0] * F[j * 3 + 0] + F[i * 3 + 1] * F[j * 3 + 1] + F[i * 3 + 2] * F[j * 3 + 2];
-    } else if (lane >= 32 && lane < 37) {
-      const int q = lane - 32;
-      const double* F = Fs + q * 9;
-      double trC = 0.0;
-#pragma unroll
-      for (int k = 0; k < 9; k++) trC += F[k] * F[k];
-      const double trE = 0.5 * (trC - 3.0);
-      const double dV = m.detJ[e * kNQ + q] * m.qw[q];
-      // h*K (SVK.cuh:35-55) + C_vis (FEAT10DataFunc.cuh:695-762) share their rank-1 structure:
-      sc[q * 4 + 0] = dV * (h * mat.lambda + mat.lamd);           // * Fh_i (x) Fh_j
-      sc[q * 4 + 1] = dV * (h * mat.mu + mat.eta);                // * Fh_j (x) Fh_i  and  * (h_i.h_j) FF^T
-      sc[q * 4 + 2] = dV * h * (mat.lambda * trE - mat.mu);       // * (h_i.h_j) I
-      sc[q * 4 + 3] = dV * h * mat.mu;                            // * (Fh_i.Fh_j) I
+      for (int a = 0; a < S; a++) s += xs[r * S + a] * hs[q * 3 * S + c * S + a];
+      Fs[t] = s;
     }
     __syncthreads();
-    if (lane < kNPair) {
-#pragma unroll 1
-      for (int q = 0; q < kNQ; q++) {
-        const double* hq = hs + q * 30;
-        const double hi0 = hq[pi], hi1 = hq[10 + pi], hi2 = hq[20 + pi];
-        const double hj0 = hq[pj], hj1 = hq[10 + pj], hj2 = hq[20 + pj];
-        const double* fi = Fh + q * 30 + pi * 3;
-        const double* fj = Fh + q * 30 + pj * 3;
-        const double fi0 = fi[0], fi1 = fi[1], fi2 = fi[2];
-        const double fj0 = fj[0], fj1 = fj[1], fj2 = fj[2];
-        const double A1 = sc[q * 4 + 0], B1 = sc[q * 4 + 1], C0 = sc[q * 4 + 2], C1 = sc[q * 4 + 3];
-        const double s = hi0 * hj0 + hi1 * hj1 + hi2 * hj2;
-        const double t = fi0 * fj0 + fi1 * fj1 + fi2 * fj2;
-        const double bs = B1 * s;
-        const double cd = C0 * s + C1 * t;
-        const double u0 = A1 * fi0, u1 = A1 * fi1, u2 = A1 * fi2;
-        const double w0 = B1 * fj0, w1 = B1 * fj1, w2 = B1 * fj2;
-        const double* T = FFT + q * 6;
-        acc[0] += u0 * fj0 + w0 * fi0 + bs * T[0] + cd;
-        acc[1] += u0 * fj1 + w0 * fi1 + bs * T[1];
-        acc[2] += u0 * fj2 + w0 * fi2 + bs * T[2];
-        acc[3] += u1 * fj0 + w1 * fi0 + bs * T[1];
-        acc[4] += u1 * fj1 + w1 * fi1 + bs * T[3] + cd;
-        acc[5] += u1 * fj2 + w1 * fi2 + bs * T[4];
-        acc[6] += u2 * fj0 + w2 * fi0 + bs * T[2];
-        acc[7] += u2 * fj1 + w2 * fi1 + bs * T[4];
-        acc[8] += u2 * fj2 + w2 * fi2 + bs * T[5] + cd;
+
+    if (MODEL == kSVK) {
+      double* Fh = U;                 // [QC][S][3]
+      double* FFT = U + QC * 3 * S;   // [QC][6]  (00,01,02,11,12,22)
+      double* sc = FFT + QC * 6;      // [QC][4]
+      for (int t = lane; t < QC * 3 * S; t += 64) {  // Fh_a^q[r] = sum_c F_q[r][c] h_a^q[c]
+        const int q = t / (3 * S), a = (t % (3 * S)) / 3, r = t % 3;
+        const double* hq = hs + q * 3 * S;
+        Fh[t] = Fs[q * 9 + r * 3 + 0] * hq[a] + Fs[q * 9 + r * 3 + 1] * hq[S + a] + Fs[q * 9 + r * 3 + 2] * hq[2 * S + a];
       }
-    }
-  } else {
-    // Mooney-Rivlin: per-qp state on lanes 0..4, then the 5x81 entries of
-    //   At = dV * ( h * dP/dF  +  A_vis )         (MooneyRivlin.cuh:113-225, FEAT10DataFunc.cuh:695-762)
-    // spread over the wave, then block(i,j)[d][e] = sum_JL At[d][J][e][L] h_i[J] h_j[L].
-    double* st = U;            // [5][64]: C 0, FC 9, FFT 18, G 27, T1 36, T2 45, scalars 54..
-    double* At = U + 5 * 64;   // [5][81]
-    if (lane < kNQ) {
-      const int q = lane;
-      double F[3][3];
+      for (int t = lane; t < QC * 6; t += 64) {
+        const int q = t / 6, k = t % 6;
+        const int i = (k < 3) ? 0 : ((k < 5) ? 1 : 2);
+        const int j = (k < 3) ? k : ((k < 5) ? k - 2 : 2);
+        const double* F = Fs + q * 9;
+        FFT[t] = F[i * 3 + 0] * F[j * 3 + 0] + F[i * 3 + 1] * F[j * 3 + 1] + F[i * 3 + 2] * F[j * 3 + 2];
+      }
+      if (lane < QC) {
+        const int q = lane;
+        const double* F = Fs + q * 9;
+        double trC = 0.0;
 #pragma unroll
-      for (int i = 0; i < 3; i++)
+        for (int k = 0; k < 9; k++) trC += F[k] * F[k];
+        const double trE = 0.5 * (trC - 3.0);
+        const double dV = m.detJ[(size_t)e * Q + q0 + q] * m.qw[q0 + q];
+        // h*K (SVK.cuh:35-55) + C_vis (FEAT10DataFunc.cuh:695-762) share their rank-1 structure:
+        sc[q * 4 + 0] = dV * (h * mat.lambda + mat.lamd);      // * Fh_i (x) Fh_j
+        sc[q * 4 + 1] = dV * (h * mat.mu + mat.eta);           // * Fh_j (x) Fh_i  and  * (h_i.h_j) FF^T
+        sc[q * 4 + 2] = dV * h * (mat.lambda * trE - mat.mu);  // * (h_i.h_j) I
+        sc[q * 4 + 3] = dV * h * mat.mu;                       // * (Fh_i.Fh_j) I
+      }
+      __syncthreads();
 #pragma unroll
-        for (int j = 0; j < 3; j++) F[i][j] = Fs[q * 9 + i * 3 + j];
-      MRState s;
-      mr_state(F, mat.mu10, mat.mu01, mat.kappa, s);
-      double* o = st + q * 64;
-#pragma unroll
-      for (int i = 0; i < 3; i++)
-#pragma unroll
-        for (int j = 0; j < 3; j++) {
-          o[0 + i * 3 + j] = s.C[i][j];
-          o[9 + i * 3 + j] = s.FC[i][j];
-          o[18 + i * 3 + j] = s.FFT[i][j];
-          o[27 + i * 3 + j] = s.G[i][j];
-          o[36 + i * 3 + j] = F[i][j] - (s.I1 / 3.0) * s.G[i][j];
-          o[45 + i * 3 + j] = s.I1 * F[i][j] - s.FC[i][j] - (2.0 * s.I2 / 3.0) * s.G[i][j];
-        }
-      o[54] = s.I1;
-      o[55] = s.I2;
-      o[56] = s.t1;
-      o[57] = s.t2;
-      o[58] = s.t3;
-      o[59] = mat.kappa * (2.0 * s.J - 1.0) * s.J;
-      o[60] = m.detJ[e * kNQ + q] * m.qw[q];
-    }
-    __syncthreads();
-    for (int n = lane; n < kNQ * 81; n += 64) {
-      const int q = n / 81, r = n % 81;
-      const int i = r / 27, j = (r / 9) % 3, k = (r / 3) % 3, l = r % 3;
-      const double* o = st + q * 64;
-      const double* F = Fs + q * 9;
-      const double* C = o;
-      const double* FC = o + 9;
-      const double* FFT = o + 18;
-      const double* G = o + 27;
-      const double* T1 = o + 36;
-      const double* T2 = o + 45;
-      const double I1 = o[54], I2 = o[55], t1 = o[56], t2 = o[57], t3 = o[58], k3 = o[59], dV = o[60];
-      const double dik = (i == k) ? 1.0 : 0.0, djl = (j == l) ? 1.0 : 0.0;
-      const double Gkl = G[k * 3 + l], Gij = G[i * 3 + j], GilGkj = G[i * 3 + l] * G[k * 3 + j];
-      const double dt1 = (-2.0 / 3.0) * t1 * Gkl;
-      const double dt2 = (-4.0 / 3.0) * t2 * Gkl;
-      const double dt3 = k3 * Gkl;
-      const double dT1 = dik * djl - (2.0 / 3.0) * F[k * 3 + l] * Gij + (I1 / 3.0) * GilGkj;
-      const double dT2 = 2.0 * F[k * 3 + l] * F[i * 3 + j] + I1 * dik * djl -
-                         (dik * C[l * 3 + j] + F[i * 3 + l] * F[k * 3 + j] + djl * FFT[i * 3 + k]) -
-                         (4.0 / 3.0) * (I1 * F[k * 3 + l] - FC[k * 3 + l]) * Gij + (2.0 * I2 / 3.0) * GilGkj;
-      const double Ael = dt1 * T1[i * 3 + j] + t1 * dT1 + dt2 * T2[i * 3 + j] + t2 * dT2 + dt3 * Gij - t3 * GilGkj;
-      // viscous: eta F[d][L]F[e][J] + eta FF^T[d][e] d_JL + lamd F[d][J]F[e][L]   (d=i, J=j, e=k, L=l)
-      const double Avis = mat.eta * (F[i * 3 + l] * F[k * 3 + j] + FFT[i * 3 + k] * djl) +
-                          mat.lamd * F[i * 3 + j] * F[k * 3 + l];
-      At[n] = dV * (h * Ael + Avis);
-    }
-    __syncthreads();
-    if (lane < kNPair) {
+      for (int n = 0; n < NPL; n++) {
+        if (lane + 64 * n >= P) continue;
+        const int i = pi[n], j = pj[n];
 #pragma unroll 1
-      for (int q = 0; q < kNQ; q++) {
-        const double* hq = hs + q * 30;
-        const double hi[3] = {hq[pi], hq[10 + pi], hq[20 + pi]};
-        const double hj[3] = {hq[pj], hq[10 + pj], hq[20 + pj]};
-        const double* A = At + q * 81;
+        for (int q = 0; q < QC; q++) {
+          const double* hq = hs + q * 3 * S;
+          const double hi0 = hq[i], hi1 = hq[S + i], hi2 = hq[2 * S + i];
+          const double hj0 = hq[j], hj1 = hq[S + j], hj2 = hq[2 * S + j];
+          const double* fi = Fh + q * 3 * S + i * 3;
+          const double* fj = Fh + q * 3 * S + j * 3;
+          const double fi0 = fi[0], fi1 = fi[1], fi2 = fi[2];
+          const double fj0 = fj[0], fj1 = fj[1], fj2 = fj[2];
+          const double A1 = sc[q * 4 + 0], B1 = sc[q * 4 + 1], C0 = sc[q * 4 + 2], C1 = sc[q * 4 + 3];
+          const double s = hi0 * hj0 + hi1 * hj1 + hi2 * hj2;
+          const double t = fi0 * fj0 + fi1 * fj1 + fi2 * fj2;
+          const double bs = B1 * s;
+          const double cd = C0 * s + C1 * t;
+          const double u0 = A1 * fi0, u1 = A1 * fi1, u2 = A1 * fi2;
+          const double w0 = B1 * fj0, w1 = B1 * fj1, w2 = B1 * fj2;
+          const double* T = FFT + q * 6;
+          acc[n][0] += u0 * fj0 + w0 * fi0 + bs * T[0] + cd;
+          acc[n][1] += u0 * fj1 + w0 * fi1 + bs * T[1];
+          acc[n][2] += u0 * fj2 + w0 * fi2 + bs * T[2];
+          acc[n][3] += u1 * fj0 + w1 * fi0 + bs * T[1];
+          acc[n][4] += u1 * fj1 + w1 * fi1 + bs * T[3] + cd;
+          acc[n][5] += u1 * fj2 + w1 * fi2 + bs * T[4];
+          acc[n][6] += u2 * fj0 + w2 * fi0 + bs * T[2];
+          acc[n][7] += u2 * fj1 + w2 * fi1 + bs * T[4];
+          acc[n][8] += u2 * fj2 + w2 * fi2 + bs * T[5] + cd;
+        }
+      }
+    } else {
+      // Mooney-Rivlin: per-qp state on lanes 0..QC-1, then the QC x 81 entries of
+      //   At = dV * ( h * dP/dF  +  A_vis )         (MooneyRivlin.cuh:113-225, FEAT10DataFunc.cuh:695-762)
+      // spread over the wave, then block(i,j)[d][e] = sum_JL At[d][J][e][L] h_i[J] h_j[L].
+      double* st = U;            // [QC][64]: C 0, FC 9, FFT 18, G 27, T1 36, T2 45, scalars 54..
+      double* At = U + QC * 64;  // [QC][81]
+      if (lane < QC) {
+        const int q = lane;
+        double F[3][3];
 #pragma unroll
-        for (int d = 0; d < 3; d++)
+        for (int i = 0; i < 3; i++)
 #pragma unroll
-          for (int ee = 0; ee < 3; ee++) {
-            double s = 0.0;
+          for (int j = 0; j < 3; j++) F[i][j] = Fs[q * 9 + i * 3 + j];
+        MRState ms;
+        mr_state(F, mat.mu10, mat.mu01, mat.kappa, ms);
+        double* o = st + q * 64;
 #pragma unroll
-            for (int J = 0; J < 3; J++) {
-              const double* a = A + ((d * 3 + J) * 3 + ee) * 3;
-              s += hi[J] * (a[0] * hj[0] + a[1] * hj[1] + a[2] * hj[2]);
-            }
-            acc[d * 3 + ee] += s;
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+          for (int j = 0; j < 3; j++) {
+            o[0 + i * 3 + j] = ms.C[i][j];
+            o[9 + i * 3 + j] = ms.FC[i][j];
+            o[18 + i * 3 + j] = ms.FFT[i][j];
+            o[27 + i * 3 + j] = ms.G[i][j];
+            o[36 + i * 3 + j] = F[i][j] - (ms.I1 / 3.0) * ms.G[i][j];
+            o[45 + i * 3 + j] = ms.I1 * F[i][j] - ms.FC[i][j] - (2.0 * ms.I2 / 3.0) * ms.G[i][j];
           }
+        o[54] = ms.I1;
+        o[55] = ms.I2;
+        o[56] = ms.t1;
+        o[57] = ms.t2;
+        o[58] = ms.t3;
+        o[59] = mat.kappa * (2.0 * ms.J - 1.0) * ms.J;
+        o[60] = m.detJ[(size_t)e * Q + q0 + q] * m.qw[q0 + q];
+      }
+      __syncthreads();
+      for (int n = lane; n < QC * 81; n += 64) {
+        const int q = n / 81, r = n % 81;
+        const int i = r / 27, j = (r / 9) % 3, k = (r / 3) % 3, l = r % 3;
+        const double* o = st + q * 64;
+        const double* F = Fs + q * 9;
+        const double* C = o;
+        const double* FC = o + 9;
+        const double* FFT = o + 18;
+        const double* G = o + 27;
+        const double* T1 = o + 36;
+        const double* T2 = o + 45;
+        const double I1 = o[54], I2 = o[55], t1 = o[56], t2 = o[57], t3 = o[58], k3 = o[59], dV = o[60];
+        const double dik = (i == k) ? 1.0 : 0.0, djl = (j == l) ? 1.0 : 0.0;
+        const double Gkl = G[k * 3 + l], Gij = G[i * 3 + j], GilGkj = G[i * 3 + l] * G[k * 3 + j];
+        const double dt1 = (-2.0 / 3.0) * t1 * Gkl;
+        const double dt2 = (-4.0 / 3.0) * t2 * Gkl;
+        const double dt3 = k3 * Gkl;
+        const double dT1 = dik * djl - (2.0 / 3.0) * F[k * 3 + l] * Gij + (I1 / 3.0) * GilGkj;
+        const double dT2 = 2.0 * F[k * 3 + l] * F[i * 3 + j] + I1 * dik * djl -
+                           (dik * C[l * 3 + j] + F[i * 3 + l] * F[k * 3 + j] + djl * FFT[i * 3 + k]) -
+                           (4.0 / 3.0) * (I1 * F[k * 3 + l] - FC[k * 3 + l]) * Gij + (2.0 * I2 / 3.0) * GilGkj;
+        const double Ael = dt1 * T1[i * 3 + j] + t1 * dT1 + dt2 * T2[i * 3 + j] + t2 * dT2 + dt3 * Gij - t3 * GilGkj;
+        // viscous: eta F[d][L]F[e][J] + eta FF^T[d][e] d_JL + lamd F[d][J]F[e][L]   (d=i, J=j, e=k, L=l)
+        const double Avis = mat.eta * (F[i * 3 + l] * F[k * 3 + j] + FFT[i * 3 + k] * djl) +
+                            mat.lamd * F[i * 3 + j] * F[k * 3 + l];
+        At[n] = dV * (h * Ael + Avis);
+      }
+      __syncthreads();
+#pragma unroll
+      for (int n = 0; n < NPL; n++) {
+        if (lane + 64 * n >= P) continue;
+        const int i = pi[n], j = pj[n];
+#pragma unroll 1
+        for (int q = 0; q < QC; q++) {
+          const double* hq = hs + q * 3 * S;
+          const double hi[3] = {hq[i], hq[S + i], hq[2 * S + i]};
+          const double hj[3] = {hq[j], hq[S + j], hq[2 * S + j]};
+          const double* A = At + q * 81;
+#pragma unroll
+          for (int d = 0; d < 3; d++)
+#pragma unroll
+            for (int ee = 0; ee < 3; ee++) {
+              double sm = 0.0;
+#pragma unroll
+              for (int J = 0; J < 3; J++) {
+                const double* a = A + ((d * 3 + J) * 3 + ee) * 3;
+                sm += hi[J] * (a[0] * hj[0] + a[1] * hj[1] + a[2] * hj[2]);
+              }
+              acc[n][d * 3 + ee] += sm;
+            }
+        }
       }
     }
   }
   __syncthreads();  // everyone is done reading the staged inputs: reuse LDS as the write-out stage
-  if (lane < kNPair) {
 #pragma unroll
-    for (int k = 0; k < 9; k++) lds[lane * 9 + k] = acc[k];
+  for (int n = 0; n < NPL; n++) {
+    const int p = lane + 64 * n;
+    if (p < P) {
+#pragma unroll
+      for (int k = 0; k < 9; k++) lds[p * 9 + k] = acc[n][k];
+    }
   }
   __syncthreads();
-  double* out = Kbuf + (size_t)e * (kNPair * 9);
-  for (int t = lane; t < kNPair * 9; t += 64) out[t] = lds[t];
+  double* out = Kbuf + (size_t)e * (P * 9);
+  for (int t = lane; t < P * 9; t += 64) out[t] = lds[t];
 }
 
-void launch_tangent_blocks(hipStream_t s, const T10View& m, const Material& mat, double h, double* Kbuf) {
+template <int S, int Q, int QC>
+static void launch_tangent_t(hipStream_t s, const ElemView& m, const Material& mat, double h, double* Kbuf) {
   if (mat.model == kMooneyRivlin)
-    hipLaunchKernelGGL(t10_tangent_blocks_kernel<kMooneyRivlin>, dim3(m.E), dim3(64), 0, s, m, mat, h, Kbuf);
+    hipLaunchKernelGGL((tangent_blocks_kernel<S, Q, QC, kMooneyRivlin>), dim3(m.E), dim3(64), 0, s, m, mat, h, Kbuf);
   else
-    hipLaunchKernelGGL(t10_tangent_blocks_kernel<kSVK>, dim3(m.E), dim3(64), 0, s, m, mat, h, Kbuf);
+    hipLaunchKernelGGL((tangent_blocks_kernel<S, Q, QC, kSVK>), dim3(m.E), dim3(64), 0, s, m, mat, h, Kbuf);
+}
+
+void launch_tangent_blocks(hipStream_t s, const ElemView& m, const Material& mat, double h, double* Kbuf) {
+  if (m.S == 10) launch_tangent_t<10, 5, 5>(s, m, mat, h, Kbuf);
+  else if (m.S == 8) launch_tangent_t<8, 12, 6>(s, m, mat, h, Kbuf);
+  else launch_tangent_t<16, 48, 6>(s, m, mat, h, Kbuf);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -676,7 +722,7 @@ void launch_tangent_blocks(hipStream_t s, const T10View& m, const Material& mat,
 // H layout == the reference's DOF-level CSR (SyncedNewton.cu:163-205): for node i with deg
 // neighbours, values[9*off[i] + d*3*deg + 3*k + e] = H(3i+d, 3*cols[off[i]+k]+e).
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void assemble_rows_kernel(int N, Incidence inc, const double* __restrict__ Kbuf,
+__global__ __launch_bounds__(64) void assemble_rows_kernel(int N, int S, Incidence inc, const double* __restrict__ Kbuf,
                                                           const double* __restrict__ mval, double inv_h,
                                                           const int* __restrict__ fixed_slot,
                                                           const double* __restrict__ nw, double penalty,
@@ -687,6 +733,7 @@ __global__ __launch_bounds__(64) void assemble_rows_kernel(int N, Incidence inc,
   const int off0 = inc.off[i];
   const int deg = inc.off[i + 1] - off0;
   const int n9 = 9 * deg, row = 3 * deg;
+  const int npair = S * (S + 1) / 2;
   for (int t = lane; t < n9; t += 64) acc[t] = 0.0;
   __syncthreads();
   // M/h on the xyz-diagonal of every block (SyncedNewton.cu:214-259)
@@ -704,12 +751,13 @@ __global__ __launch_bounds__(64) void assemble_rows_kernel(int N, Incidence inc,
   const int k0 = inc.n2e_off[i], k1 = inc.n2e_off[i + 1];
   for (int k = k0; k < k1; k++) {
     const int code = inc.n2e[k];
-    const int e = code / 10, il = code - e * 10;
-    const double* Ke = Kbuf + (size_t)e * (kNPair * 9);
-    const int* pos = inc.n2e_pos + (size_t)k * 10;
-    for (int t = lane; t < 90; t += 64) {
+    const int e = code / S, il = code - e * S;
+    const double* Ke = Kbuf + (size_t)e * (npair * 9);
+    const int* pos = inc.n2e_pos + (size_t)k * S;
+    for (int t = lane; t < 9 * S; t += 64) {
       const int j = t / 9, dd = (t % 9) / 3, ee = t % 3;
-      const double val = (il <= j) ? Ke[pair_index(il, j) * 9 + dd * 3 + ee] : Ke[pair_index(j, il) * 9 + ee * 3 + dd];
+      const double val =
+          (il <= j) ? Ke[pair_index(S, il, j) * 9 + dd * 3 + ee] : Ke[pair_index(S, j, il) * 9 + ee * 3 + dd];
       acc[dd * row + 3 * pos[j] + ee] += val;
     }
     __syncthreads();
@@ -718,18 +766,18 @@ __global__ __launch_bounds__(64) void assemble_rows_kernel(int N, Incidence inc,
   for (int t = lane; t < n9; t += 64) out[t] = acc[t];
 }
 
-void launch_assemble_rows(hipStream_t s, int N, int maxdeg, const Incidence& inc, const double* Kbuf,
+void launch_assemble_rows(hipStream_t s, int N, int S, int maxdeg, const Incidence& inc, const double* Kbuf,
                           const double* mval, double inv_h, const int* fixed_slot, const double* nw, double penalty,
                           double* Hval) {
   const size_t lds = (size_t)9 * maxdeg * sizeof(double);
-  hipLaunchKernelGGL(assemble_rows_kernel, dim3(N), dim3(64), lds, s, N, inc, Kbuf, mval, inv_h, fixed_slot, nw,
+  hipLaunchKernelGGL(assemble_rows_kernel, dim3(N), dim3(64), lds, s, N, S, inc, Kbuf, mval, inv_h, fixed_slot, nw,
                      penalty, Hval);
 }
 
 // ------------------------------------------------------------------------------------------------
 // consistent mass (FEAT10Data.cu:206-278), row-owner form: thread per node row, fixed order
 // ------------------------------------------------------------------------------------------------
-__global__ void mass_values_kernel(T10View m, Incidence inc, const double* __restrict__ qx,
+__global__ void mass_values_kernel(ElemView m, Incidence inc, const double* __restrict__ qx,
                                    const double* __restrict__ qy, const double* __restrict__ qz, double rho0,
                                    double* __restrict__ mval) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -758,7 +806,7 @@ __global__ void mass_values_kernel(T10View m, Incidence inc, const double* __res
   }
 }
 
-void launch_mass_values(hipStream_t s, const T10View& m, const Incidence& inc, const double* qx, const double* qy,
+void launch_mass_values(hipStream_t s, const ElemView& m, const Incidence& inc, const double* qx, const double* qy,
                         const double* qz, double rho0, double* mval) {
   hipLaunchKernelGGL(mass_values_kernel, dim3((m.N + 127) / 128), dim3(128), 0, s, m, inc, qx, qy, qz, rho0, mval);
 }

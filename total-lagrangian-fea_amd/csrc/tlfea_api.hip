@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "../../include/tlfea_c.h"
+#include "ancf_host.h"
 #include "tlfea_internal.h"
 
 using namespace tlfea;
@@ -47,15 +48,20 @@ int dmalloc(T** p, size_t n) {
 }  // namespace
 
 // =================================================================================================
-struct tlfea_t10_s {
+struct tlfea_t10_s {  // any element type; the name is kept for the ABI's first element type
+  int kind = kT10, S = kNN, Q = kNQ, nn = kNN;  // shape functions, force QPs, nodes per element
+  int n_nodes = 0;                             // mesh nodes (== N for T10, N/4 for the ANCF types)
   int E = 0, N = 0, Epad = 0;
+  // ANCF set-up data (host): per-element dimensions, (B^T)^-1 column-major, force and mass rules
+  std::vector<double> Lv, Wv, Hv, Binv;
+  std::vector<double> fr[6], mr[6];  // gauss xi/eta/zeta, weight xi/eta/zeta
   int n_constraint = 0, n_fixed = 0;
   hipStream_t stream = nullptr;  // default stream, as the reference
   // mesh + state
   int* d_conn = nullptr;
   double *d_x = nullptr, *d_y = nullptr, *d_z = nullptr, *d_xt = nullptr, *d_yt = nullptr, *d_zt = nullptr;
   double *d_qx = nullptr, *d_qy = nullptr, *d_qz = nullptr;
-  double h_qw[kNQ] = {0};
+  double h_qw[kMaxQ] = {0};
   double *d_gradN = nullptr, *d_gradN_t = nullptr, *d_detJ = nullptr;
   double *d_F = nullptr, *d_P = nullptr, *d_Fdot = nullptr, *d_Pvis = nullptr;  // lazily, CalcP only
   double *d_fbuf = nullptr, *d_fint = nullptr, *d_fext = nullptr;
@@ -74,12 +80,12 @@ struct tlfea_t10_s {
   bool is_setup = false, is_constraints_setup = false, is_csr_setup = false, is_j_csr_setup = false,
        is_cj_csr_setup = false, have_dndu = false;
 
-  T10View view() const {
-    T10View v;
-    v.E = E; v.N = N; v.Epad = Epad;
+  ElemView view() const {
+    ElemView v;
+    v.E = E; v.N = N; v.Epad = Epad; v.S = S; v.Q = Q;
     v.conn = d_conn; v.x = d_x; v.y = d_y; v.z = d_z;
     v.gradN = d_gradN; v.gradN_t = d_gradN_t; v.detJ = d_detJ;
-    for (int q = 0; q < kNQ; q++) v.qw[q] = h_qw[q];
+    for (int q = 0; q < kMaxQ; q++) v.qw[q] = h_qw[q];
     return v;
   }
   Incidence inc() const { return Incidence{d_n2e_off, d_n2e, d_n2e_pos, d_off, d_cols, d_diagpos}; }
@@ -93,25 +99,49 @@ extern "C" int tlfea_device_count(void) {
   return n;
 }
 
+static int alloc_common(tlfea_t10_t h) {
+  const size_t E = h->E, N = h->N, S = h->S, Q = h->Q;
+  h->Epad = (h->E + 63) / 64 * 64;
+  TRY(dmalloc(&h->d_conn, E * S));
+  TRY(dmalloc(&h->d_x, N)); TRY(dmalloc(&h->d_y, N)); TRY(dmalloc(&h->d_z, N));
+  TRY(dmalloc(&h->d_xt, N)); TRY(dmalloc(&h->d_yt, N)); TRY(dmalloc(&h->d_zt, N));
+  TRY(dmalloc(&h->d_qx, kNQ)); TRY(dmalloc(&h->d_qy, kNQ)); TRY(dmalloc(&h->d_qz, kNQ));
+  TRY(dmalloc(&h->d_gradN, E * Q * 3 * S));
+  TRY(dmalloc(&h->d_gradN_t, (size_t)h->Epad * Q * 3 * S));
+  TRY(dmalloc(&h->d_detJ, E * Q));
+  TRY(dmalloc(&h->d_fbuf, E * 3 * S));
+  TRY(dmalloc(&h->d_fint, 3 * N));
+  TRY(dmalloc(&h->d_fext, 3 * N));
+  HIP_TRY(hipMemset(h->d_fext, 0, 3 * N * sizeof(double)));
+  return 0;
+}
+
 extern "C" int tlfea_t10_create(int n_elem, int n_nodes, tlfea_t10_t* out) {
   if (!out || n_elem <= 0 || n_nodes <= 0) return fail("tlfea_t10_create: bad arguments");
   if (tlfea_device_count() <= 0) return fail("tlfea_t10_create: no HIP device visible (this engine has no CPU path)");
   auto* h = new tlfea_t10_s();
   h->E = n_elem;
-  h->N = n_nodes;
-  h->Epad = (n_elem + 63) / 64 * 64;
-  const size_t E = n_elem, N = n_nodes;
-  TRY(dmalloc(&h->d_conn, E * kNN));
-  TRY(dmalloc(&h->d_x, N)); TRY(dmalloc(&h->d_y, N)); TRY(dmalloc(&h->d_z, N));
-  TRY(dmalloc(&h->d_xt, N)); TRY(dmalloc(&h->d_yt, N)); TRY(dmalloc(&h->d_zt, N));
-  TRY(dmalloc(&h->d_qx, kNQ)); TRY(dmalloc(&h->d_qy, kNQ)); TRY(dmalloc(&h->d_qz, kNQ));
-  TRY(dmalloc(&h->d_gradN, E * kNQ * 30));
-  TRY(dmalloc(&h->d_gradN_t, (size_t)h->Epad * kNQ * 30));
-  TRY(dmalloc(&h->d_detJ, E * kNQ));
-  TRY(dmalloc(&h->d_fbuf, E * 30));
-  TRY(dmalloc(&h->d_fint, 3 * N));
-  TRY(dmalloc(&h->d_fext, 3 * N));
-  HIP_TRY(hipMemset(h->d_fext, 0, 3 * N * sizeof(double)));
+  h->N = h->n_nodes = n_nodes;
+  TRY(alloc_common(h));
+  *out = h;
+  return 0;
+}
+
+// GPU_ANCF3243_Data(int n_nodes, int n_elements) / GPU_ANCF3443_Data(int n_nodes, int n_elements) + Initialize()
+// (ANCF3243Data.cuh:434-509, ANCF3443Data.cuh:445-520).  kind = 3243 | 3443.
+extern "C" int tlfea_ancf_create(int kind, int n_nodes, int n_elements, tlfea_t10_t* out) {
+  if (!out || n_elements <= 0 || n_nodes <= 0 || (kind != 3243 && kind != 3443))
+    return fail("tlfea_ancf_create: bad arguments");
+  if (tlfea_device_count() <= 0) return fail("tlfea_ancf_create: no HIP device visible (this engine has no CPU path)");
+  auto* h = new tlfea_t10_s();
+  h->kind = kind == 3243 ? kANCF3243 : kANCF3443;
+  h->S = kind == 3243 ? 8 : 16;
+  h->Q = kind == 3243 ? 12 : 48;
+  h->nn = h->S / 4;
+  h->E = n_elements;
+  h->n_nodes = n_nodes;
+  h->N = 4 * n_nodes;  // coefficient vectors r, r_u, r_v, r_w per node
+  TRY(alloc_common(h));
   *out = h;
   return 0;
 }
@@ -132,6 +162,7 @@ extern "C" int tlfea_t10_setup(tlfea_t10_t h, const double* qx, const double* qy
                                const double* x, const double* y, const double* z, const int* conn) {
   if (!h) return fail("null handle");
   if (h->is_setup) return fail("GPU_FEAT10_Data is already set up.");
+  if (h->kind != kT10) return fail("tlfea_t10_setup called on an ANCF handle");
   const size_t N = h->N, E = h->E;
   for (size_t k = 0; k < E * kNN; k++)
     if (conn[k] < 0 || conn[k] >= h->N) return fail("tlfea_t10_setup: connectivity index out of range");
@@ -247,8 +278,10 @@ extern "C" int tlfea_t10_update_constraint_targets(tlfea_t10_t h, const double* 
   return 0;
 }
 
+extern "C" int tlfea_ancf_calc_dsdu_pre(tlfea_t10_t h);
 extern "C" int tlfea_t10_calc_dndu_pre(tlfea_t10_t h) {
   NEED_SETUP(h, "CalcDnDuPre.");
+  if (h->kind != kT10) return tlfea_ancf_calc_dsdu_pre(h);
   launch_dndu_pre(h->stream, h->E, h->Epad, h->d_conn, h->d_x, h->d_y, h->d_z, h->d_qx, h->d_qy, h->d_qz, h->d_gradN,
                   h->d_gradN_t, h->d_detJ);
   HIP_TRY(hipGetLastError());
@@ -262,33 +295,33 @@ extern "C" int tlfea_t10_calc_dndu_pre(tlfea_t10_t h) {
 extern "C" int tlfea_t10_build_mass_csr_pattern(tlfea_t10_t h) {
   NEED_SETUP(h, "BuildMassCSRPattern.");
   if (h->is_csr_setup) return 0;
-  const int E = h->E, N = h->N;
+  const int E = h->E, N = h->N, S = h->S;
   const int* conn = h->h_conn.data();
   std::vector<int>& n2e_off = h->h_n2e_off;
   std::vector<int>& n2e = h->h_n2e;
   n2e_off.assign(N + 1, 0);
-  for (int a = 0; a < kNN; a++)
+  for (int a = 0; a < S; a++)
     for (int e = 0; e < E; e++) n2e_off[conn[(size_t)a * E + e] + 1]++;
   for (int i = 0; i < N; i++) n2e_off[i + 1] += n2e_off[i];
-  n2e.assign((size_t)E * kNN, 0);
+  n2e.assign((size_t)E * S, 0);
   {
     std::vector<int> cur(n2e_off.begin(), n2e_off.end() - 1);
     for (int e = 0; e < E; e++)  // ascending e per node -> fixed summation order
-      for (int a = 0; a < kNN; a++) n2e[cur[conn[(size_t)a * E + e]]++] = e * kNN + a;
+      for (int a = 0; a < S; a++) n2e[cur[conn[(size_t)a * E + e]]++] = e * S + a;
   }
   std::vector<int> deg(N, 0);
   std::vector<std::vector<int>> rows;  // per-thread scratch would be enough, keep it simple & parallel
   h->h_off.assign(N + 1, 0);
-  std::vector<int> tmp_cols((size_t)E * kNN * kNN);  // upper bound, compacted below
+  std::vector<int> tmp_cols((size_t)E * S * S);  // upper bound, compacted below
   std::vector<size_t> tmp_off(N + 1, 0);
-  for (int i = 0; i < N; i++) tmp_off[i + 1] = tmp_off[i] + (size_t)(n2e_off[i + 1] - n2e_off[i]) * kNN;
+  for (int i = 0; i < N; i++) tmp_off[i + 1] = tmp_off[i] + (size_t)(n2e_off[i + 1] - n2e_off[i]) * S;
 #pragma omp parallel for schedule(dynamic, 1024)
   for (int i = 0; i < N; i++) {
     int* c = tmp_cols.data() + tmp_off[i];
     int n = 0;
     for (int k = n2e_off[i]; k < n2e_off[i + 1]; k++) {
-      const int e = n2e[k] / kNN;
-      for (int a = 0; a < kNN; a++) c[n++] = conn[(size_t)a * E + e];
+      const int e = n2e[k] / S;
+      for (int a = 0; a < S; a++) c[n++] = conn[(size_t)a * E + e];
     }
     std::sort(c, c + n);
     deg[i] = (int)(std::unique(c, c + n) - c);
@@ -305,7 +338,7 @@ extern "C" int tlfea_t10_build_mass_csr_pattern(tlfea_t10_t h) {
   h->nnz_coef = (int)nnz;
   h->maxdeg = maxdeg;
   h->h_cols.resize((size_t)nnz);
-  std::vector<int> pos((size_t)E * kNN * kNN), diagpos(N, 0);
+  std::vector<int> pos((size_t)E * S * S), diagpos(N, 0);
 #pragma omp parallel for schedule(dynamic, 1024)
   for (int i = 0; i < N; i++) {
     const int* c = tmp_cols.data() + tmp_off[i];
@@ -313,35 +346,168 @@ extern "C" int tlfea_t10_build_mass_csr_pattern(tlfea_t10_t h) {
     std::copy(c, c + deg[i], dst);
     diagpos[i] = (int)(std::lower_bound(dst, dst + deg[i], i) - dst);
     for (int k = n2e_off[i]; k < n2e_off[i + 1]; k++) {
-      const int e = n2e[k] / kNN;
-      for (int a = 0; a < kNN; a++)
-        pos[(size_t)k * kNN + a] = (int)(std::lower_bound(dst, dst + deg[i], conn[(size_t)a * E + e]) - dst);
+      const int e = n2e[k] / S;
+      for (int a = 0; a < S; a++)
+        pos[(size_t)k * S + a] = (int)(std::lower_bound(dst, dst + deg[i], conn[(size_t)a * E + e]) - dst);
     }
   }
   TRY(dmalloc(&h->d_off, (size_t)N + 1));
   TRY(dmalloc(&h->d_cols, (size_t)nnz));
   TRY(dmalloc(&h->d_n2e_off, (size_t)N + 1));
-  TRY(dmalloc(&h->d_n2e, (size_t)E * kNN));
-  TRY(dmalloc(&h->d_n2e_pos, (size_t)E * kNN * kNN));
+  TRY(dmalloc(&h->d_n2e, (size_t)E * S));
+  TRY(dmalloc(&h->d_n2e_pos, (size_t)E * S * S));
   TRY(dmalloc(&h->d_diagpos, (size_t)N));
   TRY(dmalloc(&h->d_mval, (size_t)nnz));
   HIP_TRY(hipMemcpy(h->d_off, h->h_off.data(), ((size_t)N + 1) * sizeof(int), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(h->d_cols, h->h_cols.data(), (size_t)nnz * sizeof(int), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(h->d_n2e_off, n2e_off.data(), ((size_t)N + 1) * sizeof(int), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(h->d_n2e, n2e.data(), (size_t)E * kNN * sizeof(int), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(h->d_n2e_pos, pos.data(), (size_t)E * kNN * kNN * sizeof(int), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(h->d_n2e, n2e.data(), (size_t)E * S * sizeof(int), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(h->d_n2e_pos, pos.data(), (size_t)E * S * S * sizeof(int), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(h->d_diagpos, diagpos.data(), (size_t)N * sizeof(int), hipMemcpyHostToDevice));
   HIP_TRY(hipMemset(h->d_mval, 0, (size_t)nnz * sizeof(double)));
   h->is_csr_setup = true;
   return 0;
 }
 
+static int ancf_mass_host(tlfea_t10_t h);
 extern "C" int tlfea_t10_calc_mass_matrix(tlfea_t10_t h) {
   NEED_SETUP(h, "CalcMassMatrix.");
   if (!h->is_csr_setup) TRY(tlfea_t10_build_mass_csr_pattern(h));
+  if (h->kind != kT10) return ancf_mass_host(h);
   launch_mass_values(h->stream, h->view(), h->inc(), h->d_qx, h->d_qy, h->d_qz, h->mat.rho0, h->d_mval);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipDeviceSynchronize());
+  return 0;
+}
+
+// Setup(length,width,height per element, mass rule, force rule, x12,y12,z12, connectivity)
+// (ANCF3243Data.cuh:511-651 and its scalar overload :653-670; ANCF3443Data.cuh:522-670).
+// rules: gauss/weight arrays in the order xi_m, eta_m, zeta_m (mass) and xi, eta, zeta (force);
+// conn_nodes: E x nn node ids, row-major [e][k] (set conn_is_colmajor for an Eigen-style E x nn matrix).
+extern "C" int tlfea_ancf_setup(tlfea_t10_t h, const double* L, const double* W, const double* H,
+                                const double* gxm, const double* gym, const double* gzm, const double* wxm,
+                                const double* wym, const double* wzm, const int* nqm, const double* gx,
+                                const double* gy, const double* gz, const double* wx, const double* wy,
+                                const double* wz, const int* nq, const double* x12, const double* y12,
+                                const double* z12, const int* conn_nodes, int conn_is_colmajor) {
+  if (!h || h->kind == kT10) return fail("tlfea_ancf_setup: not an ANCF handle");
+  if (h->is_setup) return fail("GPU_ANCF data is already set up.");
+  const int E = h->E, S = h->S, nn = h->nn;
+  if (nq[0] * nq[1] * nq[2] != h->Q) return fail("tlfea_ancf_setup: force rule does not match the element type");
+  const size_t N = h->N;
+  std::vector<int> conn((size_t)S * E);
+  for (int e = 0; e < E; e++)
+    for (int k = 0; k < nn; k++) {
+      const int node = conn_is_colmajor ? conn_nodes[(size_t)k * E + e] : conn_nodes[(size_t)e * nn + k];
+      if (node < 0 || node >= h->n_nodes) return fail("tlfea_ancf_setup: connectivity index out of range");
+      for (int d = 0; d < 4; d++) conn[(size_t)(4 * k + d) * E + e] = 4 * node + d;  // coef = 4*node + slot
+    }
+  h->h_conn = conn;
+  h->Lv.assign(L, L + E); h->Wv.assign(W, W + E); h->Hv.assign(H, H + E);
+  const double* fr[6] = {gx, gy, gz, wx, wy, wz};
+  const double* mr[6] = {gxm, gym, gzm, wxm, wym, wzm};
+  for (int k = 0; k < 6; k++) {
+    h->fr[k].assign(fr[k], fr[k] + nq[k % 3]);
+    h->mr[k].assign(mr[k], mr[k] + nqm[k % 3]);
+  }
+  for (int q = 0; q < h->Q; q++)  // qp = (ixi*n_eta + ieta)*n_zeta + izeta  (ANCF3243DataFunc.cuh:432-434)
+    h->h_qw[q] = wx[q / (nq[1] * nq[2])] * wy[(q / nq[2]) % nq[1]] * wz[q % nq[2]];
+  h->Binv.resize((size_t)E * S * S);
+  for (int e = 0; e < E; e++)
+    if (!ancf::B_inv(S, L[e], W[e], &h->Binv[(size_t)e * S * S])) return fail("tlfea_ancf_setup: singular B matrix");
+  HIP_TRY(hipMemcpy(h->d_x, x12, N * sizeof(double), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(h->d_y, y12, N * sizeof(double), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(h->d_z, z12, N * sizeof(double), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(h->d_xt, x12, N * sizeof(double), hipMemcpyHostToDevice));  // x12_jac: reference geometry
+  HIP_TRY(hipMemcpy(h->d_yt, y12, N * sizeof(double), hipMemcpyHostToDevice));  // AND constraint targets
+  HIP_TRY(hipMemcpy(h->d_zt, z12, N * sizeof(double), hipMemcpyHostToDevice));  // (ANCF3243Data.cuh:576-587)
+  HIP_TRY(hipMemcpy(h->d_conn, conn.data(), conn.size() * sizeof(int), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemset(h->d_fint, 0, 3 * N * sizeof(double)));
+  HIP_TRY(hipMemset(h->d_fbuf, 0, (size_t)E * 3 * S * sizeof(double)));
+  h->mat = Material{kSVK, 0, 0, 0, 0, 0, 0, 0, 0};
+  h->is_setup = true;
+  return 0;
+}
+
+// CalcDsDuPre (ANCF3243Data.cu:102-198 / ANCF3443Data.cu:96-182): reference gradients and det J from the
+// x12_jac coefficients.  One-time set-up, done on the host and uploaded in both device layouts.
+extern "C" int tlfea_ancf_calc_dsdu_pre(tlfea_t10_t h) {
+  NEED_SETUP(h, "CalcDsDuPre.");
+  if (h->kind == kT10) return fail("tlfea_ancf_calc_dsdu_pre: not an ANCF handle");
+  const int E = h->E, S = h->S, Q = h->Q, Epad = h->Epad;
+  const size_t N = h->N;
+  std::vector<double> xj(N), yj(N), zj(N);
+  HIP_TRY(hipMemcpy(xj.data(), h->d_xt, N * sizeof(double), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(yj.data(), h->d_yt, N * sizeof(double), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(zj.data(), h->d_zt, N * sizeof(double), hipMemcpyDeviceToHost));
+  const int n1 = (int)h->fr[1].size(), n2 = (int)h->fr[2].size();
+  std::vector<double> gN((size_t)E * Q * 3 * S), gNt((size_t)Epad * Q * 3 * S, 0.0), dJ((size_t)E * Q);
+#pragma omp parallel for schedule(static)
+  for (int e = 0; e < E; e++) {
+    int coefs[kMaxS];
+    for (int a = 0; a < S; a++) coefs[a] = h->h_conn[(size_t)a * E + e];
+    for (int q = 0; q < Q; q++) {
+      const int ix = q / (n1 * n2), ie = (q / n2) % n1, iz = q % n2;
+      double ds[3][16], J[3][3], JT[3][3];
+      ancf::ds_dxi(S, &h->Binv[(size_t)e * S * S], h->Lv[e], h->Wv[e], h->Hv[e], h->fr[0][ix], h->fr[1][ie], h->fr[2][iz], ds);
+      dJ[(size_t)e * Q + q] = ancf::jacobian(S, coefs, xj.data(), yj.data(), zj.data(), ds, J);
+      for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) JT[i][j] = J[j][i];
+      for (int a = 0; a < S; a++) {
+        const double rhs[3] = {ds[0][a], ds[1][a], ds[2][a]};
+        double g[3];
+        ancf::solve3(JT, rhs, g);
+        for (int d = 0; d < 3; d++) {
+          gN[((size_t)e * Q + q) * 3 * S + (size_t)d * S + a] = g[d];
+          gNt[((size_t)(q * 3 + d) * S + a) * Epad + e] = g[d];
+        }
+      }
+    }
+  }
+  HIP_TRY(hipMemcpy(h->d_gradN, gN.data(), gN.size() * sizeof(double), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(h->d_gradN_t, gNt.data(), gNt.size() * sizeof(double), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(h->d_detJ, dJ.data(), dJ.size() * sizeof(double), hipMemcpyHostToDevice));
+  h->have_dndu = true;
+  return 0;
+}
+
+// mass_matrix_qp_kernel of the ANCF types (ANCF3243Data.cu:200-288, ANCF3443Data.cu:184-254): mass rule,
+// s = B_inv b, det J of the reference map; one-time set-up on the host, summed in element order.
+static int ancf_mass_host(tlfea_t10_t h) {
+  const int E = h->E, S = h->S;
+  const size_t N = h->N;
+  std::vector<double> xj(N), yj(N), zj(N), mval((size_t)h->nnz_coef, 0.0);
+  HIP_TRY(hipMemcpy(xj.data(), h->d_xt, N * sizeof(double), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(yj.data(), h->d_yt, N * sizeof(double), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(zj.data(), h->d_zt, N * sizeof(double), hipMemcpyDeviceToHost));
+  const int m0 = (int)h->mr[0].size(), m1 = (int)h->mr[1].size(), m2 = (int)h->mr[2].size();
+  const ancf::Basis B = ancf::basis(S);
+  for (int e = 0; e < E; e++) {
+    int coefs[kMaxS], pos[kMaxS][kMaxS];
+    for (int a = 0; a < S; a++) coefs[a] = h->h_conn[(size_t)a * E + e];
+    for (int a = 0; a < S; a++) {
+      const int* row = h->h_cols.data() + h->h_off[coefs[a]];
+      const int deg = h->h_off[coefs[a] + 1] - h->h_off[coefs[a]];
+      for (int b = 0; b < S; b++) pos[a][b] = h->h_off[coefs[a]] + (int)(std::lower_bound(row, row + deg, coefs[b]) - row);
+    }
+    const double* Bi = &h->Binv[(size_t)e * S * S];
+    for (int q = 0; q < m0 * m1 * m2; q++) {
+      const int ix = q / (m1 * m2), ie = (q / m2) % m1, iz = q % m2;
+      const double wgt = h->mr[3][ix] * h->mr[4][ie] * h->mr[5][iz];
+      double b[16], sv[16], ds[3][16], J[3][3];
+      ancf::eval(B, h->Lv[e] * h->mr[0][ix] / 2, h->Wv[e] * h->mr[1][ie] / 2, h->Hv[e] * h->mr[2][iz] / 2, 0, b);
+      for (int i = 0; i < S; i++) {
+        double a = 0.0;
+        for (int j = 0; j < S; j++) a += Bi[(size_t)j * S + i] * b[j];
+        sv[i] = a;
+      }
+      ancf::ds_dxi(S, Bi, h->Lv[e], h->Wv[e], h->Hv[e], h->mr[0][ix], h->mr[1][ie], h->mr[2][iz], ds);
+      const double detJ = ancf::jacobian(S, coefs, xj.data(), yj.data(), zj.data(), ds, J);
+      for (int i = 0; i < S; i++)
+        for (int j = 0; j < S; j++) mval[pos[i][j]] += h->mat.rho0 * sv[i] * sv[j] * wgt * detJ;
+    }
+  }
+  HIP_TRY(hipMemcpy(h->d_mval, mval.data(), mval.size() * sizeof(double), hipMemcpyHostToDevice));
   return 0;
 }
 
@@ -370,7 +536,7 @@ extern "C" int tlfea_t10_convert_to_csr_constraint_jact(tlfea_t10_t h) {
 
 static int ensure_fp_buffers(tlfea_t10_t h) {
   if (h->d_F) return 0;
-  const size_t n = (size_t)h->E * kNQ * 9;
+  const size_t n = (size_t)h->E * h->Q * 9;
   TRY(dmalloc(&h->d_F, n)); TRY(dmalloc(&h->d_P, n)); TRY(dmalloc(&h->d_Fdot, n)); TRY(dmalloc(&h->d_Pvis, n));
   return 0;
 }
@@ -395,6 +561,12 @@ extern "C" int tlfea_t10_calc_internal_force(tlfea_t10_t h) {
 }
 
 extern "C" int tlfea_t10_get_n_elem(tlfea_t10_t h) { return h ? h->E : -1; }
+extern "C" int tlfea_elem_dims(tlfea_t10_t h, int* S, int* Q) {
+  if (!h) return fail("null handle");
+  *S = h->S;
+  *Q = h->Q;
+  return 0;
+}
 extern "C" int tlfea_t10_get_n_coef(tlfea_t10_t h) { return h ? h->N : -1; }
 extern "C" int tlfea_t10_get_n_constraint(tlfea_t10_t h) { return h ? h->n_constraint : -1; }
 extern "C" int tlfea_t10_is_constraint_setup(tlfea_t10_t h) { return h && h->is_constraints_setup; }
@@ -424,17 +596,17 @@ extern "C" int tlfea_t10_retrieve_position(tlfea_t10_t h, double* x, double* y, 
 }
 extern "C" int tlfea_t10_retrieve_p_from_f(tlfea_t10_t h, double* P) {
   if (!h->d_P) return fail("CalcP has not been called");
-  D2H(P, h->d_P, (size_t)h->E * kNQ * 9);
+  D2H(P, h->d_P, (size_t)h->E * h->Q * 9);
   return 0;
 }
 extern "C" int tlfea_t10_retrieve_deformation_gradient(tlfea_t10_t h, double* F) {
   if (!h->d_F) return fail("CalcP has not been called");
-  D2H(F, h->d_F, (size_t)h->E * kNQ * 9);
+  D2H(F, h->d_F, (size_t)h->E * h->Q * 9);
   return 0;
 }
-extern "C" int tlfea_t10_retrieve_dndu_pre(tlfea_t10_t h, double* g) { D2H(g, h->d_gradN, (size_t)h->E * kNQ * 30); return 0; }
-extern "C" int tlfea_t10_retrieve_detj(tlfea_t10_t h, double* d) { D2H(d, h->d_detJ, (size_t)h->E * kNQ); return 0; }
-extern "C" int tlfea_t10_retrieve_connectivity(tlfea_t10_t h, int* c) { D2H(c, h->d_conn, (size_t)h->E * kNN); return 0; }
+extern "C" int tlfea_t10_retrieve_dndu_pre(tlfea_t10_t h, double* g) { D2H(g, h->d_gradN, (size_t)h->E * h->Q * 3 * h->S); return 0; }
+extern "C" int tlfea_t10_retrieve_detj(tlfea_t10_t h, double* d) { D2H(d, h->d_detJ, (size_t)h->E * h->Q); return 0; }
+extern "C" int tlfea_t10_retrieve_connectivity(tlfea_t10_t h, int* c) { D2H(c, h->d_conn, (size_t)h->E * h->S); return 0; }
 extern "C" int tlfea_t10_retrieve_constraint_data(tlfea_t10_t h, double* c) {
   if (!h->is_constraints_setup) return fail("constraint is not set up");
   if (h->n_constraint) D2H(c, h->d_cons, h->n_constraint);
@@ -620,7 +792,7 @@ extern "C" int tlfea_newton_analyze_hessian_sparsity(tlfea_newton_t s) {
     }
   }
   TRY(dmalloc(&s->d_H, (size_t)s->h_nnz));
-  TRY(dmalloc(&s->d_Kbuf, (size_t)d->E * kNPair * 9));
+  TRY(dmalloc(&s->d_Kbuf, (size_t)d->E * (d->S * (d->S + 1) / 2) * 9));
   s->sparsity_done = true;
   if (s->verbose)
     std::printf("Sparse Hessian: %d x %d, nnz = %d\n", 3 * N, 3 * N, s->h_nnz);
@@ -806,7 +978,7 @@ static int assemble(tlfea_newton_t s) {
   }
   {
     StageTimer t(s, 3);
-    launch_assemble_rows(s->stream, s->N, d->maxdeg, d->inc(), s->d_Kbuf, d->d_mval, 1.0 / p.time_step,
+    launch_assemble_rows(s->stream, s->N, d->S, d->maxdeg, d->inc(), s->d_Kbuf, d->d_mval, 1.0 / p.time_step,
                          d->is_constraints_setup ? d->d_fixed_slot : nullptr, s->d_nw,
                          p.time_step * p.time_step * p.rho, s->d_H);
     HIP_TRY(hipGetLastError());

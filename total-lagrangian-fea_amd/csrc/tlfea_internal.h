@@ -8,10 +8,14 @@
 
 namespace tlfea {
 
-constexpr int kNQ = 5;     // Keast 5-point rule (quadrature_utils.h:134)
-constexpr int kNN = 10;    // nodes per T10 element
-constexpr int kNPair = 55; // upper-triangular node pairs (i<=j) of one element
-constexpr int kWave = 64;  // CDNA wavefront
+constexpr int kNQ = 5;      // T10: Keast 5-point rule (quadrature_utils.h:134)
+constexpr int kNN = 10;     // T10: nodes per element
+constexpr int kMaxQ = 48;   // ANCF-3443 force rule 4x4x3 (quadrature_utils.h:22)
+constexpr int kMaxS = 16;   // ANCF-3443 shape functions
+constexpr int kWave = 64;   // CDNA wavefront
+
+// element kinds: <S shape functions, Q force quadrature points>
+enum ElemKind : int { kT10 = 0, kANCF3243 = 1, kANCF3443 = 2 };
 
 enum MaterialModel : int { kSVK = 0, kMooneyRivlin = 1 }; // MaterialModel.cuh:14-17
 
@@ -25,24 +29,25 @@ struct Material {
   double rho0;
 };
 
-// Device view of one T10 mesh + state (all pointers are device pointers).
-struct T10View {
-  int E, N, Epad;
-  const int* conn;        // [10][E]   column-major E x 10 (reference layout)
+// Device view of one mesh + state (all pointers are device pointers).  "N" counts coefficient vectors: nodes
+// for T10, 4 per node (r, r_u, r_v, r_w) for the ANCF types.
+struct ElemView {
+  int E, N, Epad, S, Q;
+  const int* conn;        // [S][E]   coefficient ids, column-major E x S (T10: the reference layout)
   const double* x;        // [N] current coordinates, SoA like the reference (d_h_x12/y12/z12)
   const double* y;
   const double* z;
-  const double* gradN;    // [E][5][3][10]  reference layout: wave-per-element kernels read 1200 B runs
-  const double* gradN_t;  // [5][3][10][Epad] element-fastest copy: thread-per-element kernels coalesce
-  const double* detJ;     // [E][5]
-  double qw[kNQ];         // Keast weights
+  const double* gradN;    // [E][Q][3][S]  reference layout: wave-per-element kernels read contiguous runs
+  const double* gradN_t;  // [Q][3][S][Epad] element-fastest copy: thread-per-element kernels coalesce
+  const double* detJ;     // [E][Q]
+  double qw[kMaxQ];       // combined quadrature weights
 };
 
 // node -> element incidence and the scatter map of the row-owner ("gather") assembly
 struct Incidence {
   const int* n2e_off;   // [N+1]
-  const int* n2e;       // [10E]   e*10 + local index, ascending e per node
-  const int* n2e_pos;   // [10E][10] position of column node conn(e,j) inside row i
+  const int* n2e;       // [S*E]   e*S + local index, ascending e per node
+  const int* n2e_pos;   // [S*E][S] position of column node conn(e,j) inside row i
   const int* off;       // [N+1]   node-level adjacency CSR (== mass CSR pattern)
   const int* cols;      // [nnz_coef] sorted per row
   const int* diagpos;   // [N]     position of i in row i
@@ -52,14 +57,14 @@ struct Incidence {
 void launch_dndu_pre(hipStream_t s, int E, int Epad, const int* conn, const double* x, const double* y,
                      const double* z, const double* qx, const double* qy, const double* qz,
                      double* gradN, double* gradN_t, double* detJ);
-void launch_residual(hipStream_t s, const T10View& m, const Material& mat, const double* v /*or null*/,
+void launch_residual(hipStream_t s, const ElemView& m, const Material& mat, const double* v /*or null*/,
                      double* fbuf /*[E][30]*/, double* F, double* P, double* Fdot, double* Pvis);
-void launch_tangent_blocks(hipStream_t s, const T10View& m, const Material& mat, double h,
+void launch_tangent_blocks(hipStream_t s, const ElemView& m, const Material& mat, double h,
                            double* Kbuf /*[E][55][9]*/);
-void launch_assemble_rows(hipStream_t s, int N, int maxdeg, const Incidence& inc, const double* Kbuf,
+void launch_assemble_rows(hipStream_t s, int N, int S, int maxdeg, const Incidence& inc, const double* Kbuf,
                           const double* mval, double inv_h, const int* fixed_slot, const double* nw,
                           double penalty, double* Hval);
-void launch_mass_values(hipStream_t s, const T10View& m, const Incidence& inc, const double* qx,
+void launch_mass_values(hipStream_t s, const ElemView& m, const Incidence& inc, const double* qx,
                         const double* qy, const double* qz, double rho0, double* mval);
 void launch_grad(hipStream_t s, int N, const Incidence& inc, const double* fbuf, const double* mval,
                  const double* v, const double* vprev, const double* f_ext, const double* x,

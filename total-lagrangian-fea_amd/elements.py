@@ -14,6 +14,7 @@ def _f64(a):
 
 class GPU_FEAT10_Data:
     TYPE = "TYPE_T10"  # ElementBase.h:20
+    S, Q = 10, 5       # shape functions / force quadrature points per element
 
     def __init__(self, num_elements, num_nodes):
         self._lib = load_library()
@@ -162,28 +163,28 @@ class GPU_FEAT10_Data:
 
     def RetrievePFromFToCPU(self):
         """[E][5] 3x3 matrices; flat storage is column-major per matrix like the reference."""
-        P = np.zeros((self.n_elem, 5, 9))
+        P = np.zeros((self.n_elem, self.Q, 9))
         check(self._lib.tlfea_t10_retrieve_p_from_f(self._h, dp(P)))
-        return P.reshape(self.n_elem, 5, 3, 3).transpose(0, 1, 3, 2)
+        return P.reshape(self.n_elem, self.Q, 3, 3).transpose(0, 1, 3, 2)
 
     def RetrieveDeformationGradientToCPU(self):
-        F = np.zeros((self.n_elem, 5, 9))
+        F = np.zeros((self.n_elem, self.Q, 9))
         check(self._lib.tlfea_t10_retrieve_deformation_gradient(self._h, dp(F)))
-        return F.reshape(self.n_elem, 5, 3, 3).transpose(0, 1, 3, 2)
+        return F.reshape(self.n_elem, self.Q, 3, 3).transpose(0, 1, 3, 2)
 
     def RetrieveDnDuPreToCPU(self):
-        """[E][5] 10x3 matrices (node, direction)."""
-        g = np.zeros((self.n_elem, 5, 3, 10))
+        """[E][Q] S x 3 matrices (shape function, direction)."""
+        g = np.zeros((self.n_elem, self.Q, 3, self.S))
         check(self._lib.tlfea_t10_retrieve_dndu_pre(self._h, dp(g)))
         return g.transpose(0, 1, 3, 2)
 
     def RetrieveDetJToCPU(self):
-        d = np.zeros((self.n_elem, 5))
+        d = np.zeros((self.n_elem, self.Q))
         check(self._lib.tlfea_t10_retrieve_detj(self._h, dp(d)))
         return d
 
     def RetrieveConnectivityToCPU(self):
-        c = np.zeros((10, self.n_elem), dtype=np.int32)
+        c = np.zeros((self.S, self.n_elem), dtype=np.int32)  # coefficient ids (T10: node ids)
         check(self._lib.tlfea_t10_retrieve_connectivity(self._h, ip(c)))
         return np.ascontiguousarray(c.T)
 
@@ -206,3 +207,72 @@ class GPU_FEAT10_Data:
 
     def WriteOutputVTK(self, filename):
         check(self._lib.tlfea_t10_write_output_vtk(self._h, str(filename).encode()))
+
+
+class _GPU_ANCF_Data(GPU_FEAT10_Data):
+    """Common host mirror of GPU_ANCF3243_Data / GPU_ANCF3443_Data (lib_src/elements/ANCF3243Data.cuh:33-1152,
+    ANCF3443Data.cuh).  4 coefficient vectors per node (r, r_u, r_v, r_w): n_coef = 4 * n_nodes;
+    SetNodalFixed takes COEFFICIENT indices (ANCF3243Data.cuh:778-808)."""
+    KIND = 0
+    NN = 0
+
+    def __init__(self, num_nodes, num_elements):
+        self._lib = load_library()
+        self.n_nodes, self.n_elem = int(num_nodes), int(num_elements)
+        self.n_beam = self.n_elem
+        self.n_coef = 4 * self.n_nodes
+        self._h = C.c_void_p()
+        self._initialized = False
+
+    def Initialize(self):
+        check(self._lib.tlfea_ancf_create(self.KIND, self.n_nodes, self.n_elem, C.byref(self._h)))
+        self._initialized = True
+
+    def _setup(self, length, width, height, mass_rule, force_rule, h_x12, h_y12, h_z12, connectivity):
+        E = self.n_elem
+        L, W, H = (np.ascontiguousarray(np.broadcast_to(np.asarray(a, dtype=np.float64), (E,))) for a in
+                   (length, width, height))
+        mr = [_f64(a) for a in mass_rule]
+        fr = [_f64(a) for a in force_rule]
+        nqm = np.array([len(mr[0]), len(mr[1]), len(mr[2])], dtype=np.int32)
+        nq = np.array([len(fr[0]), len(fr[1]), len(fr[2])], dtype=np.int32)
+        conn = np.ascontiguousarray(np.asarray(connectivity).reshape(E, self.NN), dtype=np.int32)
+        x, y, z = _f64(h_x12), _f64(h_y12), _f64(h_z12)
+        assert x.size == y.size == z.size == self.n_coef
+        check(self._lib.tlfea_ancf_setup(self._h, dp(L), dp(W), dp(H), dp(mr[0]), dp(mr[1]), dp(mr[2]), dp(mr[3]),
+                                         dp(mr[4]), dp(mr[5]), ip(nqm), dp(fr[0]), dp(fr[1]), dp(fr[2]), dp(fr[3]),
+                                         dp(fr[4]), dp(fr[5]), ip(nq), dp(x), dp(y), dp(z), ip(conn), 0))
+
+    def CalcDsDuPre(self):
+        check(self._lib.tlfea_ancf_calc_dsdu_pre(self._h))
+
+    CalcDnDuPre = CalcDsDuPre
+    RetrieveDsDuPreToCPU = GPU_FEAT10_Data.RetrieveDnDuPreToCPU
+
+    def get_n_beam(self):
+        return self.n_elem
+
+
+class GPU_ANCF3243_Data(_GPU_ANCF_Data):
+    TYPE, KIND, NN, S, Q = "TYPE_3243", 3243, 2, 8, 12
+
+    def Setup(self, length, width, height, gauss_xi_m, gauss_xi, gauss_eta, gauss_zeta, weight_xi_m, weight_xi,
+              weight_eta, weight_zeta, h_x12, h_y12, h_z12, h_element_connectivity):
+        """Argument order of ANCF3243Data.cuh:511-521 (the mass rule shares eta/zeta with the force rule)."""
+        self._setup(length, width, height,
+                    (gauss_xi_m, gauss_eta, gauss_zeta, weight_xi_m, weight_eta, weight_zeta),
+                    (gauss_xi, gauss_eta, gauss_zeta, weight_xi, weight_eta, weight_zeta),
+                    h_x12, h_y12, h_z12, h_element_connectivity)
+
+
+class GPU_ANCF3443_Data(_GPU_ANCF_Data):
+    TYPE, KIND, NN, S, Q = "TYPE_3443", 3443, 4, 16, 48
+
+    def Setup(self, length, width, height, gauss_xi_m, gauss_eta_m, gauss_zeta_m, gauss_xi, gauss_eta, gauss_zeta,
+              weight_xi_m, weight_eta_m, weight_zeta_m, weight_xi, weight_eta, weight_zeta, h_x12, h_y12, h_z12,
+              element_connectivity):
+        """Argument order of ANCF3443Data.cuh:532-542."""
+        self._setup(length, width, height,
+                    (gauss_xi_m, gauss_eta_m, gauss_zeta_m, weight_xi_m, weight_eta_m, weight_zeta_m),
+                    (gauss_xi, gauss_eta, gauss_zeta, weight_xi, weight_eta, weight_zeta),
+                    h_x12, h_y12, h_z12, element_connectivity)
