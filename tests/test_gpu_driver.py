@@ -43,3 +43,27 @@ def test_cpp_facade_compiles_without_gpu():
     assert os.path.exists(DRIVER)
     out = subprocess.run([DRIVER, "--bogus"], capture_output=True, text=True)
     assert out.returncode == 1 and "Unknown argument" in out.stderr
+
+
+@pytest.mark.gpu
+def test_cpp_ancf3243_cantilever_config_a(tmp_path):
+    """BASELINE config A: lib_bin/beam_sag/test_ancf3243.cc flow (30 elements, L=0.5, W=H=0.1, tip Fz=3100 N,
+    damping 1e5/1e5, params {1e-4,0,1e-6,1e14,5,10,1e-3}) through the C++ facade vs the oracle; CSV `step,tip_z`."""
+    from tests.test_gpu_ancf import SVK_D, beam_problem
+    drv = os.path.join(os.path.dirname(DRIVER), "test_ancf3243")
+    if not os.path.exists(drv):
+        subprocess.check_call(["make", "-C", os.path.dirname(DRIVER)])
+    csv = tmp_path / "tip.csv"
+    out = subprocess.run([drv, "--steps=4", "--dt=1e-3", f"--csv_path={csv}"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    assert open(csv).readline().strip() == "step,tip_z"
+    rows = np.loadtxt(csv, delimiter=",", skiprows=1)
+    kind, x, y, z, conn, (L, W, H), fixed, f_ext = beam_problem(30)
+    o = orc.AncfOracle(kind, x, y, z, conn, L, W, H, orc.svk(7e8, 0.33, rho0=2700.0, eta=1e5, lamd=1e5), fixed, f_ext)
+    o.calc_dsdu_pre()
+    o.calc_mass()
+    prm = orc.NewtonParams(1e-4, 0.0, 1e-6, 1e14, 5, 10, 1e-3)
+    tip = conn[-1, 1] * 4
+    for step in range(4):
+        o.newton_step(prm)
+        assert abs(rows[step, 1] - o.z[tip]) <= 1e-10 * abs(o.z[tip] - z[tip]) + 8e-16 * max(1.0, abs(o.z[tip]))

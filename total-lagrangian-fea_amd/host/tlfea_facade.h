@@ -8,6 +8,10 @@
 #pragma once
 #include <algorithm>
 #include <climits>
+#include <cmath>
+#include <initializer_list>
+#include <stdexcept>
+#include <utility>
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
@@ -44,9 +48,40 @@ static const tlfea::VectorXd tet5pt_y = make5({0.25, kB, kB, 0.5, kB});
 static const tlfea::VectorXd tet5pt_z = make5({0.25, kB, kB, kB, 0.5});
 static const tlfea::VectorXd tet5pt_weights =
     make5({-4.0 / 5.0 * kB, 9.0 / 20.0 * kB, 9.0 / 20.0 * kB, 9.0 / 20.0 * kB, 9.0 / 20.0 * kB});
+// Gauss-Legendre tables of the ANCF elements (quadrature_utils.h:8-128)
+constexpr int N_SHAPE_3243 = 8, N_SHAPE_3443 = 16, N_TOTAL_QP_3_2_2 = 12, N_TOTAL_QP_4_4_3 = 48;
+inline tlfea::VectorXd makev(std::initializer_list<double> a) {
+  tlfea::VectorXd v(static_cast<int>(a.size()));
+  int i = 0;
+  for (double x : a) v(i++) = x;
+  return v;
+}
+static const tlfea::VectorXd gauss_xi_m_6 = makev({-0.93246951420315202, -0.66120938646626451, -0.23861918608319691,
+                                                   0.23861918608319691, 0.66120938646626451, 0.93246951420315202});
+static const tlfea::VectorXd weight_xi_m_6 = makev({0.17132449237917034, 0.36076157304813861, 0.46791393457269104,
+                                                    0.46791393457269104, 0.36076157304813861, 0.17132449237917034});
+static const tlfea::VectorXd gauss_xi_m_7 = makev({-0.949107912342759, -0.741531185599394, -0.405845151377397, 0.0,
+                                                   0.405845151377397, 0.741531185599394, 0.949107912342759});
+static const tlfea::VectorXd weight_xi_m_7 = makev({0.129484966168870, 0.279705391489277, 0.381830050505119,
+                                                    0.417959183673469, 0.381830050505119, 0.279705391489277,
+                                                    0.129484966168870});
+static const tlfea::VectorXd gauss_eta_m_7 = gauss_xi_m_7, weight_eta_m_7 = weight_xi_m_7;
+static const tlfea::VectorXd gauss_zeta_m_3 = makev({-0.7745966692414834, 0.0, 0.7745966692414834});
+static const tlfea::VectorXd weight_zeta_m_3 = makev({0.5555555555555556, 0.8888888888888888, 0.5555555555555556});
+static const tlfea::VectorXd gauss_xi_3 = makev({-0.77459666924148340, 0.0, 0.77459666924148340});
+static const tlfea::VectorXd weight_xi_3 = makev({0.55555555555555556, 0.88888888888888889, 0.55555555555555556});
+static const tlfea::VectorXd gauss_xi_4 = makev({-0.8611363115940526, -0.3399810435848563, 0.3399810435848563,
+                                                 0.8611363115940526});
+static const tlfea::VectorXd weight_xi_4 = makev({0.3478548451374538, 0.6521451548625461, 0.6521451548625461,
+                                                  0.3478548451374538});
+static const tlfea::VectorXd gauss_eta_2 = makev({-0.57735026918962576, 0.57735026918962576});
+static const tlfea::VectorXd weight_eta_2 = makev({1.0, 1.0});
+static const tlfea::VectorXd gauss_eta_4 = gauss_xi_4, weight_eta_4 = weight_xi_4;
+static const tlfea::VectorXd gauss_zeta_2 = gauss_eta_2, weight_zeta_2 = weight_eta_2;
+static const tlfea::VectorXd gauss_zeta_3 = gauss_xi_3, weight_zeta_3 = weight_xi_3;
 }  // namespace Quadrature
 
-namespace ANCFCPUUtils {  // cpu_utils.cc:607-754
+namespace ANCFCPUUtils {  // cpu_utils.cc:607-754, mesh_utils.cc:13-167
 inline void FEAT10_remap_tetgen_indices(const tlfea::VectorXi& tetgen_elem, tlfea::VectorXi& standard_elem) {
   if (tetgen_elem.size() != 10 || standard_elem.size() != 10) {
     std::cerr << "Error: Element arrays must have size 10 for T10 elements" << std::endl;
@@ -134,6 +169,89 @@ inline int FEAT10_read_elements(const std::string& filename, tlfea::MatrixXi& el
       for (int j = 0; j < 10; j++) elements(e, j) = s(j);
   }
   return n_elements;
+}
+// GridMeshGenerator (mesh_utils.cc:13-167): ANCF-3243 beam / net meshes
+class GridMeshGenerator {
+ public:
+  GridMeshGenerator(double X, double Y, double L, bool include_horizontal = true, bool include_vertical = true)
+      : L_(L), h_(include_horizontal), v_(include_vertical) {
+    if (L <= 0) throw std::invalid_argument("L must be > 0");
+    if (std::abs(std::round(X / L) * L - X) > 1e-12 || std::abs(std::round(Y / L) * L - Y) > 1e-12)
+      throw std::invalid_argument("X and Y must be exact multiples of L");
+    nx_ = static_cast<int>(std::round(X / L));
+    ny_ = static_cast<int>(std::round(Y / L));
+    if (h_ && nx_ == 0) h_ = false;
+    if (v_ && ny_ == 0) v_ = false;
+  }
+  void generate_mesh() {
+    elems_.clear();
+    if (h_)
+      for (int j = 0; j <= ny_; j++)
+        for (int i = 0; i < nx_; i++) elems_.push_back({node_id(i, j), node_id(i + 1, j)});
+    if (v_)
+      for (int i = 0; i <= nx_; i++)
+        for (int j = 0; j < ny_; j++) elems_.push_back({node_id(i, j), node_id(i, j + 1)});
+  }
+  int node_id(int i, int j) const {
+    if (i < 0 || i > nx_ || j < 0 || j > ny_) throw std::out_of_range("(i,j) out of range");
+    return j * (nx_ + 1) + i;
+  }
+  int get_num_nodes() const { return (nx_ + 1) * (ny_ + 1); }
+  int get_num_elements() const { return static_cast<int>(elems_.size()); }
+  void get_coordinates(tlfea::VectorXd& x, tlfea::VectorXd& y, tlfea::VectorXd& z) {
+    const int n = get_num_nodes();
+    x.resize(4 * n);
+    y.resize(4 * n);
+    z.resize(4 * n);
+    for (int j = 0; j <= ny_; j++)
+      for (int i = 0; i <= nx_; i++) {
+        const int b = 4 * node_id(i, j);
+        x(b) = i * L_; x(b + 1) = 1.0;
+        y(b) = 1.0; y(b + 2) = 1.0;
+        z(b + 3) = 1.0;
+      }
+  }
+  void get_element_connectivity(tlfea::MatrixXi& c) {
+    c.resize(get_num_elements(), 2);
+    for (int e = 0; e < get_num_elements(); e++) {
+      c(e, 0) = elems_[e].first;
+      c(e, 1) = elems_[e].second;
+    }
+  }
+
+ private:
+  double L_;
+  bool h_, v_;
+  int nx_ = 0, ny_ = 0;
+  std::vector<std::pair<int, int>> elems_;
+};
+
+// ANCF3443_generate_beam_coordinates (cpu_utils.cc:476-595)
+inline void ANCF3443_generate_beam_coordinates(int n_beam, tlfea::VectorXd& x12, tlfea::VectorXd& y12,
+                                               tlfea::VectorXd& z12, tlfea::MatrixXi& conn) {
+  const int n_nodes = 4 + 2 * (n_beam - 1);
+  x12.resize(4 * n_nodes);
+  y12.resize(4 * n_nodes);
+  z12.resize(4 * n_nodes);
+  std::vector<std::pair<double, double>> pos = {{0, 0}, {2, 0}, {2, 1}, {0, 1}};
+  for (int i = 1; i < n_beam; i++) {
+    pos.push_back({2.0 * (i + 1), 0.0});
+    pos.push_back({2.0 * (i + 1), 1.0});
+  }
+  for (int n = 0; n < n_nodes; n++) {
+    x12(4 * n) = pos[n].first; x12(4 * n + 1) = 1.0;
+    y12(4 * n) = pos[n].second; y12(4 * n + 2) = 1.0;
+    z12(4 * n + 3) = 1.0;
+  }
+  conn.resize(n_beam, 4);
+  conn(0, 0) = 0; conn(0, 1) = 1; conn(0, 2) = 2; conn(0, 3) = 3;
+  for (int i = 1; i < n_beam; i++) {
+    if (i == 1) {
+      conn(i, 0) = 1; conn(i, 1) = 4; conn(i, 2) = 5; conn(i, 3) = 2;
+    } else {
+      conn(i, 0) = 4 + (i - 2) * 2; conn(i, 1) = 4 + (i - 1) * 2; conn(i, 2) = 4 + (i - 1) * 2 + 1; conn(i, 3) = 5 + (i - 2) * 2;
+    }
+  }
 }
 }  // namespace ANCFCPUUtils
 
@@ -281,6 +399,84 @@ struct GPU_FEAT10_Data : public ElementBase {
   }
 };
 
+// GPU_ANCF3243_Data / GPU_ANCF3443_Data (ANCF3243Data.cuh:33-1152, ANCF3443Data.cuh): share the handle type and
+// every non-T10-specific entry point with GPU_FEAT10_Data; n_coef = 4 * n_nodes, SetNodalFixed takes
+// coefficient indices.
+struct GPU_ANCF_DataBase : public GPU_FEAT10_Data {
+  GPU_ANCF_DataBase(int kind, ElementType t, int n_nodes, int n_elements)
+      : GPU_FEAT10_Data(n_elements, 4 * n_nodes), kind_(kind), n_nodes_(n_nodes) {
+    type = t;
+    n_beam = n_elements;
+  }
+  void Initialize() { TLFEA_HANDLE_ERROR(tlfea_ancf_create(kind_, n_nodes_, n_elem, &h)); }
+  void CalcDsDuPre() { TLFEA_HANDLE_ERROR(tlfea_ancf_calc_dsdu_pre(h)); }
+  int n_beam;
+
+ protected:
+  void setup_impl(const tlfea::VectorXd& L, const tlfea::VectorXd& W, const tlfea::VectorXd& H,
+                  const tlfea::VectorXd* mr[6], const tlfea::VectorXd* fr[6], const tlfea::VectorXd& x,
+                  const tlfea::VectorXd& y, const tlfea::VectorXd& z, const int* conn, int colmajor) {
+    const int nqm[3] = {mr[0]->size(), mr[1]->size(), mr[2]->size()};
+    const int nq[3] = {fr[0]->size(), fr[1]->size(), fr[2]->size()};
+    TLFEA_SOFT(tlfea_ancf_setup(h, L.data(), W.data(), H.data(), mr[0]->data(), mr[1]->data(), mr[2]->data(),
+                                mr[3]->data(), mr[4]->data(), mr[5]->data(), nqm, fr[0]->data(), fr[1]->data(),
+                                fr[2]->data(), fr[3]->data(), fr[4]->data(), fr[5]->data(), nq, x.data(), y.data(),
+                                z.data(), conn, colmajor));
+  }
+  static tlfea::VectorXd fill(int n, double v) {
+    tlfea::VectorXd r(n);
+    for (int i = 0; i < n; i++) r(i) = v;
+    return r;
+  }
+  int kind_, n_nodes_;
+};
+
+struct GPU_ANCF3243_Data : public GPU_ANCF_DataBase {
+  GPU_ANCF3243_Data(int n_nodes, int n_elements) : GPU_ANCF_DataBase(3243, TYPE_3243, n_nodes, n_elements) {}
+  // ANCF3243Data.cuh:511-521 (per-element dimensions) and :653-670 (scalar overload)
+  void Setup(const tlfea::VectorXd& length, const tlfea::VectorXd& width, const tlfea::VectorXd& height,
+             const tlfea::VectorXd& gauss_xi_m, const tlfea::VectorXd& gauss_xi, const tlfea::VectorXd& gauss_eta,
+             const tlfea::VectorXd& gauss_zeta, const tlfea::VectorXd& weight_xi_m, const tlfea::VectorXd& weight_xi,
+             const tlfea::VectorXd& weight_eta, const tlfea::VectorXd& weight_zeta, const tlfea::VectorXd& h_x12,
+             const tlfea::VectorXd& h_y12, const tlfea::VectorXd& h_z12, const tlfea::MatrixXi& conn) {
+    const tlfea::VectorXd* mr[6] = {&gauss_xi_m, &gauss_eta, &gauss_zeta, &weight_xi_m, &weight_eta, &weight_zeta};
+    const tlfea::VectorXd* fr[6] = {&gauss_xi, &gauss_eta, &gauss_zeta, &weight_xi, &weight_eta, &weight_zeta};
+    setup_impl(length, width, height, mr, fr, h_x12, h_y12, h_z12, conn.data(), /*column-major E x 2*/ 1);
+  }
+  void Setup(double L, double W, double H, const tlfea::VectorXd& gauss_xi_m, const tlfea::VectorXd& gauss_xi,
+             const tlfea::VectorXd& gauss_eta, const tlfea::VectorXd& gauss_zeta, const tlfea::VectorXd& weight_xi_m,
+             const tlfea::VectorXd& weight_xi, const tlfea::VectorXd& weight_eta, const tlfea::VectorXd& weight_zeta,
+             const tlfea::VectorXd& h_x12, const tlfea::VectorXd& h_y12, const tlfea::VectorXd& h_z12,
+             const tlfea::MatrixXi& conn) {
+    Setup(fill(n_elem, L), fill(n_elem, W), fill(n_elem, H), gauss_xi_m, gauss_xi, gauss_eta, gauss_zeta, weight_xi_m,
+          weight_xi, weight_eta, weight_zeta, h_x12, h_y12, h_z12, conn);
+  }
+};
+
+struct GPU_ANCF3443_Data : public GPU_ANCF_DataBase {
+  GPU_ANCF3443_Data(int n_nodes, int n_elements) : GPU_ANCF_DataBase(3443, TYPE_3443, n_nodes, n_elements) {}
+  // ANCF3443Data.cuh:532-542
+  void Setup(const tlfea::VectorXd& length, const tlfea::VectorXd& width, const tlfea::VectorXd& height,
+             const tlfea::VectorXd& gauss_xi_m, const tlfea::VectorXd& gauss_eta_m, const tlfea::VectorXd& gauss_zeta_m,
+             const tlfea::VectorXd& gauss_xi, const tlfea::VectorXd& gauss_eta, const tlfea::VectorXd& gauss_zeta,
+             const tlfea::VectorXd& weight_xi_m, const tlfea::VectorXd& weight_eta_m,
+             const tlfea::VectorXd& weight_zeta_m, const tlfea::VectorXd& weight_xi, const tlfea::VectorXd& weight_eta,
+             const tlfea::VectorXd& weight_zeta, const tlfea::VectorXd& h_x12, const tlfea::VectorXd& h_y12,
+             const tlfea::VectorXd& h_z12, const tlfea::MatrixXi& conn) {
+    const tlfea::VectorXd* mr[6] = {&gauss_xi_m, &gauss_eta_m, &gauss_zeta_m, &weight_xi_m, &weight_eta_m, &weight_zeta_m};
+    const tlfea::VectorXd* fr[6] = {&gauss_xi, &gauss_eta, &gauss_zeta, &weight_xi, &weight_eta, &weight_zeta};
+    setup_impl(length, width, height, mr, fr, h_x12, h_y12, h_z12, conn.data(), 1);
+  }
+  void Setup(double L, double W, double H, const tlfea::VectorXd& gxm, const tlfea::VectorXd& gym,
+             const tlfea::VectorXd& gzm, const tlfea::VectorXd& gx, const tlfea::VectorXd& gy, const tlfea::VectorXd& gz,
+             const tlfea::VectorXd& wxm, const tlfea::VectorXd& wym, const tlfea::VectorXd& wzm,
+             const tlfea::VectorXd& wx, const tlfea::VectorXd& wy, const tlfea::VectorXd& wz, const tlfea::VectorXd& x,
+             const tlfea::VectorXd& y, const tlfea::VectorXd& z, const tlfea::MatrixXi& conn) {
+    Setup(fill(n_elem, L), fill(n_elem, W), fill(n_elem, H), gxm, gym, gzm, gx, gy, gz, wxm, wym, wzm, wx, wy, wz, x, y,
+          z, conn);
+  }
+};
+
 class SolverBase {  // SolverBase.h:16-23
  public:
   virtual ~SolverBase() = default;
@@ -297,10 +493,7 @@ struct SyncedNewtonParams {  // SyncedNewton.cuh:29-33
 class SyncedNewtonSolver : public SolverBase {
  public:
   SyncedNewtonSolver(ElementBase* data, int n_constraints) {
-    if (data->type != TYPE_T10) {
-      std::cerr << "Unknown element type!" << std::endl;  // SyncedNewton.cuh:78-81 (3243/3443: next rounds)
-      return;
-    }
+    // SyncedNewton.cuh:52-85: the three element types share one device path here
     TLFEA_HANDLE_ERROR(tlfea_newton_create(static_cast<GPU_FEAT10_Data*>(data)->h, n_constraints, &s_));
   }
   ~SyncedNewtonSolver() override { tlfea_newton_destroy(s_); }
