@@ -26,16 +26,18 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s, ~6.3 achievable)
 
 
-def alg_bytes(E, N, nnz_coef):
-    """Algorithmic (compulsory) bytes per launch of each hot kernel, see DESIGN.md section 4."""
-    npair = 55
+def alg_bytes(E, N, nnz_coef, S=10, Q=5):
+    """Algorithmic (compulsory) bytes per launch of each hot kernel, see DESIGN.md section 4.
+    S shape functions / Q quadrature points per element (T10: 10/5, ANCF-3243: 8/12, ANCF-3443: 16/48)."""
+    npair = S * (S + 1) // 2
+    elem_in = 4 * S + 24 * S * Q + 8 * Q  # connectivity + gradients + det J
     return {
-        # conn + x gather (unique nodes) + gradN + detJ -> 30 force components per element
-        "residual": E * (40 + 1200 + 40 + 240) + N * 24,
-        # + element-major symmetric block buffer (55 blocks x 72 B)
-        "tangent_blocks": E * (40 + 1200 + 40) + N * 24 + E * npair * 72,
-        # block buffer in, scatter map in, mass in, H (9 doubles per node pair) out once
-        "assemble_rows": E * npair * 72 + E * 400 + nnz_coef * 8 + nnz_coef * 72,
+        # inputs + x gather (unique coefficient vectors) -> 3S force components per element
+        "residual": E * (elem_in + 24 * S) + N * 24,
+        # + element-major symmetric block buffer (S(S+1)/2 blocks x 72 B)
+        "tangent_blocks": E * elem_in + N * 24 + E * npair * 72,
+        # block buffer in, scatter map in, mass in, H (9 doubles per coefficient pair) out once
+        "assemble_rows": E * npair * 72 + E * 4 * S * S + nnz_coef * 8 + nnz_coef * 72,
         # H values + node-level columns + z,p_old in, p_new,q out
         "spmv": nnz_coef * 72 + nnz_coef * 4 + N * 96,
     }
@@ -71,9 +73,12 @@ def main():
     par = import_module("total-lagrangian-fea_amd.partition")
 
     cfg = wl.CONFIGS[args.config]
-    nx = cfg["cells"][0]
+    is_ancf = "kind" in cfg
+    if is_ancf and world > 1:
+        raise SystemExit("ANCF configs are single-GPU workloads")
+    nx = 0 if is_ancf else cfg["cells"][0]
     # weak scaling: every rank owns one full-size x-slab of a bar `world` times as long
-    w = wl.build(args.config, cells=cfg["cells"], x_offset_cells=rank * nx)
+    w = wl.build(args.config) if is_ancf else wl.build(args.config, cells=cfg["cells"], x_offset_cells=rank * nx)
     part = None
     if world > 1:
         par.restrict_bcs_to_global_ends(w, rank, world, cfg)
@@ -122,7 +127,7 @@ def main():
     torch.cuda.synchronize()
     st = s.GetStageMs(reset=True)
     s.SetProfiling(False)
-    ab = alg_bytes(E, N, nnz_coef)
+    ab = alg_bytes(E, N, nnz_coef, d.S, d.Q)
     roof_all = {}
     for k in ("residual", "tangent_blocks", "assemble_rows", "spmv"):
         ms, n = st[k]
@@ -160,7 +165,9 @@ def main():
         "roofline": roofline, "roofline_all": roof_all,
     }
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if is_ancf:
+        out["metric"] = "ANCF element-updates/sec per Newton step (not the BASELINE metric: T10 is)"
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not is_ancf:
         out["cpu_baseline"] = cpu_baseline(w, args)
     del s
     d.Destroy()

@@ -482,15 +482,14 @@ static int ancf_mass_host(tlfea_t10_t h) {
   HIP_TRY(hipMemcpy(zj.data(), h->d_zt, N * sizeof(double), hipMemcpyDeviceToHost));
   const int m0 = (int)h->mr[0].size(), m1 = (int)h->mr[1].size(), m2 = (int)h->mr[2].size();
   const ancf::Basis B = ancf::basis(S);
+  // element-local S x S masses in parallel, then a row-owner gather in ascending element order (deterministic)
+  std::vector<double> Me((size_t)E * S * S, 0.0);
+#pragma omp parallel for schedule(static)
   for (int e = 0; e < E; e++) {
-    int coefs[kMaxS], pos[kMaxS][kMaxS];
+    int coefs[kMaxS];
     for (int a = 0; a < S; a++) coefs[a] = h->h_conn[(size_t)a * E + e];
-    for (int a = 0; a < S; a++) {
-      const int* row = h->h_cols.data() + h->h_off[coefs[a]];
-      const int deg = h->h_off[coefs[a] + 1] - h->h_off[coefs[a]];
-      for (int b = 0; b < S; b++) pos[a][b] = h->h_off[coefs[a]] + (int)(std::lower_bound(row, row + deg, coefs[b]) - row);
-    }
     const double* Bi = &h->Binv[(size_t)e * S * S];
+    double* M = &Me[(size_t)e * S * S];
     for (int q = 0; q < m0 * m1 * m2; q++) {
       const int ix = q / (m1 * m2), ie = (q / m2) % m1, iz = q % m2;
       const double wgt = h->mr[3][ix] * h->mr[4][ie] * h->mr[5][iz];
@@ -504,7 +503,19 @@ static int ancf_mass_host(tlfea_t10_t h) {
       ancf::ds_dxi(S, Bi, h->Lv[e], h->Wv[e], h->Hv[e], h->mr[0][ix], h->mr[1][ie], h->mr[2][iz], ds);
       const double detJ = ancf::jacobian(S, coefs, xj.data(), yj.data(), zj.data(), ds, J);
       for (int i = 0; i < S; i++)
-        for (int j = 0; j < S; j++) mval[pos[i][j]] += h->mat.rho0 * sv[i] * sv[j] * wgt * detJ;
+        for (int j = 0; j < S; j++) M[i * S + j] += h->mat.rho0 * sv[i] * sv[j] * wgt * detJ;
+    }
+  }
+#pragma omp parallel for schedule(static)
+  for (int i = 0; i < (int)N; i++) {
+    const int* row = h->h_cols.data() + h->h_off[i];
+    const int deg = h->h_off[i + 1] - h->h_off[i];
+    for (int k = h->h_n2e_off[i]; k < h->h_n2e_off[i + 1]; k++) {
+      const int e = h->h_n2e[k] / S, il = h->h_n2e[k] % S;
+      for (int j = 0; j < S; j++) {
+        const int c = h->h_conn[(size_t)j * E + e];
+        mval[h->h_off[i] + (int)(std::lower_bound(row, row + deg, c) - row)] += Me[((size_t)e * S + il) * S + j];
+      }
     }
   }
   HIP_TRY(hipMemcpy(h->d_mval, mval.data(), mval.size() * sizeof(double), hipMemcpyHostToDevice));

@@ -159,3 +159,21 @@ def ANCF3243_calculate_offsets(n_beam):
     """cpu_utils.cc:597-605"""
     start = np.arange(n_beam, dtype=np.int32) * 4
     return start, start + 7
+
+
+def structured_3443_plate(nx, ny, L, W):
+    """nx x ny ANCF-3443 shell elements of size L x W in the z=0 plane (BASELINE config D generator).
+    Node id = j*(nx+1)+i; element nodes P1(i,j) P2(i+1,j) P3(i+1,j+1) P4(i,j+1) (cpu_utils.cc:213-217 order);
+    coefficients per node r=(x,y,0), r_u=(1,0,0), r_v=(0,1,0), r_w=(0,0,1).  -> (x12, y12, z12, conn[E,4])"""
+    ii, jj = np.meshgrid(np.arange(nx + 1), np.arange(ny + 1), indexing="xy")
+    n = (nx + 1) * (ny + 1)
+    x, y, z = np.zeros(4 * n), np.zeros(4 * n), np.zeros(4 * n)
+    x[0::4] = (ii * L).reshape(-1)
+    y[0::4] = (jj * W).reshape(-1)
+    x[1::4] = 1.0
+    y[2::4] = 1.0
+    z[3::4] = 1.0
+    ei, ej = np.meshgrid(np.arange(nx), np.arange(ny), indexing="xy")
+    n0 = (ej * (nx + 1) + ei).reshape(-1)
+    conn = np.stack([n0, n0 + 1, n0 + nx + 2, n0 + nx + 1], axis=1).astype(np.int32)
+    return x, y, z, conn

@@ -9,6 +9,10 @@ CONFIGS = {
     "B": dict(cells=(12, 12, 12), size=(1.0, 1.0, 1.0), material="neo", desc="T10 cube 12^3x6, neo-Hookean"),
     "C": dict(cells=(90, 60, 30), size=(3.0, 2.0, 1.0), material="svk", desc="T10 bar 90x60x30x6, SVK"),
     "S": dict(cells=(4, 3, 2), size=(3.0, 2.0, 1.0), material="svk", desc="small bar (tests)"),
+    # ANCF configs (element counts instead of cells)
+    "A": dict(kind=3243, n=(30,), dims=(0.5, 0.1, 0.1), material="svk_damped", desc="ANCF-3243 cantilever, 30 beams"),
+    "D": dict(kind=3443, n=(512, 500), dims=(0.1, 0.1, 0.01), material="svk", desc="ANCF-3443 plate 512x500"),
+    "Ds": dict(kind=3443, n=(16, 12), dims=(0.1, 0.1, 0.01), material="svk", desc="small ANCF-3443 plate (tests)"),
 }
 
 
@@ -19,6 +23,8 @@ def material(name):
         return dict(kind="mr", mu10=mu / 2, mu01=0.0, kappa=K, rho0=920.0, eta=0.0, lamd=0.0)
     if name == "svk":  # test_feat10_resolution.cc:40-42
         return dict(kind="svk", E=7e8, nu=0.33, rho0=2700.0, eta=0.0, lamd=0.0)
+    if name == "svk_damped":  # test_ancf3243.cc:36-38,287-291
+        return dict(kind="svk", E=7e8, nu=0.33, rho0=2700.0, eta=1e5, lamd=1e5)
     raise KeyError(name)
 
 
@@ -26,6 +32,8 @@ def build(config, cells=None, x_offset_cells=0):
     """-> dict(X, conn, fixed, f_ext, x0, material, params).  `cells`/`x_offset_cells` let a rank build its own
     x-slab of a longer bar (weak scaling): the slab is shifted so that slabs share their interface plane."""
     cfg = CONFIGS[config]
+    if "kind" in cfg:
+        return build_ancf(config)
     nx, ny, nz = cells or cfg["cells"]
     lx, ly, lz = cfg["size"]
     full_nx = cfg["cells"][0]
@@ -53,7 +61,82 @@ def build(config, cells=None, x_offset_cells=0):
     return dict(X=X, conn=conn, fixed=fixed, f_ext=f_ext, x0=x0, material=mat, params=params, desc=cfg["desc"])
 
 
+def build_ancf(config):
+    """ANCF workloads: config A = lib_bin/beam_sag/test_ancf3243.cc cantilever; config D = 3443 plate, one edge
+    clamped (all 4 coefficient vectors of the x=0 nodes), uniform -z line load on the opposite edge."""
+    cfg = CONFIGS[config]
+    mat = material(cfg["material"])
+    L, W, H = cfg["dims"]
+    if cfg["kind"] == 3243:
+        gen = mesh_utils.GridMeshGenerator(cfg["n"][0] * L, 0.0, L, True, False)
+        gen.generate_mesh()
+        x, y, z = gen.get_coordinates()
+        conn = gen.get_element_connectivity()
+        fixed = np.arange(4, dtype=np.int32)
+        f_ext = np.zeros(3 * len(x))
+        f_ext[(conn[-1, 1] * 4) * 3 + 2] = 3100.0
+        params = (1e-4, 0.0, 1e-6, 1e14, 5, 10, 1e-3)  # test_ancf3243.cc:329
+    else:
+        nx, ny = cfg["n"]
+        x, y, z, conn = mesh_utils.structured_3443_plate(nx, ny, L, W)
+        edge = np.where(np.abs(x[0::4]) < 1e-12)[0]
+        fixed = (4 * edge[:, None] + np.arange(4)[None, :]).reshape(-1).astype(np.int32)
+        tip = np.where(np.abs(x[0::4] - nx * L) < 1e-9)[0]
+        f_ext = np.zeros(3 * len(x))
+        f_ext[(4 * tip) * 3 + 2] = -50.0 / len(tip)
+        params = (1e-4, 0.0, 1e-6, 1e14, 5, 10, 1e-3)  # test_ancf3443.cc:357
+    rng = np.random.default_rng(12345)
+    x0 = np.stack([x, y, z], axis=1)
+    pert = 1e-4 * min(L, W) * rng.normal(size=x0.shape)
+    pert[fixed] = 0.0
+    return dict(kind=cfg["kind"], x12=x, y12=y, z12=z, conn=conn, dims=(L, W, H), fixed=fixed, f_ext=f_ext,
+                x0=x0 + pert, X=x0, material=mat, params=params, desc=cfg["desc"])
+
+
+def make_ancf_engine(tl, w, with_solver=True):
+    """Reference call order of lib_bin/beam_sag/test_ancf3243.cc:242-349 / test_ancf3443.cc:240-357."""
+    q = tl.quadrature
+    m, (L, W, H) = w["material"], w["dims"]
+    n_nodes = len(w["x12"]) // 4
+    if w["kind"] == 3243:
+        d = tl.GPU_ANCF3243_Data(n_nodes, w["conn"].shape[0])
+    else:
+        d = tl.GPU_ANCF3443_Data(n_nodes, w["conn"].shape[0])
+    d.Initialize()
+    d.SetNodalFixed(w["fixed"])
+    d.SetExternalForce(w["f_ext"])
+    if w["kind"] == 3243:
+        d.Setup(L, W, H, q.gauss_xi_m_6, q.gauss_xi_3, q.gauss_eta_2, q.gauss_zeta_2, q.weight_xi_m_6, q.weight_xi_3,
+                q.weight_eta_2, q.weight_zeta_2, w["x12"], w["y12"], w["z12"], w["conn"])
+    else:
+        d.Setup(L, W, H, q.gauss_xi_m_7, q.gauss_eta_m_7, q.gauss_zeta_m_3, q.gauss_xi_4, q.gauss_eta_4, q.gauss_zeta_3,
+                q.weight_xi_m_7, q.weight_eta_m_7, q.weight_zeta_m_3, q.weight_xi_4, q.weight_eta_4, q.weight_zeta_3,
+                w["x12"], w["y12"], w["z12"], w["conn"])
+    d.SetDensity(m["rho0"])
+    d.SetDamping(m["eta"], m["lamd"])
+    d.SetSVK(m["E"], m["nu"])
+    d.CalcDsDuPre()
+    d.CalcMassMatrix()
+    d.CalcConstraintData()
+    d.ConvertToCSR_ConstraintJacT()
+    d.BuildConstraintJacobianCSR()
+    if not with_solver:
+        return d, None
+    s = tl.SyncedNewtonSolver(d, d.get_n_constraint())
+    s.Setup()
+    s.SetParameters(tl.SyncedNewtonParams(*w["params"]))
+    s.AnalyzeHessianSparsity()
+    s.SetFixedSparsityPattern(True)
+    return d, s
+
+
 def make_engine(tl, w, with_solver=True):
+    if "kind" in w:
+        return make_ancf_engine(tl, w, with_solver)
+    return make_engine_t10(tl, w, with_solver)
+
+
+def make_engine_t10(tl, w, with_solver=True):
     """Reference call order (test_feat10_resolution.cc:273-375) on the product path."""
     q = tl.quadrature
     X, conn, m = w["X"], w["conn"], w["material"]
