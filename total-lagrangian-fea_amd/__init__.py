@@ -12,6 +12,7 @@ from .binding import (LIB_PATH, TlfeaError, load_library, device_count, exported
 from .elements import GPU_ANCF3243_Data, GPU_ANCF3443_Data, GPU_FEAT10_Data  # noqa: F401
 from .solvers import SyncedNewtonParams, SyncedNewtonSolver, LinSolveOpts  # noqa: F401
 from . import mesh_utils, quadrature  # noqa: F401
+from .mesh_manager import MeshManager  # noqa: F401
 
-__all__ = ["GPU_FEAT10_Data", "GPU_ANCF3243_Data", "GPU_ANCF3443_Data", "SyncedNewtonSolver", "SyncedNewtonParams", "LinSolveOpts", "mesh_utils",
+__all__ = ["GPU_FEAT10_Data", "GPU_ANCF3243_Data", "GPU_ANCF3443_Data", "SyncedNewtonSolver", "SyncedNewtonParams", "LinSolveOpts", "mesh_utils", "MeshManager",
            "quadrature", "load_library", "device_count", "TlfeaError", "LIB_PATH", "exported_symbols"]

@@ -8,6 +8,7 @@
 #include "tlfea_internal.h"
 
 #include <algorithm>
+#include <cstdlib>
 
 namespace tlfea {
 
@@ -174,7 +175,7 @@ __device__ __forceinline__ double ld_stream(const double* p) {
 
 // FUSED: p_new = z + beta p_old is formed on the fly (small meshes: one launch fewer per iteration).
 // !FUSED: p was written by pcg_direction_kernel; only p is gathered (large meshes: half the gather traffic).
-template <bool FUSED, bool NT>
+template <bool FUSED, bool NT, int LANES>
 __global__ __launch_bounds__(1024) void spmv_dir_dot_kernel(int N, Incidence inc, const double* __restrict__ Hval,
                                                            const double* __restrict__ z,
                                                            const double* __restrict__ p_old, int first,
@@ -189,18 +190,20 @@ __global__ __launch_bounds__(1024) void spmv_dir_dot_kernel(int N, Incidence inc
     sum_slots2(rz_part_old, rz_part_new, rz_old, rz_new, sh);
     beta = rz_new / rz_old;
   }
-  const int l32 = threadIdx.x & 31, hw = threadIdx.x >> 5;  // 32 half-waves per workgroup
+  // LANES (32 or 16) lanes walk one node row: 2 or 4 rows per wavefront at a time
+  const int l32 = threadIdx.x & (LANES - 1), hw = threadIdx.x / LANES;
+  constexpr int kGroups = 1024 / LANES;
   const int rows_per_block = (N + gridDim.x - 1) / gridDim.x;
   const int r0 = blockIdx.x * rows_per_block;
   const int r1 = min(N, r0 + rows_per_block);
   double pq = 0.0;
-  for (int i = r0 + hw; i < r1; i += 32) {
+  for (int i = r0 + hw; i < r1; i += kGroups) {
     const int off0 = inc.off[i], deg = inc.off[i + 1] - off0, row = 3 * deg;
     const double* Hi = Hval + (size_t)9 * off0;
     double s0 = 0.0, s1 = 0.0, s2 = 0.0;
     // two column rounds in flight per pass (the loads of both rounds are issued before either gather returns)
-    for (int t = l32; t < row; t += 64) {
-      const int t2 = t + 32;
+    for (int t = l32; t < row; t += 2 * LANES) {
+      const int t2 = t + LANES;
       const bool has2 = t2 < row;
       const double h0 = ld_stream<NT>(Hi + t), h1 = ld_stream<NT>(Hi + row + t), h2 = ld_stream<NT>(Hi + 2 * row + t);
       const int k = t / 3, e = t - 3 * k;
@@ -227,7 +230,7 @@ __global__ __launch_bounds__(1024) void spmv_dir_dot_kernel(int N, Incidence inc
       s2 += h2 * pa + g2 * pb;
     }
 #pragma unroll
-    for (int o = 16; o > 0; o >>= 1) {
+    for (int o = LANES / 2; o > 0; o >>= 1) {
       s0 += __shfl_xor(s0, o);
       s1 += __shfl_xor(s1, o);
       s2 += __shfl_xor(s2, o);
@@ -260,13 +263,17 @@ void launch_spmv_dir_dot(hipStream_t s, int N, const Incidence& inc, const doubl
                          const double* p_old, int first, const double* rz_part_old, const double* rz_part_new,
                          double* p_new, double* q, double* pq_part, bool fused, bool nt) {
   const dim3 g(spmv_grid(N)), b(1024);
-#define TLFEA_SPMV(F, T)                                                                                          \
-  hipLaunchKernelGGL((spmv_dir_dot_kernel<F, T>), g, b, 0, s, N, inc, Hval, z, p_old, first, rz_part_old, rz_part_new, \
-                     p_new, q, pq_part)
-  if (fused && nt) TLFEA_SPMV(true, true);
-  else if (fused) TLFEA_SPMV(true, false);
-  else if (nt) TLFEA_SPMV(false, true);
-  else TLFEA_SPMV(false, false);
+  static const int lanes = std::getenv("TLFEA_SPMV_LANES") ? std::atoi(std::getenv("TLFEA_SPMV_LANES")) : 32;
+#define TLFEA_SPMV(F, T, L)                                                                                       \
+  hipLaunchKernelGGL((spmv_dir_dot_kernel<F, T, L>), g, b, 0, s, N, inc, Hval, z, p_old, first, rz_part_old,          \
+                     rz_part_new, p_new, q, pq_part)
+  if (lanes == 16) {
+    if (fused) TLFEA_SPMV(true, false, 16);
+    else TLFEA_SPMV(false, false, 16);
+  } else if (fused && nt) TLFEA_SPMV(true, true, 32);
+  else if (fused) TLFEA_SPMV(true, false, 32);
+  else if (nt) TLFEA_SPMV(false, true, 32);
+  else TLFEA_SPMV(false, false, 32);
 #undef TLFEA_SPMV
 }
 
