@@ -128,16 +128,19 @@ def main():
     st = s.GetStageMs(reset=True)
     s.SetProfiling(False)
     ab = alg_bytes(E, N, nnz_coef, d.S, d.Q)
+    # mean launch duration: `reps` back-to-back launches per kernel between one hipEvent pair on the launch stream
+    # (kernel time + same-stream boundary; agrees with rocprofv3 --kernel-trace, profiles/*kernel_stats.csv)
+    kt = s.TimeKernels(reps=40 if E < 200000 else 10)
     roof_all = {}
     for k in ("residual", "tangent_blocks", "assemble_rows", "spmv"):
         ms, n = st[k]
         if n == 0:
             continue
-        avg_s = ms / n * 1e-3
+        avg_s = kt[k] * 1e-3
         ach = ab[k] / avg_s / 1e9
         roof_all[k] = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                        "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "avg_us": round(avg_s * 1e6, 2),
-                       "launches": n, "alg_bytes": ab[k], "total_ms": round(ms, 3)}
+                       "launches": n, "alg_bytes": ab[k], "total_ms": round(kt[k] * n, 3)}
     pmc = load_pmc_traffic() if args.config == "B" and world == 1 else {}
     for k, v in roof_all.items():
         if k in pmc:

@@ -407,46 +407,51 @@ void launch_constraint(hipStream_t s, int n_fixed, const int* fixed_nodes, const
                      xt, yt, zt, cons);
 }
 
-// Fused: f_int gather + constraints + grad L (SyncedNewton.cu:344-407), thread per node.
-__global__ void grad_kernel(int N, Incidence inc, const double* __restrict__ fbuf, const double* __restrict__ mval,
-                            const double* __restrict__ v, const double* __restrict__ vprev,
-                            const double* __restrict__ f_ext, const double* __restrict__ x,
-                            const double* __restrict__ y, const double* __restrict__ z,
-                            const double* __restrict__ xt, const double* __restrict__ yt,
-                            const double* __restrict__ zt, const int* __restrict__ fixed_slot,
-                            const double* __restrict__ lam, const double* __restrict__ nw, double h, double rho,
-                            double* __restrict__ f_int, double* __restrict__ cons, double* __restrict__ g) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+// Fused: f_int gather + constraints + grad L (SyncedNewton.cu:344-407).  A 32-lane half-wave per coefficient
+// row: lanes walk the mass row (coalesced values / columns, gathered velocities) and the row's element force
+// rows, then a fixed-order butterfly sums the six partials (deterministic).
+__global__ __launch_bounds__(256) void grad_kernel(int N, Incidence inc, const double* __restrict__ fbuf,
+                                                  const double* __restrict__ mval, const double* __restrict__ v,
+                                                  const double* __restrict__ vprev, const double* __restrict__ f_ext,
+                                                  const double* __restrict__ x, const double* __restrict__ y,
+                                                  const double* __restrict__ z, const double* __restrict__ xt,
+                                                  const double* __restrict__ yt, const double* __restrict__ zt,
+                                                  const int* __restrict__ fixed_slot, const double* __restrict__ lam,
+                                                  const double* __restrict__ nw, double h, double rho,
+                                                  double* __restrict__ f_int, double* __restrict__ cons,
+                                                  double* __restrict__ g) {
+  const int l32 = threadIdx.x & 31;
+  const int i = blockIdx.x * 8 + (threadIdx.x >> 5);
   if (i >= N) return;
-  double f[3] = {0.0, 0.0, 0.0};
-  for (int k = inc.n2e_off[i]; k < inc.n2e_off[i + 1]; k++) {
-    const double* r = fbuf + (size_t)inc.n2e[k] * 3;
-    f[0] += r[0];
-    f[1] += r[1];
-    f[2] += r[2];
-  }
   const double inv_h = 1.0 / h;
-  double res[3] = {0.0, 0.0, 0.0};
-  for (int k = inc.off[i]; k < inc.off[i + 1]; k++) {
+  double a[6] = {0, 0, 0, 0, 0, 0};  // f[0..2], mass term[0..2]
+  for (int k = inc.n2e_off[i] + l32; k < inc.n2e_off[i + 1]; k += 32) {
+    const double* r = fbuf + (size_t)inc.n2e[k] * 3;
+    a[0] += r[0];
+    a[1] += r[1];
+    a[2] += r[2];
+  }
+  for (int k = inc.off[i] + l32; k < inc.off[i + 1]; k += 32) {
     const int c = inc.cols[k];
     const double mij = mval[k];
 #pragma unroll
-    for (int d = 0; d < 3; d++) res[d] += mij * (v[3 * c + d] - vprev[3 * c + d]) * inv_h;
-  }
-  const int slot = fixed_slot ? fixed_slot[i] : -1;
-  double cv[3] = {0, 0, 0};
-  if (slot >= 0) {
-    cv[0] = x[i] - xt[i];
-    cv[1] = y[i] - yt[i];
-    cv[2] = z[i] - zt[i];
+    for (int d = 0; d < 3; d++) a[3 + d] += mij * (v[3 * c + d] - vprev[3 * c + d]) * inv_h;
   }
 #pragma unroll
-  for (int d = 0; d < 3; d++) {
-    f_int[3 * i + d] = f[d];
-    double r = res[d] + f[d] - f_ext[3 * i + d];
+  for (int o = 16; o > 0; o >>= 1)
+#pragma unroll
+    for (int k = 0; k < 6; k++) a[k] += __shfl_xor(a[k], o);
+  if (l32 < 3) {
+    const int d = l32;
+    const int slot = fixed_slot ? fixed_slot[i] : -1;
+    const double fd = (d == 0) ? a[0] : ((d == 1) ? a[1] : a[2]);
+    const double md = (d == 0) ? a[3] : ((d == 1) ? a[4] : a[5]);
+    f_int[3 * i + d] = fd;
+    double r = md + fd - f_ext[3 * i + d];
     if (slot >= 0) {
-      cons[3 * slot + d] = cv[d];
-      r += (nw ? nw[i] : 1.0) * h * (lam[3 * slot + d] + rho * cv[d]);  // nw: 1/multiplicity across ranks
+      const double cv = (d == 0) ? (x[i] - xt[i]) : ((d == 1) ? (y[i] - yt[i]) : (z[i] - zt[i]));
+      cons[3 * slot + d] = cv;
+      r += (nw ? nw[i] : 1.0) * h * (lam[3 * slot + d] + rho * cv);  // nw: 1/multiplicity across ranks
     }
     g[3 * i + d] = r;
   }
@@ -456,8 +461,8 @@ void launch_grad(hipStream_t s, int N, const Incidence& inc, const double* fbuf,
                  const double* vprev, const double* f_ext, const double* x, const double* y, const double* z,
                  const double* xt, const double* yt, const double* zt, const int* fixed_slot, const double* lam,
                  const double* nw, double h, double rho, double* f_int, double* cons, double* g) {
-  hipLaunchKernelGGL(grad_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, inc, fbuf, mval, v, vprev, f_ext, x, y,
-                     z, xt, yt, zt, fixed_slot, lam, nw, h, rho, f_int, cons, g);
+  hipLaunchKernelGGL(grad_kernel, dim3((N + 7) / 8), dim3(256), 0, s, N, inc, fbuf, mval, v, vprev, f_ext, x, y, z,
+                     xt, yt, zt, fixed_slot, lam, nw, h, rho, f_int, cons, g);
 }
 
 // ------------------------------------------------------------------------------------------------

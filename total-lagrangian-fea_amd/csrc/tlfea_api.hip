@@ -1091,6 +1091,43 @@ extern "C" int tlfea_newton_linear_solve(tlfea_newton_t s, const double* b, doub
   return 0;
 }
 
+// Average duration (ms) of each hot kernel over `reps` back-to-back launches on the launch stream, bracketed by
+// one hipEvent pair per kernel (no host work between launches, so the figure is kernel time + the ~1.5 us
+// same-stream boundary, directly comparable with rocprofv3 --kernel-trace).  The launches recompute what the
+// last Newton iteration computed (same inputs, same outputs), so the solver state is unchanged.
+// out[0] residual, [1] tangent blocks, [2] row assembly, [3] SpMV.
+extern "C" int tlfea_newton_time_kernels(tlfea_newton_t s, int reps, double* out_ms4) {
+  TRY(tlfea_newton_analyze_hessian_sparsity(s));
+  tlfea_t10_t d = s->d;
+  const tlfea_newton_params& p = s->prm;
+  if (reps < 1) reps = 1;
+  const int N = s->N;
+  const bool fused = s->pcg_fused < 0 ? (N <= 200000) : (s->pcg_fused != 0);
+  for (int k = 0; k < 4; k++) {
+    HIP_TRY(hipEventRecord(s->ev[6], s->stream));
+    for (int r = 0; r < reps; r++) {
+      if (k == 0)
+        launch_residual(s->stream, d->view(), d->mat, s->d_v, d->d_fbuf, nullptr, nullptr, nullptr, nullptr);
+      else if (k == 1)
+        launch_tangent_blocks(s->stream, d->view(), d->mat, p.time_step, s->d_Kbuf);
+      else if (k == 2)
+        launch_assemble_rows(s->stream, N, d->S, d->maxdeg, d->inc(), s->d_Kbuf, d->d_mval, 1.0 / p.time_step,
+                             d->is_constraints_setup ? d->d_fixed_slot : nullptr, s->d_nw,
+                             p.time_step * p.time_step * p.rho, s->d_H);
+      else  // same variant the solver uses; first=1 reads no reduction slots, inputs are the last z / p
+        launch_spmv_dir_dot(s->stream, N, d->inc(), s->d_H, s->d_zv, s->d_p, 1, part(s, 1), part(s, 0), s->d_p2, s->d_q,
+                            part(s, 2), fused, s->spmv_nt);
+    }
+    HIP_TRY(hipEventRecord(s->ev[7], s->stream));
+    HIP_TRY(hipEventSynchronize(s->ev[7]));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, s->ev[6], s->ev[7]));
+    out_ms4[k] = ms / reps;
+  }
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
 // y = H x for host vectors with the current H (partition-boundary rows summed over ranks)
 extern "C" int tlfea_newton_apply_hessian(tlfea_newton_t s, const double* x, double* y) {
   const size_t n = 3 * (size_t)s->N;

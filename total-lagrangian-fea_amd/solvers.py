@@ -149,6 +149,12 @@ class SyncedNewtonSolver:
         check(self._lib.tlfea_newton_get_stage_ms(self._h, dp(ms), dp(cnt), int(reset)))
         return {k: (ms[i], int(cnt[i])) for i, k in enumerate(self.STAGES) if k != "_"}
 
+    def TimeKernels(self, reps=20):
+        """-> {kernel: mean ms} over `reps` back-to-back launches each (hipEvents on the launch stream)."""
+        out = np.zeros(4)
+        check(self._lib.tlfea_newton_time_kernels(self._h, int(reps), dp(out)))
+        return dict(zip(["residual", "tangent_blocks", "assemble_rows", "spmv"], out.tolist()))
+
     def BeginStep(self):
         check(self._lib.tlfea_newton_begin_step(self._h))
 
