@@ -52,6 +52,7 @@ def main():
     ap.add_argument("--rel-tol", type=float, default=1e-12)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--max-pcg", type=int, default=50000, help="cap on PCG iterations (kernel experiments only)")
+    ap.add_argument("--cheb-deg", type=int, default=12, help="Chebyshev preconditioner degree (1 = block-Jacobi)")
     args = ap.parse_args()
 
     import torch
@@ -86,7 +87,7 @@ def main():
         part = par.slab_partition_structured(w["X"], lx * rank, lx * (rank + 1), rank, world)
         w["f_ext"] = (w["f_ext"].reshape(-1, 3) * part.node_weight[:, None]).reshape(-1)  # this rank's share
     d, s = wl.make_engine(tl, w)
-    s.SetLinSolveOpts(tl.LinSolveOpts(args.rel_tol, args.max_pcg, 25))
+    s.SetLinSolveOpts(tl.LinSolveOpts(args.rel_tol, args.max_pcg, 25, args.cheb_deg, 400.0))
     if world > 1:
         par.attach(s, part, torch, dist)
     d.UpdatePositions(w["x0"][:, 0], w["x0"][:, 1], w["x0"][:, 2])

@@ -42,9 +42,12 @@ typedef struct {
  * 1103-1114); this engine solves the same SPD system H dv = -g with a block-Jacobi preconditioned
  * CG on the device.  rel_tol is on ||r||/||b||. */
 typedef struct {
-  double rel_tol; /* default 1e-12 */
-  int max_iter;   /* default 20000 */
-  int check_every; /* iterations between host convergence checks (default 25) */
+  double rel_tol;    /* default 1e-12 */
+  int max_iter;      /* default 20000 (outer CG iterations) */
+  int check_every;   /* outer iterations between host convergence checks (default 25) */
+  int cheb_degree;   /* degree of the Chebyshev polynomial of D^-1 H used as preconditioner; 1 = plain block-Jacobi
+                        (default 12: one CG iteration then costs 11 reduction-free SpMV launches + the CG pair) */
+  double cheb_kappa; /* the polynomial targets [lmax/kappa, lmax] of D^-1 H (default 400) */
 } tlfea_linsolve_opts;
 
 const char *tlfea_last_error(void);

@@ -137,6 +137,27 @@ def test_hessian(mesh, mat):
     d.Destroy()
 
 
+@pytest.mark.parametrize("deg", [1, 4, 12])
+def test_linear_solve_preconditioner_degrees(deg):
+    """Plain block-Jacobi (deg 1) and Chebyshev polynomial preconditioners give the same solution."""
+    X, conn = load_mesh("res2")
+    fixed = fixed_x0(X)
+    o, d = make_oracle(X, conn, MATERIALS["svk"], fixed), make_gpu(X, conn, MATERIALS["svk"], fixed)
+    x, _ = perturbed_state(X, sigma=1e-4)
+    set_state(o, d, x)
+    s = tl.SyncedNewtonSolver(d, d.get_n_constraint())
+    s.SetParameters(tl.SyncedNewtonParams(1e-4, 1e-4, 1e-4, 1e14, 5, 10, 1e-3))
+    s.SetLinSolveOpts(tl.LinSolveOpts(1e-13, 20000, 10, deg, 400.0))
+    s.AssembleHessian()
+    ro, ci, val = o.assemble_hessian(1e-3, 1e14)
+    b = np.random.default_rng(3).normal(size=3 * X.shape[0])
+    x_ref = orc.solve_spd_upper(ro, ci, val, b)
+    x_gpu, iters, rel = s.LinearSolve(b)
+    assert rel < 1e-12 and relerr(x_gpu, x_ref) < 1e-8
+    del s
+    d.Destroy()
+
+
 @pytest.mark.parametrize("tag", ["beam_3x2x1", "res2"])
 def test_linear_solve_against_direct(tag):
     X, conn = load_mesh(tag)

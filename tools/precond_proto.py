@@ -294,3 +294,31 @@ def run_patch(config="B", cells=None):
     P, _ = p1_prolongation(conn, N); Ac = (P.T @ H @ P).tocsc(); lu = spla.splu(Ac)
     def M2(r): return M_as(r) + P @ lu.solve(P.T @ r)
     _, it = pcg(H, b, M2); print("additive Schwarz + exact P1 coarse: iters", it)
+
+
+def run_chebpoly(config="B", cells=None):
+    """PCG with a degree-d Chebyshev polynomial of D^-1 H as preconditioner (no inner dot products)."""
+    w, H, b = build(config, cells)
+    Minv, _ = block_jacobi(H)
+    _, it0 = pcg(H, b, Minv); print("block-Jacobi PCG:", it0)
+    lmax = est_lmax(H, Minv, 30) * 1.05
+    # lambda_min estimate from Lanczos on the first CG iterations is emulated by trying several kappa guesses
+    for kappa in (100, 400, 1000, 2500):
+        for deg in (4, 8, 16):
+            a, bb = lmax / kappa, lmax
+            theta, delta = 0.5 * (bb + a), 0.5 * (bb - a)
+            sigma = theta / delta
+            def M(r, deg=deg, theta=theta, delta=delta, sigma=sigma):
+                rho = 1.0 / sigma
+                d = Minv(r) / theta
+                z = d.copy()
+                res = r.copy()
+                for _ in range(deg - 1):
+                    res -= H @ d
+                    rho_new = 1.0 / (2 * sigma - rho)
+                    d = rho_new * rho * d + (2 * rho_new / delta) * Minv(res)
+                    z += d
+                    rho = rho_new
+                return z
+            _, it = pcg(H, b, M)
+            print(f"kappa {kappa:5d} deg {deg:2d}: outer iters {it:4d}  SpMVs {it*deg:5d}  kernels ~{it*(deg-1+2)}")

@@ -23,7 +23,8 @@ class NewtonParams(C.Structure):  # SyncedNewtonParams (SyncedNewton.cuh:29-33)
 
 
 class LinSolveOptsC(C.Structure):
-    _fields_ = [("rel_tol", C.c_double), ("max_iter", C.c_int), ("check_every", C.c_int)]
+    _fields_ = [("rel_tol", C.c_double), ("max_iter", C.c_int), ("check_every", C.c_int), ("cheb_degree", C.c_int),
+                ("cheb_kappa", C.c_double)]
 
 
 def exported_symbols():

@@ -21,6 +21,8 @@
 // Math follows SVK.cuh:14-55, MooneyRivlin.cuh:17-225, FEAT10Data.cu:97-278 (cited inline).
 #include "tlfea_internal.h"
 
+#include <cstdlib>
+
 namespace tlfea {
 
 // ------------------------------------------------------------------------------------------------
@@ -494,20 +496,25 @@ struct TangentLds {
   static constexpr int kTotal = (kU + kUsize > kPairs * 9) ? (kU + kUsize) : (kPairs * 9);
 };
 
-template <int S, int Q, int QC, int MODEL>
-__global__ __launch_bounds__(64) void tangent_blocks_kernel(ElemView m, Material mat, double h,
-                                                           double* __restrict__ Kbuf) {
+// WPB wavefronts per workgroup, one element each (own LDS slice); all waves run the same barrier sequence, so
+// __syncthreads() stays legal; WPB > 1 cuts the workgroup dispatch count (972k single-wave groups at config C).
+template <int S, int Q, int QC, int MODEL, int WPB>
+__global__ __launch_bounds__(64 * WPB) void tangent_blocks_kernel(ElemView m, Material mat, double h,
+                                                                 double* __restrict__ Kbuf) {
   using LD = TangentLds<S, Q, QC, MODEL>;
   constexpr int P = LD::kPairs;
   constexpr int NPL = (P + 63) / 64;  // pairs per lane
-  __shared__ double lds[LD::kTotal];
+  __shared__ double lds_all[LD::kTotal * WPB];
+  double* lds = lds_all + (threadIdx.x >> 6) * LD::kTotal;
   double* xs = lds + LD::kX;
   double* hs = lds + LD::kH;
   double* Fs = lds + LD::kF;
   double* U = lds + LD::kU;
-  const int e = blockIdx.x;
-  const int lane = threadIdx.x;
   const int E = m.E;
+  const int e_raw = blockIdx.x * WPB + (threadIdx.x >> 6);
+  const bool live = e_raw < E;
+  const int e = live ? e_raw : E - 1;  // idle waves shadow the last element (they must still hit every barrier)
+  const int lane = threadIdx.x & 63;
 
   for (int t = lane; t < 3 * S; t += 64) {
     const int a = t % S, d = t / S;
@@ -705,15 +712,25 @@ __global__ __launch_bounds__(64) void tangent_blocks_kernel(ElemView m, Material
   }
   __syncthreads();
   double* out = Kbuf + (size_t)e * (P * 9);
-  for (int t = lane; t < P * 9; t += 64) out[t] = lds[t];
+  if (live)
+    for (int t = lane; t < P * 9; t += 64) out[t] = lds[t];
 }
 
 template <int S, int Q, int QC>
 static void launch_tangent_t(hipStream_t s, const ElemView& m, const Material& mat, double h, double* Kbuf) {
+  static const int wpb = std::getenv("TLFEA_TANGENT_WPB") ? std::atoi(std::getenv("TLFEA_TANGENT_WPB")) : 1;
+  if (wpb == 4) {
+    const dim3 g((m.E + 3) / 4), b(256);
+    if (mat.model == kMooneyRivlin)
+      hipLaunchKernelGGL((tangent_blocks_kernel<S, Q, QC, kMooneyRivlin, 4>), g, b, 0, s, m, mat, h, Kbuf);
+    else
+      hipLaunchKernelGGL((tangent_blocks_kernel<S, Q, QC, kSVK, 4>), g, b, 0, s, m, mat, h, Kbuf);
+    return;
+  }
   if (mat.model == kMooneyRivlin)
-    hipLaunchKernelGGL((tangent_blocks_kernel<S, Q, QC, kMooneyRivlin>), dim3(m.E), dim3(64), 0, s, m, mat, h, Kbuf);
+    hipLaunchKernelGGL((tangent_blocks_kernel<S, Q, QC, kMooneyRivlin, 1>), dim3(m.E), dim3(64), 0, s, m, mat, h, Kbuf);
   else
-    hipLaunchKernelGGL((tangent_blocks_kernel<S, Q, QC, kSVK>), dim3(m.E), dim3(64), 0, s, m, mat, h, Kbuf);
+    hipLaunchKernelGGL((tangent_blocks_kernel<S, Q, QC, kSVK, 1>), dim3(m.E), dim3(64), 0, s, m, mat, h, Kbuf);
 }
 
 void launch_tangent_blocks(hipStream_t s, const ElemView& m, const Material& mat, double h, double* Kbuf) {

@@ -350,6 +350,215 @@ void launch_pcg_update(hipStream_t s, int N, const double* Dinv, const double* w
                      z, rz_part_new, rr_part);
 }
 
+// ---- Chebyshev polynomial preconditioner ----------------------------------------------------------
+// z = p_d(D^-1 H) D^-1 r : d steps of the Chebyshev iteration for H z = r on [lmax/kappa, lmax] of D^-1 H, started
+// from z = 0.  A fixed polynomial, so it is a valid (SPD) CG preconditioner; unlike CG it needs NO dot products:
+// every step is one SpMV fused with its vector updates -- on small meshes the two reductions per CG iteration are
+// what the iteration costs, on large ones the fused step streams H once with no extra vector passes.
+// step 0 (no SpMV):  d = D^-1 r / theta ; z = d ; res = r
+__global__ __launch_bounds__(256) void cheb_init_kernel(int N, const double* __restrict__ Dinv,
+                                                       const double* __restrict__ r, double inv_theta,
+                                                       double* __restrict__ d, double* __restrict__ z,
+                                                       double* __restrict__ res) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= N) return;
+  const double r0 = r[3 * i], r1 = r[3 * i + 1], r2 = r[3 * i + 2];
+  const double* D = Dinv + (size_t)9 * i;
+#pragma unroll
+  for (int c = 0; c < 3; c++) {
+    const double v = (D[3 * c] * r0 + D[3 * c + 1] * r1 + D[3 * c + 2] * r2) * inv_theta;
+    d[3 * i + c] = v;
+    z[3 * i + c] = v;
+  }
+  res[3 * i] = r0;
+  res[3 * i + 1] = r1;
+  res[3 * i + 2] = r2;
+}
+
+void launch_cheb_init(hipStream_t s, int N, const double* Dinv, const double* r, double inv_theta, double* d,
+                      double* z, double* res) {
+  hipLaunchKernelGGL(cheb_init_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, Dinv, r, inv_theta, d, z, res);
+}
+
+// step k >= 1:  res -= H d_old ; d_new = c1 d_old + c2 D^-1 res ; z += d_new          (one launch, no reduction)
+// LAST adds the partial slots of r.z for the enclosing CG (w: 1/multiplicity weights, multi-GPU).
+template <bool LAST>
+__global__ __launch_bounds__(1024) void cheb_step_kernel(int N, Incidence inc, const double* __restrict__ Hval,
+                                                        const double* __restrict__ Dinv,
+                                                        const double* __restrict__ d_old, double c1, double c2,
+                                                        double* __restrict__ d_new, double* __restrict__ z,
+                                                        double* __restrict__ res, const double* __restrict__ r,
+                                                        const double* __restrict__ w, double* __restrict__ rz_part) {
+  __shared__ double sh[32];
+  const int l32 = threadIdx.x & 31, hw = threadIdx.x >> 5;
+  const int rows_per_block = (N + gridDim.x - 1) / gridDim.x;
+  const int r0 = blockIdx.x * rows_per_block;
+  const int r1 = min(N, r0 + rows_per_block);
+  double rz = 0.0;
+  for (int i = r0 + hw; i < r1; i += 32) {
+    const int off0 = inc.off[i], deg = inc.off[i + 1] - off0, row = 3 * deg;
+    const double* Hi = Hval + (size_t)9 * off0;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+    for (int t = l32; t < row; t += 64) {
+      const int t2 = t + 32;
+      const bool has2 = t2 < row;
+      const double h0 = Hi[t], h1 = Hi[row + t], h2 = Hi[2 * row + t];
+      const int k = t / 3, e = t - 3 * k;
+      const int ca = 3 * inc.cols[off0 + k] + e;
+      double g0 = 0.0, g1 = 0.0, g2 = 0.0;
+      int cb = ca;
+      if (has2) {
+        g0 = Hi[t2];
+        g1 = Hi[row + t2];
+        g2 = Hi[2 * row + t2];
+        const int kb = t2 / 3, eb = t2 - 3 * kb;
+        cb = 3 * inc.cols[off0 + kb] + eb;
+      }
+      const double pa = d_old[ca], pb = d_old[cb];
+      s0 += h0 * pa + g0 * pb;
+      s1 += h1 * pa + g1 * pb;
+      s2 += h2 * pa + g2 * pb;
+    }
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) {
+      s0 += __shfl_xor(s0, o);
+      s1 += __shfl_xor(s1, o);
+      s2 += __shfl_xor(s2, o);
+    }
+    // all lanes hold the row sums: lanes 0..2 finish component c
+    if (l32 < 3) {
+      const int c = l32;
+      const double e0 = res[3 * i] - s0, e1 = res[3 * i + 1] - s1, e2 = res[3 * i + 2] - s2;
+      const double* D = Dinv + (size_t)9 * i;
+      const double zc = D[3 * c] * e0 + D[3 * c + 1] * e1 + D[3 * c + 2] * e2;
+      const double dn = c1 * d_old[3 * i + c] + c2 * zc;
+      const double zn = z[3 * i + c] + dn;
+      d_new[3 * i + c] = dn;
+      z[3 * i + c] = zn;
+      if (LAST) rz += (w ? w[3 * i + c] : 1.0) * r[3 * i + c] * zn;
+    }
+    // res is read by lanes 0..2 of THIS half-wave only, so it can be overwritten once they are done
+    if (!LAST) {
+      const double ec = (l32 == 0) ? s0 : ((l32 == 1) ? s1 : s2);
+      if (l32 < 3) res[3 * i + l32] = res[3 * i + l32] - ec;
+    }
+  }
+  if (LAST) {
+    const double t = block_sum(rz, sh);
+    if (threadIdx.x == 0) rz_part[blockIdx.x] = t;
+    if (blockIdx.x == 0)
+      for (int k = gridDim.x + threadIdx.x; k < kNPart; k += blockDim.x) rz_part[k] = 0.0;
+  }
+}
+
+void launch_cheb_step(hipStream_t s, int N, const Incidence& inc, const double* Hval, const double* Dinv,
+                      const double* d_old, double c1, double c2, double* d_new, double* z, double* res,
+                      const double* r, const double* w, double* rz_part, bool last) {
+  const dim3 g(spmv_grid(N)), b(1024);
+  if (last)
+    hipLaunchKernelGGL((cheb_step_kernel<true>), g, b, 0, s, N, inc, Hval, Dinv, d_old, c1, c2, d_new, z, res, r, w,
+                       rz_part);
+  else
+    hipLaunchKernelGGL((cheb_step_kernel<false>), g, b, 0, s, N, inc, Hval, Dinv, d_old, c1, c2, d_new, z, res, r, w,
+                       rz_part);
+}
+
+// the same step with the SpMV result q = H d_old already summed over ranks (multi-GPU path)
+template <bool LAST>
+__global__ __launch_bounds__(256) void cheb_update_kernel(int N, const double* __restrict__ Dinv,
+                                                         const double* __restrict__ q,
+                                                         const double* __restrict__ d_old, double c1, double c2,
+                                                         double* __restrict__ d_new, double* __restrict__ z,
+                                                         double* __restrict__ res, const double* __restrict__ r,
+                                                         const double* __restrict__ w, double* __restrict__ rz_part) {
+  __shared__ double sh[32];
+  double rz = 0.0;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < N; i += gridDim.x * 256) {
+    const double e0 = res[3 * i] - q[3 * i], e1 = res[3 * i + 1] - q[3 * i + 1], e2 = res[3 * i + 2] - q[3 * i + 2];
+    res[3 * i] = e0;
+    res[3 * i + 1] = e1;
+    res[3 * i + 2] = e2;
+    const double* D = Dinv + (size_t)9 * i;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      const double zc = D[3 * c] * e0 + D[3 * c + 1] * e1 + D[3 * c + 2] * e2;
+      const double dn = c1 * d_old[3 * i + c] + c2 * zc;
+      const double zn = z[3 * i + c] + dn;
+      d_new[3 * i + c] = dn;
+      z[3 * i + c] = zn;
+      if (LAST) rz += (w ? w[3 * i + c] : 1.0) * r[3 * i + c] * zn;
+    }
+  }
+  if (LAST) {
+    const double t = block_sum(rz, sh);
+    if (threadIdx.x == 0) rz_part[blockIdx.x] = t;
+    if (blockIdx.x == 0)
+      for (int k = gridDim.x + threadIdx.x; k < kNPart; k += blockDim.x) rz_part[k] = 0.0;
+  }
+}
+
+void launch_cheb_update(hipStream_t s, int N, const double* Dinv, const double* q, const double* d_old, double c1,
+                        double c2, double* d_new, double* z, double* res, const double* r, const double* w,
+                        double* rz_part, bool last) {
+  const dim3 g(std::max(1, std::min(kNPart, (N + 255) / 256))), b(256);
+  if (last)
+    hipLaunchKernelGGL((cheb_update_kernel<true>), g, b, 0, s, N, Dinv, q, d_old, c1, c2, d_new, z, res, r, w, rz_part);
+  else
+    hipLaunchKernelGGL((cheb_update_kernel<false>), g, b, 0, s, N, Dinv, q, d_old, c1, c2, d_new, z, res, r, w, rz_part);
+}
+
+// x += alpha p ; r -= alpha q ; partial r.r  (z comes from the polynomial preconditioner afterwards)
+__global__ __launch_bounds__(256) void pcg_update_noz_kernel(int N, const double* __restrict__ w,
+                                                            const double* __restrict__ p, const double* __restrict__ q,
+                                                            const double* __restrict__ rz_part_old,
+                                                            const double* __restrict__ pq_part, double* __restrict__ x,
+                                                            double* __restrict__ r, double* __restrict__ rr_part) {
+  __shared__ double sh[32];
+  double rz_old, pq;
+  sum_slots2(rz_part_old, pq_part, rz_old, pq, sh);
+  const double alpha = rz_old / pq;
+  double rr = 0.0;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < 3 * N; i += gridDim.x * 256) {
+    x[i] += alpha * p[i];
+    const double rv = r[i] - alpha * q[i];
+    r[i] = rv;
+    rr += (w ? w[i] : 1.0) * rv * rv;
+  }
+  const double t = block_sum(rr, sh);
+  if (threadIdx.x == 0) rr_part[blockIdx.x] = t;
+  if (blockIdx.x == 0)
+    for (int k = gridDim.x + threadIdx.x; k < kNPart; k += blockDim.x) rr_part[k] = 0.0;
+}
+
+void launch_pcg_update_noz(hipStream_t s, int N, const double* w, const double* p, const double* q,
+                           const double* rz_part_old, const double* pq_part, double* x, double* r, double* rr_part) {
+  const int n_blocks = std::max(1, std::min(kNPart, (3 * N + 255) / 256));
+  hipLaunchKernelGGL(pcg_update_noz_kernel, dim3(n_blocks), dim3(256), 0, s, N, w, p, q, rz_part_old, pq_part, x, r,
+                     rr_part);
+}
+
+// v <- D^-1 q (power iteration for lambda_max of D^-1 H)
+__global__ void apply_dinv_kernel(int N, const double* __restrict__ Dinv, const double* __restrict__ q,
+                                  double* __restrict__ v) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const double* D = Dinv + (size_t)9 * i;
+  const double a = q[3 * i], b = q[3 * i + 1], c = q[3 * i + 2];
+  v[3 * i] = D[0] * a + D[1] * b + D[2] * c;
+  v[3 * i + 1] = D[3] * a + D[4] * b + D[5] * c;
+  v[3 * i + 2] = D[6] * a + D[7] * b + D[8] * c;
+}
+void launch_apply_dinv(hipStream_t s, int N, const double* Dinv, const double* q, double* v) {
+  hipLaunchKernelGGL(apply_dinv_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, Dinv, q, v);
+}
+__global__ void scale_kernel(int n, double a, double* __restrict__ v) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) v[i] *= a;
+}
+void launch_scale(hipStream_t s, int n, double a, double* v) {
+  hipLaunchKernelGGL(scale_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, a, v);
+}
+
 // ---- Newton vector updates (SyncedNewton.cu:413-534) ---------------------------------------------
 __global__ void newton_update_kernel(int N, const double* __restrict__ dv, double* __restrict__ v,
                                      const double* __restrict__ xp, const double* __restrict__ yp,

@@ -677,7 +677,10 @@ struct tlfea_newton_s {
   int N = 0, n_constraints = 0;
   int n_constraints_global = 0;  // over all ranks (control flow must be identical on every rank)
   tlfea_newton_params prm{1e-4, 1e-4, 1e-4, 1e14, 5, 10, 1e-3};
-  tlfea_linsolve_opts lin{1e-12, 20000, 25};
+  tlfea_linsolve_opts lin{1e-12, 20000, 25, 12, 400.0};
+  double lam_max = 0.0;       // estimate of lambda_max(D^-1 H) (power iteration, warm-started across solves)
+  double* d_eigv = nullptr;   // its vector
+  double *d_cd = nullptr, *d_cd2 = nullptr, *d_cres = nullptr;  // Chebyshev work vectors
   bool fixed_pattern = false, sparsity_done = false;
   int verbose = 0;
   hipStream_t stream = nullptr;
@@ -715,7 +718,8 @@ extern "C" int tlfea_newton_create(tlfea_t10_t data, int n_constraints, tlfea_ne
   s->n_constraints_global = n_constraints;
   const size_t n = 3 * (size_t)s->N;
   TRY(dmalloc(&s->d_v, n)); TRY(dmalloc(&s->d_vprev, n)); TRY(dmalloc(&s->d_g, n)); TRY(dmalloc(&s->d_dv, n));
-  TRY(dmalloc(&s->d_r, n)); TRY(dmalloc(&s->d_b, n)); TRY(dmalloc(&s->d_p, n)); TRY(dmalloc(&s->d_p2, n)); TRY(dmalloc(&s->d_q, n)); TRY(dmalloc(&s->d_zv, n));
+  TRY(dmalloc(&s->d_r, n)); TRY(dmalloc(&s->d_b, n)); TRY(dmalloc(&s->d_eigv, n)); TRY(dmalloc(&s->d_cd, n));
+  TRY(dmalloc(&s->d_cd2, n)); TRY(dmalloc(&s->d_cres, n)); TRY(dmalloc(&s->d_p, n)); TRY(dmalloc(&s->d_p2, n)); TRY(dmalloc(&s->d_q, n)); TRY(dmalloc(&s->d_zv, n));
   TRY(dmalloc(&s->d_lam, (size_t)std::max(1, n_constraints)));
   TRY(dmalloc(&s->d_xp, (size_t)s->N)); TRY(dmalloc(&s->d_yp, (size_t)s->N)); TRY(dmalloc(&s->d_zp, (size_t)s->N));
   TRY(dmalloc(&s->d_parts, (size_t)6 * kNPart));
@@ -723,6 +727,7 @@ extern "C" int tlfea_newton_create(tlfea_t10_t data, int n_constraints, tlfea_ne
   TRY(dmalloc(&s->d_Dinv, (size_t)9 * s->N));
   for (auto& e : s->ev) HIP_TRY(hipEventCreate(&e));
   if (const char* e = std::getenv("TLFEA_PCG_FUSED")) s->pcg_fused = std::atoi(e);
+  if (const char* e = std::getenv("TLFEA_CHEB_DEG")) s->lin.cheb_degree = std::max(1, std::atoi(e));
   if (const char* e = std::getenv("TLFEA_SPMV_NT")) s->spmv_nt = std::atoi(e) != 0;
   *out = s;
   return tlfea_newton_setup(s);
@@ -730,7 +735,7 @@ extern "C" int tlfea_newton_create(tlfea_t10_t data, int n_constraints, tlfea_ne
 
 extern "C" int tlfea_newton_destroy(tlfea_newton_t s) {
   if (!s) return 0;
-  void* ptrs[] = {s->d_v, s->d_vprev, s->d_lam, s->d_g, s->d_dv, s->d_r, s->d_b, s->d_xp, s->d_yp, s->d_zp, s->d_H,
+  void* ptrs[] = {s->d_v, s->d_vprev, s->d_lam, s->d_g, s->d_dv, s->d_r, s->d_b, s->d_eigv, s->d_cd, s->d_cd2, s->d_cres, s->d_xp, s->d_yp, s->d_zp, s->d_H,
                   s->d_Kbuf, s->d_Dinv, s->d_p, s->d_p2, s->d_q, s->d_zv, s->d_parts, s->d_scal, s->d_if_node, s->d_if_slot, s->d_ibuf, s->d_w, s->d_nw, s->d_wc, s->d_D};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
@@ -761,6 +766,8 @@ extern "C" int tlfea_newton_set_linsolve_opts(tlfea_newton_t s, const tlfea_lins
   if (!s || !o) return fail("null argument");
   s->lin = *o;
   if (s->lin.check_every < 1) s->lin.check_every = 1;
+  if (s->lin.cheb_degree < 1) s->lin.cheb_degree = 1;
+  if (!(s->lin.cheb_kappa > 1.0)) s->lin.cheb_kappa = 400.0;
   return 0;
 }
 extern "C" int tlfea_newton_set_fixed_sparsity_pattern(tlfea_newton_t s, int fixed) {
@@ -998,6 +1005,61 @@ static int assemble(tlfea_newton_t s) {
   return 0;
 }
 
+// lambda_max(D^-1 H) by power iteration (warm-started from the previous solve's vector; H changes little between
+// Newton iterations).  Power iteration converges from below, hence the safety factor.
+static int estimate_lam_max(tlfea_newton_t s, const double* d_b) {
+  tlfea_t10_t d = s->d;
+  const int N = s->N, n = 3 * N;
+  const bool cold = !(s->lam_max > 0.0);
+  const int iters = cold ? 16 : 4;
+  double nrm = 0.0;
+  if (cold) launch_apply_dinv(s->stream, N, s->d_Dinv, d_b, s->d_eigv);
+  TRY(device_norm(s, s->d_eigv, s->d_w, n, &nrm));
+  if (!(nrm > 0.0)) return 0;
+  launch_scale(s->stream, n, 1.0 / nrm, s->d_eigv);
+  double lam = s->lam_max;
+  for (int k = 0; k < iters; k++) {
+    launch_spmv_dir_dot(s->stream, N, d->inc(), s->d_H, s->d_eigv, s->d_eigv, 1, part(s, 1), part(s, 0), s->d_p2, s->d_q,
+                        part(s, 2), false, s->spmv_nt);
+    if (s->ar) TRY(iface_sum(s, s->d_q, 3));
+    launch_apply_dinv(s->stream, N, s->d_Dinv, s->d_q, s->d_eigv);
+    TRY(device_norm(s, s->d_eigv, s->d_w, n, &lam));
+    if (!(lam > 0.0)) return fail("lambda_max estimate failed");
+    launch_scale(s->stream, n, 1.0 / lam, s->d_eigv);
+  }
+  s->lam_max = lam;
+  return 0;
+}
+
+// z = p_deg(D^-1 H) D^-1 r on [lmax/kappa, lmax]; the last step leaves the r.z slots in rz_part
+static int cheb_apply(tlfea_newton_t s, const double* d_r, double* d_z, double* rz_part) {
+  tlfea_t10_t d = s->d;
+  const int N = s->N, deg = s->lin.cheb_degree;
+  const double b = 1.15 * s->lam_max, a = b / s->lin.cheb_kappa;
+  const double theta = 0.5 * (b + a), delta = 0.5 * (b - a), sigma = theta / delta;
+  double rho = 1.0 / sigma;
+  double *d_old = s->d_cd, *d_new = s->d_cd2;
+  launch_cheb_init(s->stream, N, s->d_Dinv, d_r, 1.0 / theta, d_old, d_z, s->d_cres);
+  for (int k = 1; k < deg; k++) {
+    const double rho_new = 1.0 / (2.0 * sigma - rho);
+    const double c1 = rho_new * rho, c2 = 2.0 * rho_new / delta;
+    const bool last = (k == deg - 1);
+    if (s->ar) {
+      launch_spmv_dir_dot(s->stream, N, d->inc(), s->d_H, d_old, d_old, 1, part(s, 1), part(s, 0), s->d_p2, s->d_q,
+                          part(s, 2), false, s->spmv_nt);
+      TRY(iface_sum(s, s->d_q, 3));
+      launch_cheb_update(s->stream, N, s->d_Dinv, s->d_q, d_old, c1, c2, d_new, d_z, s->d_cres, d_r, s->d_w, rz_part,
+                         last);
+    } else {
+      launch_cheb_step(s->stream, N, d->inc(), s->d_H, s->d_Dinv, d_old, c1, c2, d_new, d_z, s->d_cres, d_r, s->d_w,
+                       rz_part, last);
+    }
+    std::swap(d_old, d_new);
+    rho = rho_new;
+  }
+  return 0;
+}
+
 // Solve H x = b on the device (b, x device vectors of 3N).  Standard PCG, block-Jacobi.
 static int pcg(tlfea_newton_t s, const double* d_b, double* d_x, int* iters_out, double* rel_out) {
   tlfea_t10_t d = s->d;
@@ -1025,12 +1087,20 @@ static int pcg(tlfea_newton_t s, const double* d_b, double* d_x, int* iters_out,
     const double target = s->lin.rel_tol * s->lin.rel_tol * bb;
     double* pq_part = part(s, 2);
     const bool fused = s->pcg_fused < 0 ? (N <= 200000) : (s->pcg_fused != 0);
-    int cur = 0;  // which rz partial buffer is "old"
+    const int deg = s->lin.cheb_degree;
+    // an outer iteration costs `deg` SpMV launches: test convergence proportionally more often
+    const int check_every = std::max(1, s->lin.check_every / deg);
+    if (deg > 1) TRY(estimate_lam_max(s, d_b));
+    int cur = 0;  // rz slots of the current iteration live in part(cur), the previous ones in part(1-cur)
     double *p_old = s->d_p, *p_new = s->d_p2;
-    // state entering iteration k: z, r, rz partials in part(cur) [and part(1-cur) = previous, for beta]
     while (it < s->lin.max_iter) {
+      if (deg > 1) {
+        // polynomial preconditioner: z = Cheb(r), r.z slots -> part(cur)   (deg-1 SpMV launches, no reductions)
+        TRY(cheb_apply(s, s->d_r, s->d_zv, part(s, cur)));
+        if (s->ar) TRY(parts_sum(s, part(s, cur)));
+      }
       if (s->profiling) (void)hipEventRecord(s->ev[4], s->stream);
-      // beta = rz(cur)/rz(1-cur); p_new = z + beta p_old; q = H p_new; partials of p_new.q
+      // beta = rz(cur)/rz(1-cur); p = z + beta p; q = H p; partials of p.q
       if (fused) {
         launch_spmv_dir_dot(s->stream, N, d->inc(), s->d_H, s->d_zv, p_old, it == 0, part(s, 1 - cur), part(s, cur),
                             p_new, s->d_q, pq_part, true, s->spmv_nt);
@@ -1045,17 +1115,24 @@ static int pcg(tlfea_newton_t s, const double* d_b, double* d_x, int* iters_out,
         float ms = 0.f;
         (void)hipEventElapsedTime(&ms, s->ev[4], s->ev[5]);
         s->stage_ms[6] += ms;
-        s->stage_n[6] += 1;
+        s->stage_n[6] += deg;  // SpMV launches of this iteration (Chebyshev steps included)
       }
       if (s->ar) TRY(iface_sum(s, s->d_q, 3, pq_part, kNPart));  // boundary rows of q + p.q slots, one collective
-      // alpha = rz(cur)/pq; x += alpha p; r -= alpha q; z = Dinv r; new rz partials into part(1-cur)
-      launch_pcg_update(s->stream, N, s->d_Dinv, w, fused ? p_new : p_old, s->d_q, part(s, cur), pq_part, d_x, s->d_r,
-                        s->d_zv, part(s, 1 - cur), part(s, 3));
-      if (s->ar) TRY(parts_sum(s, part(s, 1 - cur), part(s, 3)));  // r.z and r.r slots, one collective
+      if (deg > 1) {
+        // alpha = rz(cur)/pq; x += alpha p; r -= alpha q; r.r slots
+        launch_pcg_update_noz(s->stream, N, w, fused ? p_new : p_old, s->d_q, part(s, cur), pq_part, d_x, s->d_r,
+                              part(s, 3));
+        if (s->ar) TRY(parts_sum(s, part(s, 3)));
+      } else {
+        // ... and z = Dinv r with the new r.z slots into part(1-cur)
+        launch_pcg_update(s->stream, N, s->d_Dinv, w, fused ? p_new : p_old, s->d_q, part(s, cur), pq_part, d_x, s->d_r,
+                          s->d_zv, part(s, 1 - cur), part(s, 3));
+        if (s->ar) TRY(parts_sum(s, part(s, 1 - cur), part(s, 3)));  // r.z and r.r slots, one collective
+      }
       cur = 1 - cur;
       if (fused) std::swap(p_old, p_new);
       it++;
-      if (it % s->lin.check_every == 0 || it == s->lin.max_iter) {
+      if (it % check_every == 0 || it == s->lin.max_iter) {
         launch_sum_parts(s->stream, part(s, 3), s->d_scal + 2);
         HIP_TRY(hipMemcpyAsync(&rr, s->d_scal + 2, sizeof(double), hipMemcpyDeviceToHost, s->stream));
         HIP_TRY(hipStreamSynchronize(s->stream));

@@ -91,6 +91,18 @@ void launch_pcg_update(hipStream_t s, int N, const double* Dinv, const double* w
                        const double* rz_part_old, const double* pq_part, double* x, double* r, double* z,
                        double* rz_part_new, double* rr_part);
 void launch_sum_parts(hipStream_t s, const double* part, double* out);
+void launch_cheb_init(hipStream_t s, int N, const double* Dinv, const double* r, double inv_theta, double* d,
+                      double* z, double* res);
+void launch_cheb_step(hipStream_t s, int N, const Incidence& inc, const double* Hval, const double* Dinv,
+                      const double* d_old, double c1, double c2, double* d_new, double* z, double* res,
+                      const double* r, const double* w, double* rz_part, bool last);
+void launch_cheb_update(hipStream_t s, int N, const double* Dinv, const double* q, const double* d_old, double c1,
+                        double c2, double* d_new, double* z, double* res, const double* r, const double* w,
+                        double* rz_part, bool last);
+void launch_pcg_update_noz(hipStream_t s, int N, const double* w, const double* p, const double* q,
+                           const double* rz_part_old, const double* pq_part, double* x, double* r, double* rr_part);
+void launch_apply_dinv(hipStream_t s, int N, const double* Dinv, const double* q, double* v);
+void launch_scale(hipStream_t s, int n, double a, double* v);
 void launch_newton_update(hipStream_t s, int N, const double* dv, double* v, const double* xp, const double* yp,
                           const double* zp, double h, double* x, double* y, double* z);
 void launch_axpy_neg(hipStream_t s, int n, const double* g, double* r);

@@ -23,6 +23,8 @@ class LinSolveOpts:
     rel_tol: float = 1e-12
     max_iter: int = 20000
     check_every: int = 25
+    cheb_degree: int = 12     # Chebyshev polynomial preconditioner degree (1 = plain block-Jacobi)
+    cheb_kappa: float = 400.0
 
 
 class SyncedNewtonSolver:
@@ -52,7 +54,7 @@ class SyncedNewtonSolver:
         check(self._lib.tlfea_newton_set_parameters(self._h, C.byref(p)))
 
     def SetLinSolveOpts(self, o):
-        c = LinSolveOptsC(o.rel_tol, o.max_iter, o.check_every)
+        c = LinSolveOptsC(o.rel_tol, o.max_iter, o.check_every, o.cheb_degree, o.cheb_kappa)
         check(self._lib.tlfea_newton_set_linsolve_opts(self._h, C.byref(c)))
 
     def AnalyzeHessianSparsity(self):
