@@ -52,7 +52,7 @@ def main():
     ap.add_argument("--rel-tol", type=float, default=1e-12)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--max-pcg", type=int, default=50000, help="cap on PCG iterations (kernel experiments only)")
-    ap.add_argument("--cheb-deg", type=int, default=12, help="Chebyshev preconditioner degree (1 = block-Jacobi)")
+    ap.add_argument("--cheb-deg", type=int, default=0, help="Chebyshev preconditioner degree (1 = block-Jacobi, 0 = auto)")
     args = ap.parse_args()
 
     import torch
@@ -63,10 +63,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    torch.cuda.set_device(local_rank)
+    # TLFEA_BENCH_BACKEND=gloo rehearses the multi-rank path on a box with fewer GPUs than ranks (ranks share GPUs,
+    # collectives go through a host staging copy); production is nccl == RCCL over xGMI, one GPU per rank.
+    backend = os.environ.get("TLFEA_BENCH_BACKEND", "nccl")
+    n_dev = max(1, torch.cuda.device_count())
+    torch.cuda.set_device(local_rank % n_dev if backend != "nccl" else local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     tl = importlib.import_module("total-lagrangian-fea_amd")
     from importlib import import_module
@@ -104,6 +111,7 @@ def main():
         return its
 
     def barrier():
+        torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -115,7 +123,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        t = torch.tensor([dt], device="cuda" if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     value = E * world * args.steps / dt
@@ -162,7 +170,9 @@ def main():
         "config": {"workload": f"config {args.config}: {w['desc']}, {E} elements / {N} nodes per GPU, "
                                f"implicit Newton iteration incl. PCG solve (rel_tol {args.rel_tol:g})",
                    "elements_per_gpu": E, "nodes_per_gpu": N, "hessian_nnz": 9 * nnz_coef,
-                   "pcg_iters_per_step": round(float(np.mean(pcg_its)), 1)},
+                   "pcg_outer_iters_per_step": round(float(np.mean(pcg_its)), 1),
+                   "preconditioner": "auto: Chebyshev(12) of block-Jacobi below 200k rows, block-Jacobi above"
+                   if args.cheb_deg == 0 else f"Chebyshev degree {args.cheb_deg} of block-Jacobi"},
         "element_stage": {"ms_per_step": round(elem_ms, 4), "value": round(E / (elem_ms * 1e-3), 1),
                           "note": "residual+gradient+tangent+assembly only (no linear solve), profiling pass"},
         "stage_ms_per_step": stage_share,

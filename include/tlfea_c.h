@@ -45,8 +45,8 @@ typedef struct {
   double rel_tol;    /* default 1e-12 */
   int max_iter;      /* default 20000 (outer CG iterations) */
   int check_every;   /* outer iterations between host convergence checks (default 25) */
-  int cheb_degree;   /* degree of the Chebyshev polynomial of D^-1 H used as preconditioner; 1 = plain block-Jacobi
-                        (default 12: one CG iteration then costs 11 reduction-free SpMV launches + the CG pair) */
+  int cheb_degree;   /* degree of the Chebyshev polynomial of D^-1 H used as preconditioner; 1 = plain block-Jacobi;
+                        0 (default) = auto: 12 up to 200k coefficient rows (launch-bound regime), 1 above */
   double cheb_kappa; /* the polynomial targets [lmax/kappa, lmax] of D^-1 H (default 400) */
 } tlfea_linsolve_opts;
 

@@ -88,3 +88,19 @@ def test_two_ranks_hip_engine_one_gpu(tmp_path):
 def test_three_ranks_hip_engine_one_gpu(tmp_path):
     rep = launch(3, ["--engine", "hip", "--mesh", "box", "--steps", "1"], tmp_path)
     assert rep["ok"], rep
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_rehearsal(tmp_path):
+    """bench.py --gpus 2 end to end (slab construction, interface attach, timing loop, JSON line) with the gloo
+    rehearsal backend: both ranks share the one GPU of the test box; production uses nccl (RCCL)."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup",
+           "1", "--config", "S", "--max-pcg", "2000"]
+    env = dict(os.environ, TLFEA_BENCH_BACKEND="gloo", OMP_NUM_THREADS="2", MASTER_ADDR="127.0.0.1")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0
+    assert out["config"]["elements_per_gpu"] == 6 * 4 * 3 * 2

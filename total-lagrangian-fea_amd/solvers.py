@@ -23,7 +23,7 @@ class LinSolveOpts:
     rel_tol: float = 1e-12
     max_iter: int = 20000
     check_every: int = 25
-    cheb_degree: int = 12     # Chebyshev polynomial preconditioner degree (1 = plain block-Jacobi)
+    cheb_degree: int = 0      # Chebyshev polynomial preconditioner degree (1 = block-Jacobi, 0 = auto by size)
     cheb_kappa: float = 400.0
 
 
