@@ -40,6 +40,8 @@ def alg_bytes(E, N, nnz_coef, S=10, Q=5):
         "assemble_rows": E * npair * 72 + E * 4 * S * S + nnz_coef * 8 + nnz_coef * 72,
         # H values + node-level columns + z,p_old in, p_new,q out
         "spmv": nnz_coef * 72 + nnz_coef * 4 + N * 96,
+        # Chebyshev step: H + columns + d_old gather, res in/out, D^-1, z in/out, d_new out
+        "cheb_step": nnz_coef * 72 + nnz_coef * 4 + N * (24 + 48 + 72 + 48 + 24),
     }
 
 
@@ -141,7 +143,10 @@ def main():
     # (kernel time + same-stream boundary; agrees with rocprofv3 --kernel-trace, profiles/*kernel_stats.csv)
     kt = s.TimeKernels(reps=40 if E < 200000 else 10)
     roof_all = {}
-    for k in ("residual", "tangent_blocks", "assemble_rows", "spmv"):
+    deg_eff = (12 if N <= 200000 else 1) if args.cheb_deg == 0 else args.cheb_deg
+    n_outer = st["spmv"][1] // max(1, deg_eff)       # stage counter tallies deg launches per outer iteration
+    st = dict(st, spmv=(st["spmv"][0], n_outer), cheb_step=(0.0, n_outer * (deg_eff - 1)))
+    for k in ("residual", "tangent_blocks", "assemble_rows", "spmv", "cheb_step"):
         ms, n = st[k]
         if n == 0:
             continue
@@ -193,9 +198,9 @@ def main():
 
 def load_pmc_traffic():
     """HBM bytes per launch from the committed PMC summary (collected with the same command, config B)."""
-    path = os.path.join(ROOT, "profiles", "r01_configB_pmc_hbm.csv")
-    names = {"t10_residual_kernel": "residual", "t10_tangent_blocks_kernel": "tangent_blocks",
-             "assemble_rows_kernel": "assemble_rows", "spmv_dir_dot_kernel": "spmv"}
+    path = os.path.join(ROOT, "profiles", "r01_configB_pmc_hbm.csv")  # regenerated by tools/summarize_pmc.py
+    names = {"residual_kernel": "residual", "tangent_blocks_kernel": "tangent_blocks",
+             "assemble_rows_kernel": "assemble_rows", "spmv_dir_dot_kernel": "spmv", "cheb_step_kernel<false>": "cheb_step"}
     out = {}
     if not os.path.exists(path):
         return out

@@ -157,8 +157,9 @@ int tlfea_newton_assemble_hessian(tlfea_newton_t s);
 /* Solve H x = b for host vectors (b,x length 3N) with the current H; iterations returned. */
 int tlfea_newton_linear_solve(tlfea_newton_t s, const double *b, double *x, int *iters, double *rel_res);
 /* mean duration (ms) of the 4 hot kernels over `reps` back-to-back launches each (hipEvent pair per kernel on the
- * launch stream): [0] residual, [1] tangent blocks, [2] row assembly, [3] SpMV.  Solver state is unchanged. */
-int tlfea_newton_time_kernels(tlfea_newton_t s, int reps, double *out_ms4);
+ * launch stream): [0] residual, [1] tangent blocks, [2] row assembly, [3] CG SpMV, [4] Chebyshev step.  State of
+ * the Newton iteration is unchanged (only linear-solver work vectors are touched). */
+int tlfea_newton_time_kernels(tlfea_newton_t s, int reps, double *out_ms5);
 /* y = H x with the current H, host vectors of 3N (partition-boundary rows summed over ranks). */
 int tlfea_newton_apply_hessian(tlfea_newton_t s, const double *x, double *y);
 /* One full Newton iteration without the convergence test (gradient, assembly, solve, update):

@@ -1180,7 +1180,7 @@ extern "C" int tlfea_newton_linear_solve(tlfea_newton_t s, const double* b, doub
 // one hipEvent pair per kernel (no host work between launches, so the figure is kernel time + the ~1.5 us
 // same-stream boundary, directly comparable with rocprofv3 --kernel-trace).  The launches recompute what the
 // last Newton iteration computed (same inputs, same outputs), so the solver state is unchanged.
-// out[0] residual, [1] tangent blocks, [2] row assembly, [3] SpMV.
+// out[0] residual, [1] tangent blocks, [2] row assembly, [3] CG SpMV, [4] Chebyshev step (SpMV + vector updates).
 extern "C" int tlfea_newton_time_kernels(tlfea_newton_t s, int reps, double* out_ms4) {
   TRY(tlfea_newton_analyze_hessian_sparsity(s));
   tlfea_t10_t d = s->d;
@@ -1188,7 +1188,7 @@ extern "C" int tlfea_newton_time_kernels(tlfea_newton_t s, int reps, double* out
   if (reps < 1) reps = 1;
   const int N = s->N;
   const bool fused = s->pcg_fused < 0 ? (N <= 200000) : (s->pcg_fused != 0);
-  for (int k = 0; k < 4; k++) {
+  for (int k = 0; k < 5; k++) {
     HIP_TRY(hipEventRecord(s->ev[6], s->stream));
     for (int r = 0; r < reps; r++) {
       if (k == 0)
@@ -1199,9 +1199,12 @@ extern "C" int tlfea_newton_time_kernels(tlfea_newton_t s, int reps, double* out
         launch_assemble_rows(s->stream, N, d->S, d->maxdeg, d->inc(), s->d_Kbuf, d->d_mval, 1.0 / p.time_step,
                              d->is_constraints_setup ? d->d_fixed_slot : nullptr, s->d_nw,
                              p.time_step * p.time_step * p.rho, s->d_H);
-      else  // same variant the solver uses; first=1 reads no reduction slots, inputs are the last z / p
+      else if (k == 3)  // same variant the solver uses; first=1 reads no reduction slots, inputs are the last z / p
         launch_spmv_dir_dot(s->stream, N, d->inc(), s->d_H, s->d_zv, s->d_p, 1, part(s, 1), part(s, 0), s->d_p2, s->d_q,
                             part(s, 2), fused, s->spmv_nt);
+      else  // one polynomial-preconditioner step on the solver's work vectors (coefficients are irrelevant to time)
+        launch_cheb_step(s->stream, N, d->inc(), s->d_H, s->d_Dinv, s->d_cd, 0.5, 0.0, s->d_cd2, s->d_zv, s->d_cres,
+                         s->d_r, s->d_w, part(s, 0), false);
     }
     HIP_TRY(hipEventRecord(s->ev[7], s->stream));
     HIP_TRY(hipEventSynchronize(s->ev[7]));

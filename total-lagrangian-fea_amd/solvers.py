@@ -153,9 +153,9 @@ class SyncedNewtonSolver:
 
     def TimeKernels(self, reps=20):
         """-> {kernel: mean ms} over `reps` back-to-back launches each (hipEvents on the launch stream)."""
-        out = np.zeros(4)
+        out = np.zeros(5)
         check(self._lib.tlfea_newton_time_kernels(self._h, int(reps), dp(out)))
-        return dict(zip(["residual", "tangent_blocks", "assemble_rows", "spmv"], out.tolist()))
+        return dict(zip(["residual", "tangent_blocks", "assemble_rows", "spmv", "cheb_step"], out.tolist()))
 
     def BeginStep(self):
         check(self._lib.tlfea_newton_begin_step(self._h))
