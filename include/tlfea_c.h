@@ -46,8 +46,13 @@ typedef struct {
   int max_iter;      /* default 20000 (outer CG iterations) */
   int check_every;   /* outer iterations between host convergence checks (default 25) */
   int cheb_degree;   /* degree of the Chebyshev polynomial of D^-1 H used as preconditioner; 1 = plain block-Jacobi;
-                        0 (default) = auto: 12 up to 200k coefficient rows (launch-bound regime), 1 above */
-  double cheb_kappa; /* the polynomial targets [lmax/kappa, lmax] of D^-1 H (default 400) */
+                        0 (default) = auto = 24 */
+  double cheb_kappa; /* the polynomial targets [lmax/kappa, lmax] of D^-1 H; <= 1 (default 0) = auto by degree
+                        (400 / 800 / 1600 for degree < 14 / < 22 / above) */
+  int cheb_bits;     /* storage precision of the matrix the polynomial streams: 64 = H itself; 32 / 16 = a symmetrically
+                        scaled fp32 / fp16 block copy, and on one GPU the polynomial's recurrence then runs in fp32
+                        (the outer CG, its residual and its convergence test stay fp64 on H);
+                        0 (default) = auto = 16 */
 } tlfea_linsolve_opts;
 
 const char *tlfea_last_error(void);
@@ -146,6 +151,9 @@ int tlfea_newton_l2_norm(tlfea_newton_t s, const double *d_vec, int n, double *o
 
 /* ---- engine extras (no reference counterpart; used by tests/bench/INTEGRATION) -------------- */
 int tlfea_newton_set_linsolve_opts(tlfea_newton_t s, const tlfea_linsolve_opts *o);
+/* what the auto rules resolved to for this mesh: polynomial degree (1 = block-Jacobi), matrix bits of its steps and
+ * the precision of its work vectors (32 on the single-GPU low-precision path, else 64) */
+int tlfea_newton_get_linsolve_info(tlfea_newton_t s, int *cheb_degree, int *cheb_bits, int *cheb_vector_bits);
 int tlfea_newton_hessian_nnz(tlfea_newton_t s, int *nnz);
 /* H in the reference's DOF-level CSR (SyncedNewton.cu:163-205): rows 3N, sorted columns */
 int tlfea_newton_retrieve_hessian_csr(tlfea_newton_t s, int *row_offsets, int *col_indices, double *values);

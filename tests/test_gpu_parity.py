@@ -137,9 +137,10 @@ def test_hessian(mesh, mat):
     d.Destroy()
 
 
-@pytest.mark.parametrize("deg", [1, 4, 12])
-def test_linear_solve_preconditioner_degrees(deg):
-    """Plain block-Jacobi (deg 1) and Chebyshev polynomial preconditioners give the same solution."""
+@pytest.mark.parametrize("deg,bits", [(1, 0), (4, 64), (12, 64), (12, 32), (12, 16), (5, 16), (2, 16)])
+def test_linear_solve_preconditioner_degrees(deg, bits):
+    """Plain block-Jacobi (deg 1) and Chebyshev polynomial preconditioners -- streaming H itself (64) or its scaled
+    fp32 / fp16 copy -- give the same fp64 solution: only the preconditioner is low precision."""
     X, conn = load_mesh("res2")
     fixed = fixed_x0(X)
     o, d = make_oracle(X, conn, MATERIALS["svk"], fixed), make_gpu(X, conn, MATERIALS["svk"], fixed)
@@ -147,7 +148,30 @@ def test_linear_solve_preconditioner_degrees(deg):
     set_state(o, d, x)
     s = tl.SyncedNewtonSolver(d, d.get_n_constraint())
     s.SetParameters(tl.SyncedNewtonParams(1e-4, 1e-4, 1e-4, 1e14, 5, 10, 1e-3))
-    s.SetLinSolveOpts(tl.LinSolveOpts(1e-13, 20000, 10, deg, 400.0))
+    s.SetLinSolveOpts(tl.LinSolveOpts(1e-13, 20000, 10, deg, 400.0, bits))
+    assert s.GetLinSolveInfo()[:2] == (deg, 64 if deg == 1 else bits)
+    s.AssembleHessian()
+    ro, ci, val = o.assemble_hessian(1e-3, 1e14)
+    b = np.random.default_rng(3).normal(size=3 * X.shape[0])
+    x_ref = orc.solve_spd_upper(ro, ci, val, b)
+    x_gpu, iters, rel = s.LinearSolve(b)
+    assert rel < 1e-12 and relerr(x_gpu, x_ref) < 1e-8
+    del s
+    d.Destroy()
+
+
+def test_linear_solve_recovers_from_low_lambda_max(monkeypatch):
+    """A Chebyshev interval that ends below lambda_max makes the preconditioner indefinite and CG break down; the
+    solver must notice, widen the interval and still return the fp64 solution."""
+    monkeypatch.setenv("TLFEA_CHEB_LMAX_SCALE", "0.4")
+    X, conn = load_mesh("res2")
+    fixed = fixed_x0(X)
+    o, d = make_oracle(X, conn, MATERIALS["svk"], fixed), make_gpu(X, conn, MATERIALS["svk"], fixed)
+    x, _ = perturbed_state(X, sigma=1e-4)
+    set_state(o, d, x)
+    s = tl.SyncedNewtonSolver(d, d.get_n_constraint())
+    s.SetParameters(tl.SyncedNewtonParams(1e-4, 1e-4, 1e-4, 1e14, 5, 10, 1e-3))
+    s.SetLinSolveOpts(tl.LinSolveOpts(1e-13, 2000, 10, 24))
     s.AssembleHessian()
     ro, ci, val = o.assemble_hessian(1e-3, 1e14)
     b = np.random.default_rng(3).normal(size=3 * X.shape[0])

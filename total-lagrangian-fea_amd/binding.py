@@ -24,7 +24,7 @@ class NewtonParams(C.Structure):  # SyncedNewtonParams (SyncedNewton.cuh:29-33)
 
 class LinSolveOptsC(C.Structure):
     _fields_ = [("rel_tol", C.c_double), ("max_iter", C.c_int), ("check_every", C.c_int), ("cheb_degree", C.c_int),
-                ("cheb_kappa", C.c_double)]
+                ("cheb_kappa", C.c_double), ("cheb_bits", C.c_int)]
 
 
 def exported_symbols():

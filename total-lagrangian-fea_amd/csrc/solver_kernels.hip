@@ -15,6 +15,8 @@ namespace tlfea {
 // ---- deterministic reductions -------------------------------------------------------------------
 // wave64 butterfly + one LDS hop: 1-2 barriers per workgroup sum instead of a 9-barrier tree (these
 // kernels are latency-, not bandwidth-bound on small meshes).  Orders are fixed -> bitwise reproducible.
+bool row_map_tiled();
+
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -182,22 +184,25 @@ __global__ __launch_bounds__(1024) void spmv_dir_dot_kernel(int N, Incidence inc
                                                            const double* __restrict__ rz_part_old,
                                                            const double* __restrict__ rz_part_new,
                                                            double* __restrict__ p_new, double* __restrict__ q,
-                                                           double* __restrict__ pq_part) {
+                                                           double* __restrict__ pq_part, int tiled) {
   __shared__ double sh[32];
   double beta = 0.0;
   if (FUSED && !first) {
     double rz_old, rz_new;
     sum_slots2(rz_part_old, rz_part_new, rz_old, rz_new, sh);
-    beta = rz_new / rz_old;
+    beta = rz_old != 0.0 ? rz_new / rz_old : 0.0;  // exact convergence (r = 0): keep iterating harmlessly
   }
   // LANES (32 or 16) lanes walk one node row: 2 or 4 rows per wavefront at a time
   const int l32 = threadIdx.x & (LANES - 1), hw = threadIdx.x / LANES;
   constexpr int kGroups = 1024 / LANES;
+  // tiled: the workgroups sweep the rows together (kGroups rows each, round robin) so that the chip gathers from a
+  // narrow window of the vector that stays in L2; otherwise one contiguous chunk per workgroup (see cheb_lp_kernel)
   const int rows_per_block = (N + gridDim.x - 1) / gridDim.x;
-  const int r0 = blockIdx.x * rows_per_block;
-  const int r1 = min(N, r0 + rows_per_block);
+  const int r0 = tiled ? blockIdx.x * kGroups : blockIdx.x * rows_per_block;
+  const int r1 = tiled ? N : min(N, r0 + rows_per_block);
+  const int stride = tiled ? gridDim.x * kGroups : kGroups;
   double pq = 0.0;
-  for (int i = r0 + hw; i < r1; i += kGroups) {
+  for (int i = r0 + hw; i < r1; i += stride) {
     const int off0 = inc.off[i], deg = inc.off[i + 1] - off0, row = 3 * deg;
     const double* Hi = Hval + (size_t)9 * off0;
     double s0 = 0.0, s1 = 0.0, s2 = 0.0;
@@ -263,10 +268,11 @@ void launch_spmv_dir_dot(hipStream_t s, int N, const Incidence& inc, const doubl
                          const double* p_old, int first, const double* rz_part_old, const double* rz_part_new,
                          double* p_new, double* q, double* pq_part, bool fused, bool nt) {
   const dim3 g(spmv_grid(N)), b(1024);
+  const int tiled = row_map_tiled() ? 1 : 0;
   static const int lanes = std::getenv("TLFEA_SPMV_LANES") ? std::atoi(std::getenv("TLFEA_SPMV_LANES")) : 32;
 #define TLFEA_SPMV(F, T, L)                                                                                       \
   hipLaunchKernelGGL((spmv_dir_dot_kernel<F, T, L>), g, b, 0, s, N, inc, Hval, z, p_old, first, rz_part_old,          \
-                     rz_part_new, p_new, q, pq_part)
+                     rz_part_new, p_new, q, pq_part, tiled)
   if (lanes == 16) {
     if (fused) TLFEA_SPMV(true, false, 16);
     else TLFEA_SPMV(false, false, 16);
@@ -287,7 +293,7 @@ __global__ __launch_bounds__(256) void pcg_direction_kernel(int n, const double*
   if (!first) {
     double rz_old, rz_new;
     sum_slots2(rz_part_old, rz_part_new, rz_old, rz_new, sh);
-    beta = rz_new / rz_old;
+    beta = rz_old != 0.0 ? rz_new / rz_old : 0.0;
   }
   for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) p[i] = first ? z[i] : (z[i] + beta * p[i]);
 }
@@ -310,7 +316,7 @@ __global__ __launch_bounds__(256) void pcg_update_kernel(int N, const double* __
   __shared__ double sh[32];
   double rz_old, pq;
   sum_slots2(rz_part_old, pq_part, rz_old, pq, sh);
-  const double alpha = rz_old / pq;
+  const double alpha = pq != 0.0 ? rz_old / pq : 0.0;
   double rz = 0.0, rr = 0.0;
   for (int i = blockIdx.x * 256 + threadIdx.x; i < N; i += gridDim.x * 256) {
     double rv[3];
@@ -356,13 +362,21 @@ void launch_pcg_update(hipStream_t s, int N, const double* Dinv, const double* w
 // every step is one SpMV fused with its vector updates -- on small meshes the two reductions per CG iteration are
 // what the iteration costs, on large ones the fused step streams H once with no extra vector passes.
 // step 0 (no SpMV):  d = D^-1 r / theta ; z = d ; res = r
+// sc != null: scaled space of the low-precision path (Dinv is then (S D S)^-1 and res^ = S r)
 __global__ __launch_bounds__(256) void cheb_init_kernel(int N, const double* __restrict__ Dinv,
-                                                       const double* __restrict__ r, double inv_theta,
+                                                       const double* __restrict__ r,
+                                                       const double* __restrict__ sc, const double* __restrict__ coef,
                                                        double* __restrict__ d, double* __restrict__ z,
                                                        double* __restrict__ res) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= N) return;
-  const double r0 = r[3 * i], r1 = r[3 * i + 1], r2 = r[3 * i + 2];
+  const double inv_theta = coef[0];
+  double r0 = r[3 * i], r1 = r[3 * i + 1], r2 = r[3 * i + 2];
+  if (sc) {
+    r0 *= sc[3 * i];
+    r1 *= sc[3 * i + 1];
+    r2 *= sc[3 * i + 2];
+  }
   const double* D = Dinv + (size_t)9 * i;
 #pragma unroll
   for (int c = 0; c < 3; c++) {
@@ -375,9 +389,9 @@ __global__ __launch_bounds__(256) void cheb_init_kernel(int N, const double* __r
   res[3 * i + 2] = r2;
 }
 
-void launch_cheb_init(hipStream_t s, int N, const double* Dinv, const double* r, double inv_theta, double* d,
-                      double* z, double* res) {
-  hipLaunchKernelGGL(cheb_init_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, Dinv, r, inv_theta, d, z, res);
+void launch_cheb_init(hipStream_t s, int N, const double* Dinv, const double* r, const double* sc,
+                      const double* coef, double* d, double* z, double* res) {
+  hipLaunchKernelGGL(cheb_init_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, Dinv, r, sc, coef, d, z, res);
 }
 
 // step k >= 1:  res -= H d_old ; d_new = c1 d_old + c2 D^-1 res ; z += d_new          (one launch, no reduction)
@@ -385,17 +399,20 @@ void launch_cheb_init(hipStream_t s, int N, const double* Dinv, const double* r,
 template <bool LAST>
 __global__ __launch_bounds__(1024) void cheb_step_kernel(int N, Incidence inc, const double* __restrict__ Hval,
                                                         const double* __restrict__ Dinv,
-                                                        const double* __restrict__ d_old, double c1, double c2,
+                                                        const double* __restrict__ d_old, const double* __restrict__ coef,
                                                         double* __restrict__ d_new, double* __restrict__ z,
                                                         double* __restrict__ res, const double* __restrict__ r,
-                                                        const double* __restrict__ w, double* __restrict__ rz_part) {
+                                                        const double* __restrict__ w, double* __restrict__ rz_part,
+                                                        int tiled) {
+  const double c1 = coef[0], c2 = coef[1];  // device-resident: the launch sequence is replayed as a hipGraph
   __shared__ double sh[32];
   const int l32 = threadIdx.x & 31, hw = threadIdx.x >> 5;
   const int rows_per_block = (N + gridDim.x - 1) / gridDim.x;
-  const int r0 = blockIdx.x * rows_per_block;
-  const int r1 = min(N, r0 + rows_per_block);
+  const int r0 = tiled ? blockIdx.x * 32 : blockIdx.x * rows_per_block;
+  const int r1 = tiled ? N : min(N, r0 + rows_per_block);
+  const int stride = tiled ? gridDim.x * 32 : 32;
   double rz = 0.0;
-  for (int i = r0 + hw; i < r1; i += 32) {
+  for (int i = r0 + hw; i < r1; i += stride) {
     const int off0 = inc.off[i], deg = inc.off[i + 1] - off0, row = 3 * deg;
     const double* Hi = Hval + (size_t)9 * off0;
     double s0 = 0.0, s1 = 0.0, s2 = 0.0;
@@ -452,25 +469,462 @@ __global__ __launch_bounds__(1024) void cheb_step_kernel(int N, Incidence inc, c
 }
 
 void launch_cheb_step(hipStream_t s, int N, const Incidence& inc, const double* Hval, const double* Dinv,
-                      const double* d_old, double c1, double c2, double* d_new, double* z, double* res,
+                      const double* d_old, const double* coef, double* d_new, double* z, double* res,
                       const double* r, const double* w, double* rz_part, bool last) {
   const dim3 g(spmv_grid(N)), b(1024);
   if (last)
-    hipLaunchKernelGGL((cheb_step_kernel<true>), g, b, 0, s, N, inc, Hval, Dinv, d_old, c1, c2, d_new, z, res, r, w,
-                       rz_part);
+    hipLaunchKernelGGL((cheb_step_kernel<true>), g, b, 0, s, N, inc, Hval, Dinv, d_old, coef, d_new, z, res, r, w,
+                       rz_part, row_map_tiled() ? 1 : 0);
   else
-    hipLaunchKernelGGL((cheb_step_kernel<false>), g, b, 0, s, N, inc, Hval, Dinv, d_old, c1, c2, d_new, z, res, r, w,
-                       rz_part);
+    hipLaunchKernelGGL((cheb_step_kernel<false>), g, b, 0, s, N, inc, Hval, Dinv, d_old, coef, d_new, z, res, r, w,
+                       rz_part, row_map_tiled() ? 1 : 0);
+}
+
+// ---- low-precision copy of H for the polynomial preconditioner -----------------------------------------
+// The preconditioner only has to be a FIXED SPD operator close to H^-1, so its matrix need not be fp64: the
+// Chebyshev steps stream a symmetrically scaled copy  Hs = S H S,  S = diag(H)^-1/2  (|entries| <= 1, unit
+// diagonal) stored in fp16 or fp32 -- 1/4 or 1/2 of the bytes of the dominant kernel; rounding is symmetric, so
+// the polynomial stays symmetric, and p(lambda) > 0 on the whole real axis keeps it positive definite.  CG on the
+// fp64 H around it still converges to the fp64 answer (measured: same iteration counts as the fp64 polynomial).
+// The copy is block-CSR: per (row node, column node) the 3x3 block row-major, first 8 entries in one aligned
+// 16/32-byte record and the 9th in a side array, so ONE lane streams one block with two loads and gathers its
+// three vector entries; the steps work in the scaled space (d^ = S^-1 d, res^ = S res) and the last one returns
+// z = S z^.
+template <typename HT>
+struct alignas(8 * sizeof(HT)) Blk8 {
+  HT v[8];
+};
+
+// sc = diag(D)^-1/2 per DOF;  Dinv_s = (S D S)^-1 = Dinv / (sc sc^T)
+__global__ void lp_scale_kernel(int N, const double* __restrict__ D, const double* __restrict__ Dinv,
+                                double* __restrict__ sc, double* __restrict__ Dinv_s) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  double s[3];
+#pragma unroll
+  for (int c = 0; c < 3; c++) {
+    const double dd = D[(size_t)9 * i + 4 * c];
+    s[c] = dd > 0.0 ? 1.0 / sqrt(dd) : 1.0;
+    sc[3 * i + c] = s[c];
+  }
+#pragma unroll
+  for (int c = 0; c < 3; c++)
+#pragma unroll
+    for (int e = 0; e < 3; e++) Dinv_s[(size_t)9 * i + 3 * c + e] = Dinv[(size_t)9 * i + 3 * c + e] / (s[c] * s[e]);
+}
+
+void launch_lp_scale(hipStream_t s, int N, const double* D, const double* Dinv, double* sc, double* Dinv_s) {
+  hipLaunchKernelGGL(lp_scale_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, D, Dinv, sc, Dinv_s);
+}
+
+template <typename HT>
+__global__ __launch_bounds__(256) void lp_convert_kernel(int N, Incidence inc, const double* __restrict__ Hval,
+                                                        const double* __restrict__ sc, Blk8<HT>* __restrict__ B8,
+                                                        HT* __restrict__ B1) {
+  const int l32 = threadIdx.x & 31;
+  const int i = blockIdx.x * 8 + (threadIdx.x >> 5);  // 8 node rows per workgroup, 32 lanes per row
+  if (i >= N) return;
+  const int off0 = inc.off[i], deg = inc.off[i + 1] - off0, row = 3 * deg;
+  const double* Hi = Hval + (size_t)9 * off0;
+  const double si[3] = {sc[3 * i], sc[3 * i + 1], sc[3 * i + 2]};
+  for (int k = l32; k < deg; k += 32) {
+    const int c = inc.cols[off0 + k];
+    const double sj[3] = {sc[3 * c], sc[3 * c + 1], sc[3 * c + 2]};
+    Blk8<HT> b;
+    HT last = (HT)0;
+#pragma unroll
+    for (int d = 0; d < 3; d++)
+#pragma unroll
+      for (int e = 0; e < 3; e++) {
+        const HT v = (HT)(Hi[(size_t)d * row + 3 * k + e] * si[d] * sj[e]);
+        if (3 * d + e < 8) b.v[3 * d + e] = v;
+        else last = v;
+      }
+    B8[off0 + k] = b;
+    B1[off0 + k] = last;
+  }
+}
+
+void launch_lp_convert(hipStream_t s, int N, const Incidence& inc, const double* Hval, const double* sc, void* B8,
+                       void* B1, int bits) {
+  const dim3 g((N + 7) / 8), b(256);
+  if (bits == 16)
+    hipLaunchKernelGGL((lp_convert_kernel<_Float16>), g, b, 0, s, N, inc, Hval, sc, (Blk8<_Float16>*)B8, (_Float16*)B1);
+  else
+    hipLaunchKernelGGL((lp_convert_kernel<float>), g, b, 0, s, N, inc, Hval, sc, (Blk8<float>*)B8, (float*)B1);
+}
+
+// MODE 0: Chebyshev step (as cheb_step_kernel, scaled space); MODE 1: last step (returns z = S z^ and the r.z
+// slots); MODE 2: q = Hs d only (multi-GPU path: q is summed over ranks before the vector update).
+// L lanes walk the column nodes of one node row, two blocks per lane per round.  The kernel is bound by memory
+// latency, not issue: a row is a chain  offsets -> columns/blocks -> gathered vector entries -> reduction ->
+// epilogue operands -> stores.  So everything of the NEXT row that does not depend on data of this one (its
+// offsets, the first round of columns and blocks, the epilogue operands res / D^-1 / d / z) is requested while this
+// row's gathers are in flight, and the only exposed latency per row is the gather itself.
+template <typename HT>
+struct LpRound {  // one lane's share of a round: two blocks (8+1 entries each) and their column nodes
+  Blk8<HT> a, b;
+  HT a8, b8;
+  int ca, cb;
+};
+struct LpEpilogue {  // what lanes 0..2 of a group need to finish component c of their row
+  double e0, e1, e2, D0, D1, D2, dc, zc, sc, rc, wc;
+};
+
+template <typename HT, int L>
+__device__ __forceinline__ void lp_load_round(LpRound<HT>& R, const Incidence& inc, const Blk8<HT>* __restrict__ B8,
+                                              const HT* __restrict__ B1, int base, int deg, int k) {
+  // lanes past the end of the row read its first block (always there: the diagonal) and are masked by the caller
+  const int ga = base + (k < deg ? k : 0), gb = base + (k + L < deg ? k + L : 0);
+  R.ca = inc.cols[ga];
+  R.cb = inc.cols[gb];
+  R.a = B8[ga];
+  R.b = B8[gb];
+  R.a8 = B1[ga];
+  R.b8 = B1[gb];
+}
+
+template <int MODE>
+__device__ __forceinline__ void lp_load_epilogue(LpEpilogue& E, int i, int c, const double* __restrict__ Dinv_s,
+                                                 const double* __restrict__ sc, const double* __restrict__ d_old,
+                                                 const double* __restrict__ z, const double* __restrict__ res,
+                                                 const double* __restrict__ r, const double* __restrict__ w) {
+  if (MODE == 2) return;
+  E.e0 = res[3 * i];
+  E.e1 = res[3 * i + 1];
+  E.e2 = res[3 * i + 2];
+  const double* D = Dinv_s + (size_t)9 * i + 3 * c;
+  E.D0 = D[0];
+  E.D1 = D[1];
+  E.D2 = D[2];
+  E.dc = d_old[3 * i + c];
+  E.zc = z[3 * i + c];
+  if (MODE == 1) {
+    E.sc = sc[3 * i + c];
+    E.rc = r[3 * i + c];
+    E.wc = w ? w[3 * i + c] : 1.0;
+  }
+}
+
+template <typename HT>
+__device__ __forceinline__ void lp_fma_round(const LpRound<HT>& R, const double (&x)[3], const double (&y)[3],
+                                             double& s0, double& s1, double& s2) {
+  s0 += (double)R.a.v[0] * x[0] + (double)R.a.v[1] * x[1] + (double)R.a.v[2] * x[2];
+  s1 += (double)R.a.v[3] * x[0] + (double)R.a.v[4] * x[1] + (double)R.a.v[5] * x[2];
+  s2 += (double)R.a.v[6] * x[0] + (double)R.a.v[7] * x[1] + (double)R.a8 * x[2];
+  s0 += (double)R.b.v[0] * y[0] + (double)R.b.v[1] * y[1] + (double)R.b.v[2] * y[2];
+  s1 += (double)R.b.v[3] * y[0] + (double)R.b.v[4] * y[1] + (double)R.b.v[5] * y[2];
+  s2 += (double)R.b.v[6] * y[0] + (double)R.b.v[7] * y[1] + (double)R.b8 * y[2];
+}
+
+// TILED: the workgroups sweep the rows together, G rows (one per lane group) at a time in round-robin order, instead
+// of each owning one contiguous chunk: at any moment the whole chip then gathers from a narrow window of the vector
+// (a few mesh planes) that stays in every XCD's L2, whereas 64 resident chunks per XCD spread over the whole vector
+// do not fit (4 MiB) once the mesh is large.
+template <typename HT, int L, int MODE, bool TILED>
+__global__ __launch_bounds__(1024) void cheb_lp_kernel(int N, Incidence inc, const Blk8<HT>* __restrict__ B8,
+                                                      const HT* __restrict__ B1, const double* __restrict__ Dinv_s,
+                                                      const double* __restrict__ sc,
+                                                      const double* __restrict__ d_old, const double* __restrict__ coef,
+                                                      double* __restrict__ d_new, const double* __restrict__ z,
+                                                      double* __restrict__ z_new, const double* __restrict__ res,
+                                                      double* __restrict__ res_new, const double* __restrict__ r,
+                                                      const double* __restrict__ w, double* __restrict__ out) {
+  const double c1 = coef[0], c2 = coef[1];  // device-resident: the launch sequence is replayed as a hipGraph
+  __shared__ double sh[32];
+  constexpr int G = 1024 / L;
+  const int lane = threadIdx.x & (L - 1), grp = threadIdx.x / L;
+  const int c = lane < 3 ? lane : 0;
+  int i, r1, stride;
+  if (TILED) {
+    i = blockIdx.x * G + grp;
+    r1 = N;
+    stride = gridDim.x * G;
+  } else {
+    const int rows_per_block = (N + gridDim.x - 1) / gridDim.x;
+    const int r0 = blockIdx.x * rows_per_block;
+    i = r0 + grp;
+    r1 = min(N, r0 + rows_per_block);
+    stride = G;
+  }
+  double rz = 0.0;
+  for (; i < r1; i += stride) {
+    const int base = inc.off[i], deg = inc.off[i + 1] - base;
+    // operands lanes 0..2 need to finish the row: requested first, back before the reduction is done
+    LpEpilogue E;
+    if (lane < 3) lp_load_epilogue<MODE>(E, i, c, Dinv_s, sc, d_old, z, res, r, w);
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+    for (int k = lane; k < deg; k += 2 * L) {
+      LpRound<HT> T;
+      lp_load_round<HT, L>(T, inc, B8, B1, base, deg, k);
+      const double mb = k + L < deg ? 1.0 : 0.0;
+      const double* xa = d_old + 3 * (size_t)T.ca;
+      const double* xb = d_old + 3 * (size_t)T.cb;
+      const double xx[3] = {xa[0], xa[1], xa[2]};
+      const double yy[3] = {mb * xb[0], mb * xb[1], mb * xb[2]};
+      lp_fma_round<HT>(T, xx, yy, s0, s1, s2);
+    }
+#pragma unroll
+    for (int o = L / 2; o > 0; o >>= 1) {
+      s0 += __shfl_xor(s0, o);
+      s1 += __shfl_xor(s1, o);
+      s2 += __shfl_xor(s2, o);
+    }
+    if (lane < 3) {
+      if (MODE == 2) {
+        out[3 * i + c] = (c == 0) ? s0 : ((c == 1) ? s1 : s2);
+      } else {
+        const double e0 = E.e0 - s0, e1 = E.e1 - s1, e2 = E.e2 - s2;
+        const double zc = E.D0 * e0 + E.D1 * e1 + E.D2 * e2;
+        const double dn = c1 * E.dc + c2 * zc;
+        const double zn = E.zc + dn;
+        d_new[3 * i + c] = dn;
+        if (MODE == 1) {
+          const double zt = E.sc * zn;
+          z_new[3 * i + c] = zt;
+          rz += E.wc * E.rc * zt;
+        } else {
+          z_new[3 * i + c] = zn;
+          res_new[3 * i + c] = (c == 0) ? e0 : ((c == 1) ? e1 : e2);
+        }
+      }
+    }
+  }
+  if (MODE == 1) {
+    const double t = block_sum(rz, sh);
+    if (threadIdx.x == 0) out[blockIdx.x] = t;
+    if (blockIdx.x == 0)
+      for (int k = gridDim.x + threadIdx.x; k < kNPart; k += blockDim.x) out[k] = 0.0;
+  }
+}
+
+bool row_map_tiled() {
+  static const bool t = std::getenv("TLFEA_ROW_TILED") ? std::atoi(std::getenv("TLFEA_ROW_TILED")) != 0 : true;
+  return t;
+}
+
+int lp_lanes(int N, int nnz_coef) {
+  static const int forced = std::getenv("TLFEA_LP_LANES") ? std::atoi(std::getenv("TLFEA_LP_LANES")) : 0;
+  if (forced == 8 || forced == 16 || forced == 32) return forced;
+  const double avg = (double)nnz_coef / std::max(1, N);
+  return avg > 48.0 ? 32 : 16;
+}
+
+void launch_cheb_lp(hipStream_t s, int N, int nnz_coef, const Incidence& inc, const void* B8, const void* B1, int bits,
+                    const double* Dinv_s, const double* sc, const double* d_old, const double* coef, double* d_new,
+                    const double* z, double* z_new, const double* res, double* res_new, const double* r,
+                    const double* w, double* out, int mode) {
+  const int L = lp_lanes(N, nnz_coef);
+  const dim3 g(std::max(1, std::min(kNPart, (N + 1024 / L - 1) / (1024 / L)))), b(1024);
+  const bool tiled = row_map_tiled();
+#define TLFEA_LP(T, LL, M)                                                                                           \
+  do {                                                                                                               \
+    if (tiled)                                                                                                       \
+      hipLaunchKernelGGL((cheb_lp_kernel<T, LL, M, true>), g, b, 0, s, N, inc, (const Blk8<T>*)B8, (const T*)B1,      \
+                         Dinv_s, sc, d_old, coef, d_new, z, z_new, res, res_new, r, w, out);                       \
+    else                                                                                                             \
+      hipLaunchKernelGGL((cheb_lp_kernel<T, LL, M, false>), g, b, 0, s, N, inc, (const Blk8<T>*)B8, (const T*)B1,     \
+                         Dinv_s, sc, d_old, coef, d_new, z, z_new, res, res_new, r, w, out);                       \
+  } while (0)
+#define TLFEA_LP_M(T, LL)                     \
+  do {                                        \
+    if (mode == 0) TLFEA_LP(T, LL, 0);        \
+    else if (mode == 1) TLFEA_LP(T, LL, 1);   \
+    else TLFEA_LP(T, LL, 2);                  \
+  } while (0)
+#define TLFEA_LP_L(T)                         \
+  do {                                        \
+    if (L == 8) TLFEA_LP_M(T, 8);             \
+    else if (L == 16) TLFEA_LP_M(T, 16);      \
+    else TLFEA_LP_M(T, 32);                   \
+  } while (0)
+  if (bits == 16) TLFEA_LP_L(_Float16);
+  else TLFEA_LP_L(float);
+#undef TLFEA_LP_L
+#undef TLFEA_LP_M
+#undef TLFEA_LP
+}
+
+// ---- the polynomial in single precision (single-GPU path) -------------------------------------------------
+// Inside the preconditioner nothing needs fp64: the Chebyshev recurrence only reduces its residual by ~10x, so fp32
+// vectors (d, res, z), an fp32 block-Jacobi factor and fp32 accumulation of the fp16/fp32 matrix entries change
+// z by ~1e-6 relative -- CG treats that as a slightly inexact preconditioner (measured: same iteration counts, same
+// attained true residual; the CG recurrences on H stay fp64).  It halves the gather bytes, the vector traffic and the
+// registers per block in flight (more wavefronts per SIMD on a kernel that is bound by memory latency x occupancy).
+//   init:   res^ = S r ; d = (SDS)^-1 res^ / theta ; z^ = d                         (fp64 r in, fp32 out)
+//   step k: res^ -= Hs d ; d' = c1 d + c2 (SDS)^-1 res^ ; z^ += d'
+//   last:   as a step, then z = S z^ (fp64 out) and the r.z slots
+__global__ __launch_bounds__(256) void cheb32_init_kernel(int N, const float* __restrict__ Dinv_f,
+                                                         const double* __restrict__ r, const double* __restrict__ sc,
+                                                         const double* __restrict__ coef, float* __restrict__ d,
+                                                         float* __restrict__ z, float* __restrict__ res) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= N) return;
+  const float inv_theta = (float)coef[0];
+  const float r0 = (float)(r[3 * i] * sc[3 * i]), r1 = (float)(r[3 * i + 1] * sc[3 * i + 1]),
+              r2 = (float)(r[3 * i + 2] * sc[3 * i + 2]);
+  const float* D = Dinv_f + (size_t)9 * i;
+#pragma unroll
+  for (int c = 0; c < 3; c++) {
+    const float v = (D[3 * c] * r0 + D[3 * c + 1] * r1 + D[3 * c + 2] * r2) * inv_theta;
+    d[3 * i + c] = v;
+    z[3 * i + c] = v;
+  }
+  res[3 * i] = r0;
+  res[3 * i + 1] = r1;
+  res[3 * i + 2] = r2;
+}
+
+void launch_cheb32_init(hipStream_t s, int N, const float* Dinv_f, const double* r, const double* sc,
+                        const double* coef, float* d, float* z, float* res) {
+  hipLaunchKernelGGL(cheb32_init_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, Dinv_f, r, sc, coef, d, z, res);
+}
+
+// Dinv_f = float((S D S)^-1)
+__global__ void to_float_kernel(size_t n, const double* __restrict__ a, float* __restrict__ b) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    b[i] = (float)a[i];
+}
+void launch_to_float(hipStream_t s, size_t n, const double* a, float* b) {
+  hipLaunchKernelGGL(to_float_kernel, dim3((unsigned)std::min<size_t>(4096, (n + 255) / 256)), dim3(256), 0, s, n, a, b);
+}
+
+template <typename HT, int L, bool LAST, bool TILED>
+__global__ __launch_bounds__(1024) void cheb32_kernel(int N, Incidence inc, const Blk8<HT>* __restrict__ B8,
+                                                     const HT* __restrict__ B1, const float* __restrict__ Dinv_f,
+                                                     const double* __restrict__ sc, const float* __restrict__ d_old,
+                                                     const double* __restrict__ coef, float* __restrict__ d_new,
+                                                     const float* __restrict__ z, float* __restrict__ z_new,
+                                                     const float* __restrict__ res, float* __restrict__ res_new,
+                                                     const double* __restrict__ r, double* __restrict__ z_out,
+                                                     double* __restrict__ rz_part) {
+  __shared__ double sh[32];
+  const float c1 = (float)coef[0], c2 = (float)coef[1];
+  constexpr int G = 1024 / L;
+  const int lane = threadIdx.x & (L - 1), grp = threadIdx.x / L;
+  const int c = lane < 3 ? lane : 0;
+  int i, r1, stride;
+  if (TILED) {  // see cheb_lp_kernel
+    i = blockIdx.x * G + grp;
+    r1 = N;
+    stride = gridDim.x * G;
+  } else {
+    const int rows_per_block = (N + gridDim.x - 1) / gridDim.x;
+    const int r0 = blockIdx.x * rows_per_block;
+    i = r0 + grp;
+    r1 = min(N, r0 + rows_per_block);
+    stride = G;
+  }
+  double rz = 0.0;
+  for (; i < r1; i += stride) {
+    const int base = inc.off[i], deg = inc.off[i + 1] - base;
+    // operands lanes 0..2 need to finish component c of the row: requested first, back before the reduction is done
+    float e0 = 0.f, e1 = 0.f, e2 = 0.f, D0 = 0.f, D1 = 0.f, D2 = 0.f, dc = 0.f, zc = 0.f;
+    if (lane < 3) {
+      e0 = res[3 * i];
+      e1 = res[3 * i + 1];
+      e2 = res[3 * i + 2];
+      const float* D = Dinv_f + (size_t)9 * i + 3 * c;
+      D0 = D[0];
+      D1 = D[1];
+      D2 = D[2];
+      dc = d_old[3 * i + c];
+      zc = z[3 * i + c];
+    }
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    for (int k = lane; k < deg; k += 2 * L) {
+      // lanes past the end of the row read its first block and are masked
+      const int ga = base + k, gb = base + (k + L < deg ? k + L : 0);
+      const float mb = k + L < deg ? 1.f : 0.f;
+      const int ca = inc.cols[ga], cb = inc.cols[gb];
+      const Blk8<HT> a = B8[ga], b = B8[gb];
+      const HT a8 = B1[ga], b8 = B1[gb];
+      const float* xa = d_old + 3 * (size_t)ca;
+      const float* xb = d_old + 3 * (size_t)cb;
+      const float x0 = xa[0], x1 = xa[1], x2 = xa[2];
+      const float y0 = mb * xb[0], y1 = mb * xb[1], y2 = mb * xb[2];
+      s0 += (float)a.v[0] * x0 + (float)a.v[1] * x1 + (float)a.v[2] * x2;
+      s1 += (float)a.v[3] * x0 + (float)a.v[4] * x1 + (float)a.v[5] * x2;
+      s2 += (float)a.v[6] * x0 + (float)a.v[7] * x1 + (float)a8 * x2;
+      s0 += (float)b.v[0] * y0 + (float)b.v[1] * y1 + (float)b.v[2] * y2;
+      s1 += (float)b.v[3] * y0 + (float)b.v[4] * y1 + (float)b.v[5] * y2;
+      s2 += (float)b.v[6] * y0 + (float)b.v[7] * y1 + (float)b8 * y2;
+    }
+#pragma unroll
+    for (int o = L / 2; o > 0; o >>= 1) {
+      s0 += __shfl_xor(s0, o);
+      s1 += __shfl_xor(s1, o);
+      s2 += __shfl_xor(s2, o);
+    }
+    if (lane < 3) {
+      e0 -= s0;
+      e1 -= s1;
+      e2 -= s2;
+      const float dn = c1 * dc + c2 * (D0 * e0 + D1 * e1 + D2 * e2);
+      const float zn = zc + dn;
+      d_new[3 * i + c] = dn;
+      if (LAST) {
+        const double zt = sc[3 * i + c] * (double)zn;
+        z_out[3 * i + c] = zt;
+        rz += r[3 * i + c] * zt;
+      } else {
+        z_new[3 * i + c] = zn;
+        res_new[3 * i + c] = (c == 0) ? e0 : ((c == 1) ? e1 : e2);
+      }
+    }
+  }
+  if (LAST) {
+    const double t = block_sum(rz, sh);
+    if (threadIdx.x == 0) rz_part[blockIdx.x] = t;
+    if (blockIdx.x == 0)
+      for (int k = gridDim.x + threadIdx.x; k < kNPart; k += blockDim.x) rz_part[k] = 0.0;
+  }
+}
+
+void launch_cheb32(hipStream_t s, int N, int nnz_coef, const Incidence& inc, const void* B8, const void* B1, int bits,
+                   const float* Dinv_f, const double* sc, const float* d_old, const double* coef, float* d_new,
+                   const float* z, float* z_new, const float* res, float* res_new, const double* r, double* z_out,
+                   double* rz_part, bool last) {
+  const int L = lp_lanes(N, nnz_coef);
+  const dim3 g(std::max(1, std::min(kNPart, (N + 1024 / L - 1) / (1024 / L)))), b(1024);
+  const bool tiled = row_map_tiled();
+#define TLFEA_C32(T, LL, LA, TI)                                                                                    \
+  hipLaunchKernelGGL((cheb32_kernel<T, LL, LA, TI>), g, b, 0, s, N, inc, (const Blk8<T>*)B8, (const T*)B1, Dinv_f, sc, \
+                     d_old, coef, d_new, z, z_new, res, res_new, r, z_out, rz_part)
+#define TLFEA_C32_T(T, LL, LA)             \
+  do {                                     \
+    if (tiled) TLFEA_C32(T, LL, LA, true); \
+    else TLFEA_C32(T, LL, LA, false);      \
+  } while (0)
+#define TLFEA_C32_LA(T, LL)                \
+  do {                                     \
+    if (last) TLFEA_C32_T(T, LL, true);    \
+    else TLFEA_C32_T(T, LL, false);        \
+  } while (0)
+#define TLFEA_C32_L(T)                     \
+  do {                                     \
+    if (L == 8) TLFEA_C32_LA(T, 8);        \
+    else if (L == 16) TLFEA_C32_LA(T, 16); \
+    else TLFEA_C32_LA(T, 32);              \
+  } while (0)
+  if (bits == 16) TLFEA_C32_L(_Float16);
+  else TLFEA_C32_L(float);
+#undef TLFEA_C32_L
+#undef TLFEA_C32_LA
+#undef TLFEA_C32_T
+#undef TLFEA_C32
 }
 
 // the same step with the SpMV result q = H d_old already summed over ranks (multi-GPU path)
 template <bool LAST>
 __global__ __launch_bounds__(256) void cheb_update_kernel(int N, const double* __restrict__ Dinv,
                                                          const double* __restrict__ q,
-                                                         const double* __restrict__ d_old, double c1, double c2,
+                                                         const double* __restrict__ d_old, const double* __restrict__ coef,
                                                          double* __restrict__ d_new, double* __restrict__ z,
                                                          double* __restrict__ res, const double* __restrict__ r,
-                                                         const double* __restrict__ w, double* __restrict__ rz_part) {
+                                                         const double* __restrict__ w, const double* __restrict__ sc,
+                                                         double* __restrict__ rz_part) {
+  const double c1 = coef[0], c2 = coef[1];  // device-resident: the launch sequence is replayed as a hipGraph
   __shared__ double sh[32];
   double rz = 0.0;
   for (int i = blockIdx.x * 256 + threadIdx.x; i < N; i += gridDim.x * 256) {
@@ -483,8 +937,9 @@ __global__ __launch_bounds__(256) void cheb_update_kernel(int N, const double* _
     for (int c = 0; c < 3; c++) {
       const double zc = D[3 * c] * e0 + D[3 * c + 1] * e1 + D[3 * c + 2] * e2;
       const double dn = c1 * d_old[3 * i + c] + c2 * zc;
-      const double zn = z[3 * i + c] + dn;
+      double zn = z[3 * i + c] + dn;
       d_new[3 * i + c] = dn;
+      if (LAST && sc) zn *= sc[3 * i + c];  // low-precision path: back from the scaled space
       z[3 * i + c] = zn;
       if (LAST) rz += (w ? w[3 * i + c] : 1.0) * r[3 * i + c] * zn;
     }
@@ -497,14 +952,16 @@ __global__ __launch_bounds__(256) void cheb_update_kernel(int N, const double* _
   }
 }
 
-void launch_cheb_update(hipStream_t s, int N, const double* Dinv, const double* q, const double* d_old, double c1,
-                        double c2, double* d_new, double* z, double* res, const double* r, const double* w,
-                        double* rz_part, bool last) {
+void launch_cheb_update(hipStream_t s, int N, const double* Dinv, const double* q, const double* d_old,
+                        const double* coef, double* d_new, double* z, double* res, const double* r, const double* w,
+                        const double* sc, double* rz_part, bool last) {
   const dim3 g(std::max(1, std::min(kNPart, (N + 255) / 256))), b(256);
   if (last)
-    hipLaunchKernelGGL((cheb_update_kernel<true>), g, b, 0, s, N, Dinv, q, d_old, c1, c2, d_new, z, res, r, w, rz_part);
+    hipLaunchKernelGGL((cheb_update_kernel<true>), g, b, 0, s, N, Dinv, q, d_old, coef, d_new, z, res, r, w, sc,
+                       rz_part);
   else
-    hipLaunchKernelGGL((cheb_update_kernel<false>), g, b, 0, s, N, Dinv, q, d_old, c1, c2, d_new, z, res, r, w, rz_part);
+    hipLaunchKernelGGL((cheb_update_kernel<false>), g, b, 0, s, N, Dinv, q, d_old, coef, d_new, z, res, r, w, sc,
+                       rz_part);
 }
 
 // x += alpha p ; r -= alpha q ; partial r.r  (z comes from the polynomial preconditioner afterwards)
@@ -512,11 +969,15 @@ __global__ __launch_bounds__(256) void pcg_update_noz_kernel(int N, const double
                                                             const double* __restrict__ p, const double* __restrict__ q,
                                                             const double* __restrict__ rz_part_old,
                                                             const double* __restrict__ pq_part, double* __restrict__ x,
-                                                            double* __restrict__ r, double* __restrict__ rr_part) {
+                                                            double* __restrict__ r, double* __restrict__ rr_part,
+                                                            double* __restrict__ indefinite) {
   __shared__ double sh[32];
   double rz_old, pq;
   sum_slots2(rz_part_old, pq_part, rz_old, pq, sh);
-  const double alpha = rz_old / pq;
+  const double alpha = pq != 0.0 ? rz_old / pq : 0.0;
+  // r.z < 0 means the polynomial preconditioner is not positive definite (its interval ends below lambda_max):
+  // sticky flag for the host's next convergence test
+  if (blockIdx.x == 0 && threadIdx.x == 0 && rz_old < 0.0) indefinite[0] = 1.0;
   double rr = 0.0;
   for (int i = blockIdx.x * 256 + threadIdx.x; i < 3 * N; i += gridDim.x * 256) {
     x[i] += alpha * p[i];
@@ -531,10 +992,11 @@ __global__ __launch_bounds__(256) void pcg_update_noz_kernel(int N, const double
 }
 
 void launch_pcg_update_noz(hipStream_t s, int N, const double* w, const double* p, const double* q,
-                           const double* rz_part_old, const double* pq_part, double* x, double* r, double* rr_part) {
+                           const double* rz_part_old, const double* pq_part, double* x, double* r, double* rr_part,
+                           double* indefinite) {
   const int n_blocks = std::max(1, std::min(kNPart, (3 * N + 255) / 256));
   hipLaunchKernelGGL(pcg_update_noz_kernel, dim3(n_blocks), dim3(256), 0, s, N, w, p, q, rz_part_old, pq_part, x, r,
-                     rr_part);
+                     rr_part, indefinite);
 }
 
 // v <- D^-1 q (power iteration for lambda_max of D^-1 H)
@@ -554,6 +1016,15 @@ void launch_apply_dinv(hipStream_t s, int N, const double* Dinv, const double* q
 __global__ void scale_kernel(int n, double a, double* __restrict__ v) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) v[i] *= a;
+}
+// v *= 1/sqrt(*sumsq) with the scalar on the device (power iteration without host round trips)
+__global__ void scale_inv_sqrt_kernel(int n, const double* __restrict__ sumsq, double* __restrict__ v) {
+  const double ss = sumsq[0];
+  const double a = ss > 0.0 ? 1.0 / sqrt(ss) : 0.0;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) v[i] *= a;
+}
+void launch_scale_inv_sqrt(hipStream_t s, int n, const double* sumsq, double* v) {
+  hipLaunchKernelGGL(scale_inv_sqrt_kernel, dim3(std::min(2048, (n + 255) / 256)), dim3(256), 0, s, n, sumsq, v);
 }
 void launch_scale(hipStream_t s, int n, double a, double* v) {
   hipLaunchKernelGGL(scale_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, a, v);

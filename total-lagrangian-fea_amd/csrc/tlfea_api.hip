@@ -677,13 +677,24 @@ struct tlfea_newton_s {
   int N = 0, n_constraints = 0;
   int n_constraints_global = 0;  // over all ranks (control flow must be identical on every rank)
   tlfea_newton_params prm{1e-4, 1e-4, 1e-4, 1e14, 5, 10, 1e-3};
-  tlfea_linsolve_opts lin{1e-12, 20000, 25, 0, 400.0};
+  tlfea_linsolve_opts lin{1e-12, 20000, 25, 0, 0.0, 0};
   double lam_max = 0.0;       // estimate of lambda_max(D^-1 H) (power iteration, warm-started across solves)
+  double lam_safety = 1.15;   // the polynomial's interval ends at lam_safety * lam_max (power iteration converges from below)
   double* d_eigv = nullptr;   // its vector
   double *d_cd = nullptr, *d_cd2 = nullptr, *d_cres = nullptr;  // Chebyshev work vectors
+  // low-precision scaled copy of H streamed by the Chebyshev steps (lin.cheb_bits 16/32): 8+1 entries per block
+  void *d_B8 = nullptr, *d_B1 = nullptr;
+  int lp_bits_alloc = 0;
+  double *d_sc = nullptr, *d_Dinv_s = nullptr;
+  double *d_cz = nullptr, *d_cz2 = nullptr, *d_cres2 = nullptr;  // ping-pong partners of z / res in the LP steps
+  float* d_f32 = nullptr;  // single-precision polynomial (single GPU): d, z, res ping-pong pairs (6 x 3N) + (SDS)^-1 (9N)
   bool fixed_pattern = false, sparsity_done = false;
   int verbose = 0;
-  hipStream_t stream = nullptr;
+  // Launch stream.  Single GPU: an own (blocking) stream, so that the CG iteration can be captured as a hipGraph
+  // (the legacy default stream cannot be captured; a blocking stream still orders against the data object's
+  // default-stream copies and kernels).  With a multi-GPU interface set: the default stream, the one the host's
+  // collective (torch.distributed) orders against.
+  hipStream_t stream = nullptr, stream_own = nullptr;
   double *d_v = nullptr, *d_vprev = nullptr, *d_lam = nullptr, *d_g = nullptr, *d_dv = nullptr, *d_r = nullptr,
          *d_b = nullptr;
   bool profiling = false;
@@ -694,6 +705,13 @@ struct tlfea_newton_s {
   double *d_p = nullptr, *d_p2 = nullptr, *d_q = nullptr, *d_zv = nullptr;
   double* d_parts = nullptr;  // 6 x kNPart: rz[2], pq, rr, bb, norm
   double* d_scal = nullptr;   // 4 scalars
+  double* h_pin = nullptr;    // pinned host words: [0..7] scalars read back, [8..] Chebyshev coefficients to upload
+  double* d_coef = nullptr;   // Chebyshev coefficients on the device (2 per step)
+  hipGraphExec_t cg_graph[2] = {nullptr, nullptr};  // CG iteration of even / odd parity
+  long cg_graph_key[6] = {0, 0, 0, 0, 0, 0};
+  bool use_graphs = true;     // TLFEA_GRAPH=0 launches every kernel eagerly
+  int last_outer_iters = 0;   // CG iterations of the previous solve: where the next one starts testing convergence
+  int last_deg = 0, last_bits = 0;
   int h_nnz = 0;
   std::vector<int> h_row_offsets, h_col_indices;  // reference DOF-level CSR index arrays (host)
   double stats[6] = {0, 0, 0, 0, 0, 0};
@@ -724,23 +742,38 @@ extern "C" int tlfea_newton_create(tlfea_t10_t data, int n_constraints, tlfea_ne
   TRY(dmalloc(&s->d_xp, (size_t)s->N)); TRY(dmalloc(&s->d_yp, (size_t)s->N)); TRY(dmalloc(&s->d_zp, (size_t)s->N));
   TRY(dmalloc(&s->d_parts, (size_t)6 * kNPart));
   TRY(dmalloc(&s->d_scal, (size_t)4));
+  HIP_TRY(hipHostMalloc((void**)&s->h_pin, (8 + 2 * 64) * sizeof(double)));
+  TRY(dmalloc(&s->d_coef, (size_t)2 * 64));
+  if (const char* e = std::getenv("TLFEA_GRAPH")) s->use_graphs = std::atoi(e) != 0;
   TRY(dmalloc(&s->d_Dinv, (size_t)9 * s->N));
+  TRY(dmalloc(&s->d_D, (size_t)9 * s->N));
+  TRY(dmalloc(&s->d_f32, (size_t)6 * n + (size_t)9 * s->N));
+  TRY(dmalloc(&s->d_sc, n)); TRY(dmalloc(&s->d_cz, n)); TRY(dmalloc(&s->d_cz2, n)); TRY(dmalloc(&s->d_cres2, n));
+  TRY(dmalloc(&s->d_Dinv_s, (size_t)9 * s->N));
   for (auto& e : s->ev) HIP_TRY(hipEventCreate(&e));
+  HIP_TRY(hipStreamCreate(&s->stream_own));
+  s->stream = s->stream_own;
   if (const char* e = std::getenv("TLFEA_PCG_FUSED")) s->pcg_fused = std::atoi(e);
-  if (const char* e = std::getenv("TLFEA_CHEB_DEG")) s->lin.cheb_degree = std::max(0, std::atoi(e));
+  if (const char* e = std::getenv("TLFEA_CHEB_DEG")) s->lin.cheb_degree = std::min(64, std::max(0, std::atoi(e)));
   if (const char* e = std::getenv("TLFEA_SPMV_NT")) s->spmv_nt = std::atoi(e) != 0;
+  if (const char* e = std::getenv("TLFEA_CHEB_BITS")) s->lin.cheb_bits = std::atoi(e);
   *out = s;
   return tlfea_newton_setup(s);
 }
 
+static void cg_graphs_destroy(tlfea_newton_t s);
 extern "C" int tlfea_newton_destroy(tlfea_newton_t s) {
   if (!s) return 0;
   void* ptrs[] = {s->d_v, s->d_vprev, s->d_lam, s->d_g, s->d_dv, s->d_r, s->d_b, s->d_eigv, s->d_cd, s->d_cd2, s->d_cres, s->d_xp, s->d_yp, s->d_zp, s->d_H,
-                  s->d_Kbuf, s->d_Dinv, s->d_p, s->d_p2, s->d_q, s->d_zv, s->d_parts, s->d_scal, s->d_if_node, s->d_if_slot, s->d_ibuf, s->d_w, s->d_nw, s->d_wc, s->d_D};
+                  s->d_Kbuf, s->d_Dinv, s->d_p, s->d_p2, s->d_q, s->d_zv, s->d_parts, s->d_scal, s->d_if_node, s->d_if_slot, s->d_ibuf, s->d_w, s->d_nw, s->d_wc, s->d_D, s->d_B8, s->d_B1, s->d_sc, s->d_Dinv_s, s->d_cz, s->d_cz2, s->d_cres2, s->d_f32};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   for (auto& e : s->ev)
     if (e) (void)hipEventDestroy(e);
+  if (s->h_pin) (void)hipHostFree(s->h_pin);
+  cg_graphs_destroy(s);
+  if (s->d_coef) (void)hipFree(s->d_coef);
+  if (s->stream_own) (void)hipStreamDestroy(s->stream_own);
   delete s;
   return 0;
 }
@@ -767,7 +800,9 @@ extern "C" int tlfea_newton_set_linsolve_opts(tlfea_newton_t s, const tlfea_lins
   s->lin = *o;
   if (s->lin.check_every < 1) s->lin.check_every = 1;
   if (s->lin.cheb_degree < 0) s->lin.cheb_degree = 0;
-  if (!(s->lin.cheb_kappa > 1.0)) s->lin.cheb_kappa = 400.0;
+  if (s->lin.cheb_degree > 64) s->lin.cheb_degree = 64;
+  if (!(s->lin.cheb_kappa > 1.0)) s->lin.cheb_kappa = 0.0;  // auto
+  if (s->lin.cheb_bits != 16 && s->lin.cheb_bits != 32 && s->lin.cheb_bits != 64) s->lin.cheb_bits = 0;
   return 0;
 }
 extern "C" int tlfea_newton_set_fixed_sparsity_pattern(tlfea_newton_t s, int fixed) {
@@ -834,7 +869,7 @@ extern "C" int tlfea_newton_set_interface(tlfea_newton_t s, const int* iface_nod
                                           int n_local, int n_global, const double* node_weight,
                                           tlfea_allreduce_fn fn, void* user, int sync_before_callback) {
   void** ptrs[] = {(void**)&s->d_if_node, (void**)&s->d_if_slot, (void**)&s->d_ibuf, (void**)&s->d_w,
-                   (void**)&s->d_nw, (void**)&s->d_wc, (void**)&s->d_D};
+                   (void**)&s->d_nw, (void**)&s->d_wc};
   for (void** p : ptrs)
     if (*p) {
       (void)hipFree(*p);
@@ -846,6 +881,8 @@ extern "C" int tlfea_newton_set_interface(tlfea_newton_t s, const int* iface_nod
   s->ar_user = user;
   s->sync_before_cb = sync_before_callback != 0;
   s->n_constraints_global = s->n_constraints;
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  s->stream = fn ? nullptr : s->stream_own;
   if (!fn) return 0;
   tlfea_t10_t d = s->d;
   const size_t N = s->N;
@@ -857,7 +894,6 @@ extern "C" int tlfea_newton_set_interface(tlfea_newton_t s, const int* iface_nod
   TRY(dmalloc(&s->d_ibuf, (size_t)9 * std::max(1, n_global) + 2 * kNPart));
   TRY(dmalloc(&s->d_w, 3 * N));
   TRY(dmalloc(&s->d_nw, N));
-  TRY(dmalloc(&s->d_D, 9 * N));
   if (n_local) {
     HIP_TRY(hipMemcpy(s->d_if_node, iface_nodes, (size_t)n_local * sizeof(int), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(s->d_if_slot, iface_slots, (size_t)n_local * sizeof(int), hipMemcpyHostToDevice));
@@ -929,15 +965,33 @@ static int parts_sum(tlfea_newton_t s, double* d_a, double* d_b = nullptr) {
 
 static double* part(tlfea_newton_t s, int k) { return s->d_parts + (size_t)k * kNPart; }
 
-static int device_norm(tlfea_newton_t s, const double* d_vec, const double* w, int n, double* out) {
+// sum of squares (over ranks) left in s->d_scal[0]; no host synchronisation on the single-GPU path
+static int device_sumsq_async(tlfea_newton_t s, const double* d_vec, const double* w, int n) {
   launch_norm2(s->stream, d_vec, w, n, part(s, 5), s->d_scal);
   if (s->ar) {
     TRY(parts_sum(s, part(s, 5)));
     launch_sum_parts(s->stream, part(s, 5), s->d_scal);
   }
-  double ss = 0.0;
-  HIP_TRY(hipMemcpyAsync(&ss, s->d_scal, sizeof(double), hipMemcpyDeviceToHost, s->stream));
+  return 0;
+}
+// one device scalar to the host through the pinned staging word
+static int fetch_scalar(tlfea_newton_t s, const double* d_src, double* out) {
+  HIP_TRY(hipMemcpyAsync(s->h_pin, d_src, sizeof(double), hipMemcpyDeviceToHost, s->stream));
   HIP_TRY(hipStreamSynchronize(s->stream));
+  *out = s->h_pin[0];
+  return 0;
+}
+static int fetch_scalar2(tlfea_newton_t s, const double* d_src, double* out0, double* out1) {
+  HIP_TRY(hipMemcpyAsync(s->h_pin, d_src, 2 * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  *out0 = s->h_pin[0];
+  *out1 = s->h_pin[1];
+  return 0;
+}
+static int device_norm(tlfea_newton_t s, const double* d_vec, const double* w, int n, double* out) {
+  TRY(device_sumsq_async(s, d_vec, w, n));
+  double ss = 0.0;
+  TRY(fetch_scalar(s, s->d_scal, &ss));
   *out = std::sqrt(ss);
   return 0;
 }
@@ -1005,12 +1059,46 @@ static int assemble(tlfea_newton_t s) {
   return 0;
 }
 
-// cheb_degree 0 = auto: below ~200k coefficient rows a CG iteration is bound by its two reductions and launches,
-// and a degree-12 polynomial (11 reduction-free SpMV steps per outer iteration) is 1.4x faster (config B); above,
-// the solve is bandwidth-bound, the polynomial costs ~15 % more SpMVs than CG and plain block-Jacobi wins (config C).
+// cheb_degree 0 = auto = 24.  The steps of the polynomial stream a quarter of the bytes of a CG iteration (fp16 copy
+// of H, fp32 vectors) and need no reductions, so a high degree wins on every mesh size: measured (MI355X, rel 1e-12)
+// config B 12/16/20/24/32 -> 5.3/5.1/4.7/4.7/4.8 ms per Newton iteration, config C 555/531/539/513/528 ms, against
+// 12.8 ms / 1.3-1.5 s with plain block-Jacobi.  The matching interval ratio kappa grows with the degree.
 static int cheb_degree_eff(tlfea_newton_t s) {
   if (s->lin.cheb_degree > 0) return s->lin.cheb_degree;
-  return s->N <= 200000 ? 12 : 1;
+  return 24;
+}
+static double cheb_kappa_eff(tlfea_newton_t s) {
+  if (s->lin.cheb_kappa > 1.0) return s->lin.cheb_kappa;
+  const int deg = cheb_degree_eff(s);
+  return deg >= 22 ? 1600.0 : (deg >= 14 ? 800.0 : 400.0);
+}
+
+// storage precision of the matrix streamed by the Chebyshev steps: 0 = auto = fp16 (scaled copy, see
+// solver_kernels.hip); 64 streams H itself
+static int cheb_bits_eff(tlfea_newton_t s) {
+  if (cheb_degree_eff(s) <= 1) return 64;
+  return s->lin.cheb_bits == 0 ? 16 : s->lin.cheb_bits;
+}
+
+// (re)build the low-precision copy from the current H and block diagonal (d_D, d_Dinv must be current)
+static int lp_build(tlfea_newton_t s) {
+  tlfea_t10_t d = s->d;
+  const int bits = cheb_bits_eff(s);
+  if (bits == 64) return 0;
+  if (s->lp_bits_alloc != bits) {
+    if (s->d_B8) (void)hipFree(s->d_B8);
+    if (s->d_B1) (void)hipFree(s->d_B1);
+    s->d_B8 = s->d_B1 = nullptr;
+    const size_t eb = bits / 8;
+    HIP_TRY(hipMalloc(&s->d_B8, (size_t)d->nnz_coef * 8 * eb));
+    HIP_TRY(hipMalloc(&s->d_B1, (size_t)d->nnz_coef * eb));
+    s->lp_bits_alloc = bits;
+  }
+  launch_lp_scale(s->stream, s->N, s->d_D, s->d_Dinv, s->d_sc, s->d_Dinv_s);
+  launch_lp_convert(s->stream, s->N, d->inc(), s->d_H, s->d_sc, s->d_B8, s->d_B1, bits);
+  if (!s->ar) launch_to_float(s->stream, (size_t)9 * s->N, s->d_Dinv_s, s->d_f32 + (size_t)18 * s->N);
+  HIP_TRY(hipGetLastError());
+  return 0;
 }
 
 // lambda_max(D^-1 H) by power iteration (warm-started from the previous solve's vector; H changes little between
@@ -1020,22 +1108,49 @@ static int estimate_lam_max(tlfea_newton_t s, const double* d_b) {
   const int N = s->N, n = 3 * N;
   const bool cold = !(s->lam_max > 0.0);
   const int iters = cold ? 16 : 4;
-  double nrm = 0.0;
+  // v <- D^-1 H v / ||D^-1 H v||, the norm stays on the device between iterations: one host read at the end
   if (cold) launch_apply_dinv(s->stream, N, s->d_Dinv, d_b, s->d_eigv);
-  TRY(device_norm(s, s->d_eigv, s->d_w, n, &nrm));
-  if (!(nrm > 0.0)) return 0;
-  launch_scale(s->stream, n, 1.0 / nrm, s->d_eigv);
-  double lam = s->lam_max;
+  TRY(device_sumsq_async(s, s->d_eigv, s->d_w, n));
+  launch_scale_inv_sqrt(s->stream, n, s->d_scal, s->d_eigv);
   for (int k = 0; k < iters; k++) {
     launch_spmv_dir_dot(s->stream, N, d->inc(), s->d_H, s->d_eigv, s->d_eigv, 1, part(s, 1), part(s, 0), s->d_p2, s->d_q,
                         part(s, 2), false, s->spmv_nt);
     if (s->ar) TRY(iface_sum(s, s->d_q, 3));
     launch_apply_dinv(s->stream, N, s->d_Dinv, s->d_q, s->d_eigv);
-    TRY(device_norm(s, s->d_eigv, s->d_w, n, &lam));
-    if (!(lam > 0.0)) return fail("lambda_max estimate failed");
-    launch_scale(s->stream, n, 1.0 / lam, s->d_eigv);
+    TRY(device_sumsq_async(s, s->d_eigv, s->d_w, n));
+    launch_scale_inv_sqrt(s->stream, n, s->d_scal, s->d_eigv);
   }
-  s->lam_max = lam;
+  double ss = 0.0;
+  TRY(fetch_scalar(s, s->d_scal, &ss));
+  const double lam = std::sqrt(ss);
+  if (!(lam > 0.0)) {
+    if (ss == 0.0) return 0;  // zero start vector (b = 0): keep the previous estimate
+    return fail("lambda_max estimate failed");
+  }
+  // TLFEA_CHEB_LMAX_SCALE (tests only): scales the estimate to exercise the breakdown recovery in pcg()
+  const char* fe = std::getenv("TLFEA_CHEB_LMAX_SCALE");
+  const double fudge = fe ? std::atof(fe) : 1.0;
+  s->lam_max = lam * fudge;
+  return 0;
+}
+
+// Chebyshev coefficients of this solve to the device: coef[0] = 1/theta, step k reads coef[2k], coef[2k+1].  They live
+// in device memory (not kernel arguments) so that the captured launch sequence stays valid when lambda_max moves.
+static int cheb_upload_coefficients(tlfea_newton_t s) {
+  const int deg = cheb_degree_eff(s);
+  const double b = s->lam_safety * s->lam_max, a = b / cheb_kappa_eff(s);
+  const double theta = 0.5 * (b + a), delta = 0.5 * (b - a), sigma = theta / delta;
+  double rho = 1.0 / sigma;
+  double* h = s->h_pin + 8;
+  h[0] = 1.0 / theta;
+  h[1] = 0.0;
+  for (int k = 1; k < deg; k++) {
+    const double rho_new = 1.0 / (2.0 * sigma - rho);
+    h[2 * k] = rho_new * rho;
+    h[2 * k + 1] = 2.0 * rho_new / delta;
+    rho = rho_new;
+  }
+  HIP_TRY(hipMemcpyAsync(s->d_coef, h, (size_t)2 * deg * sizeof(double), hipMemcpyHostToDevice, s->stream));
   return 0;
 }
 
@@ -1043,28 +1158,138 @@ static int estimate_lam_max(tlfea_newton_t s, const double* d_b) {
 static int cheb_apply(tlfea_newton_t s, const double* d_r, double* d_z, double* rz_part) {
   tlfea_t10_t d = s->d;
   const int N = s->N, deg = cheb_degree_eff(s);
-  const double b = 1.15 * s->lam_max, a = b / s->lin.cheb_kappa;
-  const double theta = 0.5 * (b + a), delta = 0.5 * (b - a), sigma = theta / delta;
-  double rho = 1.0 / sigma;
   double *d_old = s->d_cd, *d_new = s->d_cd2;
-  launch_cheb_init(s->stream, N, s->d_Dinv, d_r, 1.0 / theta, d_old, d_z, s->d_cres);
+  const int bits = cheb_bits_eff(s);
+  const bool lp = bits != 64;
+  const double* Dinv = lp ? s->d_Dinv_s : s->d_Dinv;
+  const double* sc = lp ? s->d_sc : nullptr;
+  if (lp && !s->ar) {
+    // single GPU: the whole polynomial in single precision (cheb32_kernel); d, z, res ping-pong so that a row's
+    // stores never order against loads of other rows; the last step returns z = S z^ in fp64 and the r.z slots
+    const size_t n = 3 * (size_t)N;
+    float *f_d = s->d_f32, *f_d2 = f_d + n, *f_z = f_d2 + n, *f_z2 = f_z + n, *f_r = f_z2 + n, *f_r2 = f_r + n;
+    const float* Dinv_f = f_r2 + n;
+    launch_cheb32_init(s->stream, N, Dinv_f, d_r, sc, s->d_coef, f_d, f_z, f_r);
+    for (int k = 1; k < deg; k++) {
+      const bool last = (k == deg - 1);
+      launch_cheb32(s->stream, N, d->nnz_coef, d->inc(), s->d_B8, s->d_B1, bits, Dinv_f, sc, f_d, s->d_coef + 2 * k, f_d2,
+                    f_z, f_z2, f_r, f_r2, d_r, d_z, rz_part, last);
+      std::swap(f_d, f_d2);
+      std::swap(f_z, f_z2);
+      std::swap(f_r, f_r2);
+    }
+    return 0;
+  }
+  // multi-GPU LP path: fp64 vectors, q = Hs d summed over ranks between the SpMV and the vector update
+  double *z_cur = d_z, *z_alt = s->d_cz2;
+  double *res_cur = s->d_cres, *res_alt = s->d_cres2;
+  launch_cheb_init(s->stream, N, Dinv, d_r, sc, s->d_coef, d_old, z_cur, res_cur);
   for (int k = 1; k < deg; k++) {
-    const double rho_new = 1.0 / (2.0 * sigma - rho);
-    const double c1 = rho_new * rho, c2 = 2.0 * rho_new / delta;
+    const double* coef = s->d_coef + 2 * k;
     const bool last = (k == deg - 1);
     if (s->ar) {
-      launch_spmv_dir_dot(s->stream, N, d->inc(), s->d_H, d_old, d_old, 1, part(s, 1), part(s, 0), s->d_p2, s->d_q,
-                          part(s, 2), false, s->spmv_nt);
+      if (lp)
+        launch_cheb_lp(s->stream, N, d->nnz_coef, d->inc(), s->d_B8, s->d_B1, bits, Dinv, sc, d_old, coef, d_new,
+                       nullptr, nullptr, nullptr, nullptr, d_r, s->d_w, s->d_q, 2);
+      else
+        launch_spmv_dir_dot(s->stream, N, d->inc(), s->d_H, d_old, d_old, 1, part(s, 1), part(s, 0), s->d_p2, s->d_q,
+                            part(s, 2), false, s->spmv_nt);
       TRY(iface_sum(s, s->d_q, 3));
-      launch_cheb_update(s->stream, N, s->d_Dinv, s->d_q, d_old, c1, c2, d_new, d_z, s->d_cres, d_r, s->d_w, rz_part,
+      launch_cheb_update(s->stream, N, Dinv, s->d_q, d_old, coef, d_new, d_z, s->d_cres, d_r, s->d_w, sc, rz_part,
                          last);
+    } else if (lp) {
+      double* z_out = last ? d_z : z_alt;
+      launch_cheb_lp(s->stream, N, d->nnz_coef, d->inc(), s->d_B8, s->d_B1, bits, Dinv, sc, d_old, coef, d_new, z_cur,
+                     z_out, res_cur, res_alt, d_r, s->d_w, rz_part, last ? 1 : 0);
+      if (!last) {
+        z_alt = z_cur;
+        z_cur = z_out;
+        std::swap(res_cur, res_alt);
+      }
     } else {
-      launch_cheb_step(s->stream, N, d->inc(), s->d_H, s->d_Dinv, d_old, c1, c2, d_new, d_z, s->d_cres, d_r, s->d_w,
+      launch_cheb_step(s->stream, N, d->inc(), s->d_H, s->d_Dinv, d_old, coef, d_new, d_z, s->d_cres, d_r, s->d_w,
                        rz_part, last);
     }
     std::swap(d_old, d_new);
-    rho = rho_new;
   }
+  return 0;
+}
+
+// Enqueue CG iteration `it` (parity cur = it & 1 selects the r.z slot pair and, in the fused variant, which of the
+// two direction buffers is read).  Everything an iteration needs from the previous one (alpha, beta, Chebyshev
+// coefficients) is read from device memory, so iterations >= 1 of either parity are the SAME launch sequence.
+static int enqueue_cg_iteration(tlfea_newton_t s, double* d_x, bool first, int cur, bool fused, int deg) {
+  tlfea_t10_t d = s->d;
+  const int N = s->N;
+  const double* w = s->d_w;
+  double* pq_part = part(s, 2);
+  double *p_old = s->d_p, *p_new = s->d_p2;
+  if (fused && cur) std::swap(p_old, p_new);
+  if (deg > 1) {
+    // polynomial preconditioner: z = Cheb(r), r.z slots -> part(cur)   (deg-1 SpMV launches, no reductions)
+    TRY(cheb_apply(s, s->d_r, s->d_zv, part(s, cur)));
+    if (s->ar) TRY(parts_sum(s, part(s, cur)));
+  }
+  if (s->profiling) (void)hipEventRecord(s->ev[4], s->stream);
+  // beta = rz(cur)/rz(1-cur); p = z + beta p; q = H p; partials of p.q
+  if (fused) {
+    launch_spmv_dir_dot(s->stream, N, d->inc(), s->d_H, s->d_zv, p_old, first, part(s, 1 - cur), part(s, cur), p_new,
+                        s->d_q, pq_part, true, s->spmv_nt);
+  } else {
+    launch_pcg_direction(s->stream, 3 * N, s->d_zv, first, part(s, 1 - cur), part(s, cur), p_old);
+    launch_spmv_dir_dot(s->stream, N, d->inc(), s->d_H, s->d_zv, p_old, first, part(s, 1 - cur), part(s, cur), p_old,
+                        s->d_q, pq_part, false, s->spmv_nt);
+  }
+  if (s->profiling) {
+    (void)hipEventRecord(s->ev[5], s->stream);
+    (void)hipEventSynchronize(s->ev[5]);
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, s->ev[4], s->ev[5]);
+    s->stage_ms[6] += ms;
+    s->stage_n[6] += deg;  // SpMV launches of this iteration (Chebyshev steps included)
+  }
+  if (s->ar) TRY(iface_sum(s, s->d_q, 3, pq_part, kNPart));  // boundary rows of q + p.q slots, one collective
+  if (deg > 1) {
+    // alpha = rz(cur)/pq; x += alpha p; r -= alpha q; r.r slots
+    launch_pcg_update_noz(s->stream, N, w, fused ? p_new : p_old, s->d_q, part(s, cur), pq_part, d_x, s->d_r, part(s, 3),
+                          s->d_scal + 3);
+    if (s->ar) TRY(parts_sum(s, part(s, 3)));
+  } else {
+    // ... and z = Dinv r with the new r.z slots into part(1-cur)
+    launch_pcg_update(s->stream, N, s->d_Dinv, w, fused ? p_new : p_old, s->d_q, part(s, cur), pq_part, d_x, s->d_r,
+                      s->d_zv, part(s, 1 - cur), part(s, 3));
+    if (s->ar) TRY(parts_sum(s, part(s, 1 - cur), part(s, 3)));  // r.z and r.r slots, one collective
+  }
+  return 0;
+}
+
+static void cg_graphs_destroy(tlfea_newton_t s) {
+  for (auto& g : s->cg_graph)
+    if (g) {
+      (void)hipGraphExecDestroy(g);
+      g = nullptr;
+    }
+}
+
+// The two launch sequences (even / odd iteration) captured once as hipGraphs and replayed: one host call per CG
+// iteration instead of deg+2 launches.  On small meshes the kernels last 5-10 us and the launch rate of the host
+// is what an iteration costs otherwise.  Single-GPU path only (the multi-GPU path calls back into the host
+// between kernels).
+static int cg_graphs_prepare(tlfea_newton_t s, double* d_x, bool fused, int deg, int bits) {
+  const long key[6] = {deg, bits, fused ? 1 : 0, (long)(size_t)d_x, (long)(size_t)s->d_B8, (long)(size_t)s->d_w};
+  if (s->cg_graph[0] && std::equal(key, key + 6, s->cg_graph_key)) return 0;
+  cg_graphs_destroy(s);
+  for (int cur = 0; cur < 2; cur++) {
+    hipGraph_t g = nullptr;
+    HIP_TRY(hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
+    const int rc = enqueue_cg_iteration(s, d_x, false, cur, fused, deg);
+    const hipError_t e = hipStreamEndCapture(s->stream, &g);
+    if (rc) return rc;
+    HIP_TRY(e);
+    HIP_TRY(hipGraphInstantiate(&s->cg_graph[cur], g, nullptr, nullptr, 0));
+    (void)hipGraphDestroy(g);
+  }
+  std::copy(key, key + 6, s->cg_graph_key);
   return 0;
 }
 
@@ -1074,11 +1299,13 @@ static int pcg(tlfea_newton_t s, const double* d_b, double* d_x, int* iters_out,
   const int N = s->N;
   StageTimer t(s, 4);
   const double* w = s->d_w;
-  if (s->ar) {
+  const bool lp = cheb_bits_eff(s) != 64;
+  if (s->ar || lp) {
     // diagonal blocks of partition-boundary nodes are partial per rank: sum them before inverting
     launch_extract_diag(s->stream, N, d->inc(), s->d_H, s->d_D);
     TRY(iface_sum(s, s->d_D, 9));
     launch_invert_diag(s->stream, N, s->d_D, s->d_Dinv);
+    if (lp) TRY(lp_build(s));
   } else {
     launch_extract_dinv(s->stream, N, d->inc(), s->d_H, s->d_Dinv);
   }
@@ -1087,66 +1314,66 @@ static int pcg(tlfea_newton_t s, const double* d_b, double* d_x, int* iters_out,
   TRY(parts_sum(s, part(s, 0), part(s, 4)));
   launch_sum_parts(s->stream, part(s, 4), s->d_scal + 1);
   double bb = 0.0;
-  HIP_TRY(hipMemcpyAsync(&bb, s->d_scal + 1, sizeof(double), hipMemcpyDeviceToHost, s->stream));
-  HIP_TRY(hipStreamSynchronize(s->stream));
+  TRY(fetch_scalar(s, s->d_scal + 1, &bb));
   int it = 0;
   double rr = bb;
   if (bb > 0.0) {
     const double target = s->lin.rel_tol * s->lin.rel_tol * bb;
-    double* pq_part = part(s, 2);
     const bool fused = s->pcg_fused < 0 ? (N <= 200000) : (s->pcg_fused != 0);
     const int deg = cheb_degree_eff(s);
     // an outer iteration costs `deg` SpMV launches: test convergence proportionally more often
-    const int check_every = std::max(1, s->lin.check_every / deg);
-    if (deg > 1) TRY(estimate_lam_max(s, d_b));
-    int cur = 0;  // rz slots of the current iteration live in part(cur), the previous ones in part(1-cur)
-    double *p_old = s->d_p, *p_new = s->d_p2;
-    while (it < s->lin.max_iter) {
-      if (deg > 1) {
-        // polynomial preconditioner: z = Cheb(r), r.z slots -> part(cur)   (deg-1 SpMV launches, no reductions)
-        TRY(cheb_apply(s, s->d_r, s->d_zv, part(s, cur)));
-        if (s->ar) TRY(parts_sum(s, part(s, cur)));
-      }
-      if (s->profiling) (void)hipEventRecord(s->ev[4], s->stream);
-      // beta = rz(cur)/rz(1-cur); p = z + beta p; q = H p; partials of p.q
-      if (fused) {
-        launch_spmv_dir_dot(s->stream, N, d->inc(), s->d_H, s->d_zv, p_old, it == 0, part(s, 1 - cur), part(s, cur),
-                            p_new, s->d_q, pq_part, true, s->spmv_nt);
-      } else {
-        launch_pcg_direction(s->stream, 3 * N, s->d_zv, it == 0, part(s, 1 - cur), part(s, cur), p_old);
-        launch_spmv_dir_dot(s->stream, N, d->inc(), s->d_H, s->d_zv, p_old, it == 0, part(s, 1 - cur), part(s, cur),
-                            p_old, s->d_q, pq_part, false, s->spmv_nt);
-      }
-      if (s->profiling) {
-        (void)hipEventRecord(s->ev[5], s->stream);
-        (void)hipEventSynchronize(s->ev[5]);
-        float ms = 0.f;
-        (void)hipEventElapsedTime(&ms, s->ev[4], s->ev[5]);
-        s->stage_ms[6] += ms;
-        s->stage_n[6] += deg;  // SpMV launches of this iteration (Chebyshev steps included)
-      }
-      if (s->ar) TRY(iface_sum(s, s->d_q, 3, pq_part, kNPart));  // boundary rows of q + p.q slots, one collective
-      if (deg > 1) {
-        // alpha = rz(cur)/pq; x += alpha p; r -= alpha q; r.r slots
-        launch_pcg_update_noz(s->stream, N, w, fused ? p_new : p_old, s->d_q, part(s, cur), pq_part, d_x, s->d_r,
-                              part(s, 3));
-        if (s->ar) TRY(parts_sum(s, part(s, 3)));
-      } else {
-        // ... and z = Dinv r with the new r.z slots into part(1-cur)
-        launch_pcg_update(s->stream, N, s->d_Dinv, w, fused ? p_new : p_old, s->d_q, part(s, cur), pq_part, d_x, s->d_r,
-                          s->d_zv, part(s, 1 - cur), part(s, 3));
-        if (s->ar) TRY(parts_sum(s, part(s, 1 - cur), part(s, 3)));  // r.z and r.r slots, one collective
-      }
-      cur = 1 - cur;
-      if (fused) std::swap(p_old, p_new);
-      it++;
-      if (it % check_every == 0 || it == s->lin.max_iter) {
-        launch_sum_parts(s->stream, part(s, 3), s->d_scal + 2);
-        HIP_TRY(hipMemcpyAsync(&rr, s->d_scal + 2, sizeof(double), hipMemcpyDeviceToHost, s->stream));
-        HIP_TRY(hipStreamSynchronize(s->stream));
-        if (!(rr > target)) break;  // also leaves on NaN
-      }
+    int check_every = std::max(1, s->lin.check_every / deg);
+    // Every convergence test drains the launch queue (tens of microseconds: as much as an iteration on a small
+    // mesh).  Consecutive Newton iterations need nearly the same number of CG iterations, so after the first solve
+    // the tests start one iteration before the previous solve's count and then run every iteration.
+    const int bits = cheb_bits_eff(s);
+    int first_check = check_every;
+    if (s->last_outer_iters > 1 && s->last_deg == deg && s->last_bits == bits) {
+      first_check = s->last_outer_iters - 1;
+      check_every = 1;
     }
+    s->last_deg = deg;
+    s->last_bits = bits;
+    if (deg > 1) {
+      TRY(estimate_lam_max(s, d_b));
+      TRY(cheb_upload_coefficients(s));
+    }
+    const bool graphs = s->use_graphs && !s->ar && !s->profiling;
+    if (graphs) TRY(cg_graphs_prepare(s, d_x, fused, deg, bits));
+    double indefinite = 0.0;
+    HIP_TRY(hipMemsetAsync(s->d_scal + 3, 0, sizeof(double), s->stream));
+    for (int attempt = 0;; attempt++) {
+      while (it < s->lin.max_iter) {
+        // r.z slots of iteration `it` live in part(it & 1), the previous ones in the other pair
+        if (graphs && it > 0)
+          HIP_TRY(hipGraphLaunch(s->cg_graph[it & 1], s->stream));
+        else
+          TRY(enqueue_cg_iteration(s, d_x, it == 0, it & 1, fused, deg));
+        it++;
+        if ((it >= first_check && (it - first_check) % check_every == 0) || it == s->lin.max_iter) {
+          launch_sum_parts(s->stream, part(s, 3), s->d_scal + 2);
+          TRY(fetch_scalar2(s, s->d_scal + 2, &rr, &indefinite));  // ||r||^2 and the r.z < 0 flag
+          if (!(rr > target)) break;                       // also leaves on NaN
+          if (rr > 1e8 * bb || indefinite != 0.0) break;   // the preconditioner is not positive definite
+        }
+      }
+      // A Chebyshev polynomial is positive only up to the upper end of its interval: if the power iteration
+      // underestimated lambda_max by more than the safety margin, CG breaks down (NaN or growth).  Widen and redo.
+      const bool broke = (rr != rr) || rr > 1e8 * bb || (indefinite != 0.0 && rr > target);
+      if (!broke || deg <= 1 || attempt >= 3) break;
+      s->lam_safety *= 1.5;  // kept for the following solves: the estimate is systematically low on this mesh
+      if (s->verbose) std::printf("PCG breakdown: Chebyshev interval widened to %.3g x lambda_max estimate\n", s->lam_safety);
+      TRY(cheb_upload_coefficients(s));
+      launch_pcg_init(s->stream, N, d_b, s->d_Dinv, w, d_x, s->d_r, s->d_zv, part(s, 0), part(s, 4));
+      TRY(parts_sum(s, part(s, 0), part(s, 4)));
+      HIP_TRY(hipMemsetAsync(s->d_scal + 3, 0, sizeof(double), s->stream));
+      indefinite = 0.0;
+      it = 0;
+      rr = bb;
+      first_check = std::max(1, s->lin.check_every / deg);
+      check_every = first_check;
+    }
+    s->last_outer_iters = it;
   } else {
     HIP_TRY(hipMemsetAsync(d_x, 0, 3 * (size_t)N * sizeof(double), s->stream));
   }
@@ -1158,6 +1385,13 @@ static int pcg(tlfea_newton_t s, const double* d_b, double* d_x, int* iters_out,
   return 0;
 }
 
+extern "C" int tlfea_newton_get_linsolve_info(tlfea_newton_t s, int* cheb_degree, int* cheb_bits, int* cheb_vector_bits) {
+  if (!s) return fail("null argument");
+  if (cheb_degree) *cheb_degree = cheb_degree_eff(s);
+  if (cheb_bits) *cheb_bits = cheb_bits_eff(s);
+  if (cheb_vector_bits) *cheb_vector_bits = (cheb_bits_eff(s) != 64 && !s->ar) ? 32 : 64;
+  return 0;
+}
 extern "C" int tlfea_newton_eval_gradient(tlfea_newton_t s, double* norm_g) {
   TRY(tlfea_newton_analyze_hessian_sparsity(s));
   return eval_gradient(s, norm_g);
@@ -1202,8 +1436,16 @@ extern "C" int tlfea_newton_time_kernels(tlfea_newton_t s, int reps, double* out
       else if (k == 3)  // same variant the solver uses; first=1 reads no reduction slots, inputs are the last z / p
         launch_spmv_dir_dot(s->stream, N, d->inc(), s->d_H, s->d_zv, s->d_p, 1, part(s, 1), part(s, 0), s->d_p2, s->d_q,
                             part(s, 2), fused, s->spmv_nt);
-      else  // one polynomial-preconditioner step on the solver's work vectors (coefficients are irrelevant to time)
-        launch_cheb_step(s->stream, N, d->inc(), s->d_H, s->d_Dinv, s->d_cd, 0.5, 0.0, s->d_cd2, s->d_zv, s->d_cres,
+      else if (cheb_bits_eff(s) != 64 && s->d_B8 && !s->ar) {  // one polynomial-preconditioner step on the solver's
+        const size_t n = 3 * (size_t)N;                          // work vectors
+        float* f = s->d_f32;
+        launch_cheb32(s->stream, N, d->nnz_coef, d->inc(), s->d_B8, s->d_B1, cheb_bits_eff(s), f + 6 * n, s->d_sc, f,
+                      s->d_coef + 2, f + n, f + 2 * n, f + 3 * n, f + 4 * n, f + 5 * n, s->d_r, s->d_zv, part(s, 0), false);
+      } else if (cheb_bits_eff(s) != 64 && s->d_B8)
+        launch_cheb_lp(s->stream, N, d->nnz_coef, d->inc(), s->d_B8, s->d_B1, cheb_bits_eff(s), s->d_Dinv_s, s->d_sc,
+                       s->d_cd, s->d_coef + 2, s->d_cd2, s->d_cz, s->d_cz2, s->d_cres, s->d_cres2, s->d_r, s->d_w, part(s, 0), 0);
+      else  // vectors (the coefficients are irrelevant to the time)
+        launch_cheb_step(s->stream, N, d->inc(), s->d_H, s->d_Dinv, s->d_cd, s->d_coef + 2, s->d_cd2, s->d_zv, s->d_cres,
                          s->d_r, s->d_w, part(s, 0), false);
     }
     HIP_TRY(hipEventRecord(s->ev[7], s->stream));

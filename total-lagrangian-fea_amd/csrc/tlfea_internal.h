@@ -91,18 +91,37 @@ void launch_pcg_update(hipStream_t s, int N, const double* Dinv, const double* w
                        const double* rz_part_old, const double* pq_part, double* x, double* r, double* z,
                        double* rz_part_new, double* rr_part);
 void launch_sum_parts(hipStream_t s, const double* part, double* out);
-void launch_cheb_init(hipStream_t s, int N, const double* Dinv, const double* r, double inv_theta, double* d,
-                      double* z, double* res);
+void launch_cheb_init(hipStream_t s, int N, const double* Dinv, const double* r, const double* sc,
+                      const double* coef, double* d, double* z, double* res);
 void launch_cheb_step(hipStream_t s, int N, const Incidence& inc, const double* Hval, const double* Dinv,
-                      const double* d_old, double c1, double c2, double* d_new, double* z, double* res,
+                      const double* d_old, const double* coef, double* d_new, double* z, double* res,
                       const double* r, const double* w, double* rz_part, bool last);
-void launch_cheb_update(hipStream_t s, int N, const double* Dinv, const double* q, const double* d_old, double c1,
-                        double c2, double* d_new, double* z, double* res, const double* r, const double* w,
-                        double* rz_part, bool last);
+void launch_cheb_update(hipStream_t s, int N, const double* Dinv, const double* q, const double* d_old,
+                        const double* coef, double* d_new, double* z, double* res, const double* r, const double* w,
+                        const double* sc, double* rz_part, bool last);
+// low-precision (fp16/fp32) scaled block-CSR copy of H for the polynomial preconditioner
+void launch_lp_scale(hipStream_t s, int N, const double* D, const double* Dinv, double* sc, double* Dinv_s);
+void launch_lp_convert(hipStream_t s, int N, const Incidence& inc, const double* Hval, const double* sc, void* B8,
+                       void* B1, int bits);
+// the polynomial in single precision (single-GPU path): fp32 vectors, fp16/fp32 matrix, fp32 accumulation
+void launch_to_float(hipStream_t s, size_t n, const double* a, float* b);
+void launch_cheb32_init(hipStream_t s, int N, const float* Dinv_f, const double* r, const double* sc,
+                        const double* coef, float* d, float* z, float* res);
+void launch_cheb32(hipStream_t s, int N, int nnz_coef, const Incidence& inc, const void* B8, const void* B1, int bits,
+                   const float* Dinv_f, const double* sc, const float* d_old, const double* coef, float* d_new,
+                   const float* z, float* z_new, const float* res, float* res_new, const double* r, double* z_out,
+                   double* rz_part, bool last);
+// mode 0: Chebyshev step, 1: last step (z back in the unscaled space + r.z slots in out), 2: out = Hs d_old
+void launch_cheb_lp(hipStream_t s, int N, int nnz_coef, const Incidence& inc, const void* B8, const void* B1, int bits,
+                    const double* Dinv_s, const double* sc, const double* d_old, const double* coef, double* d_new,
+                    const double* z, double* z_new, const double* res, double* res_new, const double* r,
+                    const double* w, double* out, int mode);
 void launch_pcg_update_noz(hipStream_t s, int N, const double* w, const double* p, const double* q,
-                           const double* rz_part_old, const double* pq_part, double* x, double* r, double* rr_part);
+                           const double* rz_part_old, const double* pq_part, double* x, double* r, double* rr_part,
+                           double* indefinite);
 void launch_apply_dinv(hipStream_t s, int N, const double* Dinv, const double* q, double* v);
 void launch_scale(hipStream_t s, int n, double a, double* v);
+void launch_scale_inv_sqrt(hipStream_t s, int n, const double* sumsq, double* v);
 void launch_newton_update(hipStream_t s, int N, const double* dv, double* v, const double* xp, const double* yp,
                           const double* zp, double h, double* x, double* y, double* z);
 void launch_axpy_neg(hipStream_t s, int n, const double* g, double* r);

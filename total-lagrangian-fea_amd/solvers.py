@@ -23,8 +23,9 @@ class LinSolveOpts:
     rel_tol: float = 1e-12
     max_iter: int = 20000
     check_every: int = 25
-    cheb_degree: int = 0      # Chebyshev polynomial preconditioner degree (1 = block-Jacobi, 0 = auto by size)
-    cheb_kappa: float = 400.0
+    cheb_degree: int = 0      # Chebyshev polynomial preconditioner degree (1 = block-Jacobi, 0 = auto = 24)
+    cheb_kappa: float = 0.0   # polynomial interval [lmax/kappa, lmax] of D^-1 H (0 = auto, by degree)
+    cheb_bits: int = 0        # matrix precision of the polynomial's steps: 64 | 32 | 16 (0 = auto = 16)
 
 
 class SyncedNewtonSolver:
@@ -54,8 +55,14 @@ class SyncedNewtonSolver:
         check(self._lib.tlfea_newton_set_parameters(self._h, C.byref(p)))
 
     def SetLinSolveOpts(self, o):
-        c = LinSolveOptsC(o.rel_tol, o.max_iter, o.check_every, o.cheb_degree, o.cheb_kappa)
+        c = LinSolveOptsC(o.rel_tol, o.max_iter, o.check_every, o.cheb_degree, o.cheb_kappa, o.cheb_bits)
         check(self._lib.tlfea_newton_set_linsolve_opts(self._h, C.byref(c)))
+
+    def GetLinSolveInfo(self):
+        """(polynomial degree, matrix bits of its steps, bits of its work vectors) the auto rules resolved to"""
+        deg, bits, vbits = C.c_int(), C.c_int(), C.c_int()
+        check(self._lib.tlfea_newton_get_linsolve_info(self._h, C.byref(deg), C.byref(bits), C.byref(vbits)))
+        return deg.value, bits.value, vbits.value
 
     def AnalyzeHessianSparsity(self):
         check(self._lib.tlfea_newton_analyze_hessian_sparsity(self._h))
