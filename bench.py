@@ -229,9 +229,12 @@ def main():
 def load_pmc_traffic():
     """HBM bytes per launch from the committed PMC summary (collected with the same command, config B)."""
     path = os.path.join(ROOT, "profiles", "r01_configB_pmc_hbm.csv")  # regenerated by tools/summarize_pmc.py
-    names = {"residual_kernel": "residual", "tangent_blocks_kernel": "tangent_blocks",
-             "assemble_rows_kernel": "assemble_rows", "spmv_dir_dot_kernel": "spmv", "cheb_step_kernel<false>": "cheb_step",
-             "cheb32_kernel": "cheb_step"}
+    import re
+    names = {r"residual_kernel": "residual", r"tangent_blocks_kernel": "tangent_blocks",
+             r"assemble_rows_kernel": "assemble_rows", r"spmv_dir_dot_kernel<true": "spmv",   # the CG variant at config B
+             r"cheb_step_kernel<false>": "cheb_step",                 # fp64 polynomial steps (cheb_bits 64)
+             # fp32 recurrence, non-final steps (rocprofv3 leaves names with _Float16 arguments mangled)
+             r"cheb32_kernel<[^,]+, \d+, false": "cheb_step", r"cheb32_kernelI\w+?_Li\d+ELb0E": "cheb_step"}
     out = {}
     if not os.path.exists(path):
         return out
@@ -239,7 +242,7 @@ def load_pmc_traffic():
     acc = {}
     for r in csv.DictReader(open(path)):
         for frag, key in names.items():
-            if frag in r["kernel"]:
+            if re.search(frag, r["kernel"]):
                 acc.setdefault(key, {})[r["counter"]] = float(r["mean_KB"])
     for key, c in acc.items():
         if "FETCH_SIZE" in c and "WRITE_SIZE" in c:

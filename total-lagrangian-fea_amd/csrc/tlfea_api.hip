@@ -1433,18 +1433,21 @@ extern "C" int tlfea_newton_time_kernels(tlfea_newton_t s, int reps, double* out
         launch_assemble_rows(s->stream, N, d->S, d->maxdeg, d->inc(), s->d_Kbuf, d->d_mval, 1.0 / p.time_step,
                              d->is_constraints_setup ? d->d_fixed_slot : nullptr, s->d_nw,
                              p.time_step * p.time_step * p.rho, s->d_H);
-      else if (k == 3)  // same variant the solver uses; first=1 reads no reduction slots, inputs are the last z / p
-        launch_spmv_dir_dot(s->stream, N, d->inc(), s->d_H, s->d_zv, s->d_p, 1, part(s, 1), part(s, 0), s->d_p2, s->d_q,
-                            part(s, 2), fused, s->spmv_nt);
-      else if (cheb_bits_eff(s) != 64 && s->d_B8 && !s->ar) {  // one polynomial-preconditioner step on the solver's
-        const size_t n = 3 * (size_t)N;                          // work vectors
+      else if (k == 3)  // the CG iteration's launch (beta from the reduction slots as in the solver; p ping-pongs)
+        launch_spmv_dir_dot(s->stream, N, d->inc(), s->d_H, s->d_zv, (r & 1) ? s->d_p2 : s->d_p, 0, part(s, 1), part(s, 0),
+                            fused ? ((r & 1) ? s->d_p : s->d_p2) : ((r & 1) ? s->d_p2 : s->d_p), s->d_q, part(s, 2), fused,
+                            s->spmv_nt);
+      else if (cheb_bits_eff(s) != 64 && s->d_B8 && !s->ar) {  // one step of the polynomial, buffers ping-pong as in
+        const size_t n = 3 * (size_t)N;                          // cheb_apply (each step reads what the last one wrote)
         float* f = s->d_f32;
-        launch_cheb32(s->stream, N, d->nnz_coef, d->inc(), s->d_B8, s->d_B1, cheb_bits_eff(s), f + 6 * n, s->d_sc, f,
-                      s->d_coef + 2, f + n, f + 2 * n, f + 3 * n, f + 4 * n, f + 5 * n, s->d_r, s->d_zv, part(s, 0), false);
+        const int a = r & 1, b = 1 - a;
+        launch_cheb32(s->stream, N, d->nnz_coef, d->inc(), s->d_B8, s->d_B1, cheb_bits_eff(s), f + 6 * n, s->d_sc,
+                      f + a * n, s->d_coef + 2, f + b * n, f + (2 + a) * n, f + (2 + b) * n, f + (4 + a) * n,
+                      f + (4 + b) * n, s->d_r, s->d_zv, part(s, 0), false);
       } else if (cheb_bits_eff(s) != 64 && s->d_B8)
         launch_cheb_lp(s->stream, N, d->nnz_coef, d->inc(), s->d_B8, s->d_B1, cheb_bits_eff(s), s->d_Dinv_s, s->d_sc,
                        s->d_cd, s->d_coef + 2, s->d_cd2, s->d_cz, s->d_cz2, s->d_cres, s->d_cres2, s->d_r, s->d_w, part(s, 0), 0);
-      else  // vectors (the coefficients are irrelevant to the time)
+      else  // fp64 polynomial step
         launch_cheb_step(s->stream, N, d->inc(), s->d_H, s->d_Dinv, s->d_cd, s->d_coef + 2, s->d_cd2, s->d_zv, s->d_cres,
                          s->d_r, s->d_w, part(s, 0), false);
     }
