@@ -134,7 +134,17 @@ int tlfea_ancf_setup(tlfea_t10_t h, const double *L, const double *W, const doub
                      const double *weight_xi, const double *weight_eta, const double *weight_zeta, const int *nq,
                      const double *x12, const double *y12, const double *z12, const int *conn_nodes,
                      int conn_is_colmajor);
-int tlfea_ancf_calc_dsdu_pre(tlfea_t10_t h); /* CalcDsDuPre  ANCF3243Data.cu:290-300, ANCF3443Data.cu:256-266 */
+int tlfea_ancf_calc_dsdu_pre(tlfea_t10_t h);
+/* SetLinearConstraintsCSR (ANCF3243Data.cuh:810-940, ANCF3443Data.cuh same member): general linear constraints
+ * c = J x - rhs, J in CSR over constraint rows, columns in the flattened DOF space (3*coef + component).  Accepted
+ * on every element kind.  Must be called before BuildMassCSRPattern / CalcMassMatrix: the Hessian pattern includes
+ * the coefficient pairs a row couples (SyncedNewton.cu:556-801).  Single-GPU path only. */
+int tlfea_t10_set_linear_constraints_csr(tlfea_t10_t h, int n_rows, const int *offsets, const int *columns,
+                                         const double *values, const double *rhs);
+/* GetConstraintMode (ANCF3243Data.cuh:436-441): 0 none, 1 kConstraintFixedCoefficients, 2 kConstraintLinearCSR */
+int tlfea_t10_get_constraint_mode(tlfea_t10_t h);
+/* nnz of J (sizes the buffers of tlfea_t10_retrieve_constraint_jac_csr / _jact_csr) */
+int tlfea_t10_constraint_jac_nnz(tlfea_t10_t h); /* CalcDsDuPre  ANCF3243Data.cu:290-300, ANCF3443Data.cu:256-266 */
 int tlfea_elem_dims(tlfea_t10_t h, int *S /*shape functions*/, int *Q /*force quadrature points*/);
 
 /* ---- SyncedNewtonSolver --------------------------------------------------------------------- */
@@ -176,6 +186,7 @@ int tlfea_newton_iteration(tlfea_newton_t s, double *norm_g, int *iters);
 int tlfea_newton_retrieve_gradient(tlfea_newton_t s, double *g /*3N*/);
 int tlfea_newton_retrieve_velocity(tlfea_newton_t s, double *v /*3N*/);
 int tlfea_newton_set_velocity(tlfea_newton_t s, const double *v /*3N*/, const double *v_prev /*3N or NULL*/);
+int tlfea_newton_set_lambda(tlfea_newton_t s, const double *lam /*n_constraints multipliers*/);
 int tlfea_newton_retrieve_lambda(tlfea_newton_t s, double *lam /*n_constraints*/);
 /* stats of the last tlfea_newton_solve(): [0] outer iterations, [1] Newton solves, [2] last ||g||,
  * [3] last ||c||, [4] total PCG iterations, [5] device ms of the step (hipEvent) */

@@ -337,6 +337,66 @@ class ElemOracle:
                           C.c_double(h), C.c_double(rho), dp(g))
         return g
 
+    # ---- general linear constraints c = J x - rhs (SetLinearConstraintsCSR) ----
+    def set_linear_constraints(self, offsets, columns, values, rhs):
+        self.j_off = np.ascontiguousarray(offsets, dtype=np.int32)
+        self.j_col = np.ascontiguousarray(columns, dtype=np.int32)
+        self.j_val = np.ascontiguousarray(values, dtype=np.float64)
+        self.j_rhs = np.ascontiguousarray(rhs, dtype=np.float64)
+        self.nc = len(self.j_rhs)
+        self.lam = np.zeros(self.nc)
+        self.fixed = np.zeros(0, dtype=np.int32)
+
+    def lin_adjacency(self):
+        self.L.orc_lin_adjacency.restype = C.c_int
+        off = np.zeros(self.N + 1, dtype=np.int32)
+        colp = c_ip()
+        nnz = self.L.orc_lin_adjacency(self.N, ip(self.m_off), ip(self.m_col), self.nc, ip(self.j_off), ip(self.j_col),
+                                       ip(off), C.byref(colp))
+        col = np.ctypeslib.as_array(colp, shape=(nnz,)).copy()
+        self.L.orc_free(colp)
+        return off, col
+
+    def lin_constraint(self):
+        c = np.zeros(self.nc)
+        self.L.orc_lin_constraint(self.nc, ip(self.j_off), ip(self.j_col), dp(self.j_val), dp(self.j_rhs), dp(self.x),
+                                  dp(self.y), dp(self.z), dp(c))
+        return c
+
+    def grad_L_lin(self, f_int, h, rho):
+        g = np.zeros(3 * self.N)
+        self.L.orc_grad_L(self.N, ip(self.m_off), ip(self.m_col), dp(self.m_val), dp(self.v), dp(self.v_prev),
+                          dp(f_int), dp(self.f_ext), None, 0, None, None, C.c_double(h), C.c_double(rho), dp(g))
+        c = self.lin_constraint()
+        self.L.orc_lin_grad_add(self.nc, ip(self.j_off), ip(self.j_col), dp(self.j_val), dp(c), dp(self.lam),
+                                C.c_double(h), C.c_double(rho), dp(g))
+        return g
+
+    def assemble_hessian_lin(self, h, rho):
+        ao, ac = self.lin_adjacency()
+        ro = np.zeros(3 * self.N + 1, dtype=np.int32)
+        ci = np.zeros(9 * len(ac), dtype=np.int32)
+        self.L.orc_hessian_pattern(self.N, ip(ao), ip(ac), ip(ro), ip(ci))
+        val = np.zeros(len(ci))
+        self.L.orc_gen_assemble_hessian_lin(self.S, self.Q, self.E, self.N, ip(self.conn_cm), dp(self.x), dp(self.y),
+                                            dp(self.z), dp(self.gradN), dp(self.detJ), dp(self.qw),
+                                            C.byref(self.mat), ip(self.m_off), ip(self.m_col), dp(self.m_val), ip(ao),
+                                            ip(ac), self.nc, ip(self.j_off), ip(self.j_col), dp(self.j_val),
+                                            C.c_double(h), C.c_double(rho), ip(ro), ip(ci), dp(val))
+        return ro, ci, val
+
+    def newton_step_lin(self, prm):
+        self.L.orc_gen_newton_step_lin.restype = C.c_int
+        stats = np.zeros(4)
+        rc = self.L.orc_gen_newton_step_lin(
+            self.S, self.Q, self.E, self.N, ip(self.conn_cm), dp(self.x), dp(self.y), dp(self.z), dp(self.gradN),
+            dp(self.detJ), dp(self.qw), C.byref(self.mat), ip(self.m_off), ip(self.m_col), dp(self.m_val), self.nc,
+            ip(self.j_off), ip(self.j_col), dp(self.j_val), dp(self.j_rhs), dp(self.f_ext), C.byref(prm), dp(self.v),
+            dp(self.v_prev), dp(self.lam), dp(stats))
+        if rc != 0:
+            raise RuntimeError("oracle: Cholesky failed (matrix not SPD)")
+        return stats
+
     def newton_step(self, prm):
         stats = np.zeros(4)
         rc = self.L.orc_gen_newton_step(

@@ -121,6 +121,28 @@ int orc_t10_newton_step(int E, int N, const int *conn, double *x, double *y, dou
                         const double *f_ext, const orc_newton_params *prm, double *v,
                         double *v_prev, double *lam, int solver, int nthreads, double *stats);
 
+/* ---- general linear constraints c = J x - rhs (kConstraintLinearCSR; ANCF3243Data.cuh:803-940,
+ * ANCF3243DataFunc.cuh:477-499, SyncedNewton.cu:292-341,377-404,556-801).  J: CSR over constraint rows, columns =
+ * 3*coef + component.  No reference run pins these (the Python prototypes have no such constraints): the restatement
+ * follows the cited lines and is cross-checked against the fixed-coefficient path (a pinned DOF written as a row). */
+int orc_lin_adjacency(int N, const int *mo, const int *mc, int nc, const int *joff, const int *jcol, int *offsets,
+                      int **columns);
+void orc_lin_constraint(int nc, const int *joff, const int *jcol, const double *jval, const double *rhs,
+                        const double *x, const double *y, const double *z, double *c);
+void orc_lin_grad_add(int nc, const int *joff, const int *jcol, const double *jval, const double *c,
+                      const double *lam, double h, double rho, double *g);
+void orc_gen_assemble_hessian_lin(int S, int Q, int E, int N, const int *conn, const double *x, const double *y,
+                                  const double *z, const double *gradN, const double *detJ, const double *qw,
+                                  const orc_material *mat, const int *mo, const int *mc, const double *mv,
+                                  const int *ao, const int *ac, int nc, const int *joff, const int *jcol,
+                                  const double *jval, double h, double rho, const int *ro, const int *ci,
+                                  double *val);
+int orc_gen_newton_step_lin(int S, int Q, int E, int N, const int *conn, double *x, double *y, double *z,
+                            const double *gradN, const double *detJ, const double *qw, const orc_material *mat,
+                            const int *mo, const int *mc, const double *mv, int nc, const int *joff, const int *jcol,
+                            const double *jval, const double *rhs, const double *f_ext,
+                            const orc_newton_params *prm, double *v, double *v_prev, double *lam, double *stats);
+
 #ifdef __cplusplus
 }
 #endif

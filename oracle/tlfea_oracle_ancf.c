@@ -375,12 +375,12 @@ int orc_gen_mass_pattern(int S, int E, int N, const int *conn, int *offsets, int
   return (int)nnz;
 }
 
-/* H = M/h + h K + C_vis + h^2 rho J^T J for fixed-coefficient constraints (SyncedNewton.cu:214-341) */
-void orc_gen_assemble_hessian(int S, int Q, int E, int N, const int *conn, const double *x, const double *y,
+/* M/h + h K + C_vis on a DOF-level pattern (ro, ci) expanded from the coefficient adjacency (ao, ac); the mass
+ * CSR (mo, mc, mv) may be a subset of that adjacency (constraint-aware pattern)  (SyncedNewton.cu:214-290) */
+static void gen_assemble_core(int S, int Q, int E, int N, const int *conn, const double *x, const double *y,
                               const double *z, const double *gradN, const double *detJ, const double *qw,
                               const orc_material *mat, const int *mo, const int *mc, const double *mv,
-                              const int *fixed, int n_fixed, double h, double rho, const int *ro, const int *ci,
-                              double *val) {
+                              const int *ao, const int *ac, double h, const int *ro, const int *ci, double *val) {
   const int n = 3 * S;
   memset(val, 0, sizeof(double) * (size_t)ro[3 * N]);
   for (int ni = 0; ni < N; ni++)
@@ -396,7 +396,7 @@ void orc_gen_assemble_hessian(int S, int Q, int E, int N, const int *conn, const
     int gn[SMAX], pos[SMAX][SMAX];
     double xn[3 * SMAX];
     for (int a = 0; a < S; a++) { gn[a] = conn[(size_t)a * E + e]; xn[3 * a] = x[gn[a]]; xn[3 * a + 1] = y[gn[a]]; xn[3 * a + 2] = z[gn[a]]; }
-    for (int a = 0; a < S; a++) for (int b = 0; b < S; b++) pos[a][b] = bsearch_i(mc + mo[gn[a]], mo[gn[a] + 1] - mo[gn[a]], gn[b]);
+    for (int a = 0; a < S; a++) for (int b = 0; b < S; b++) pos[a][b] = bsearch_i(ac + ao[gn[a]], ao[gn[a] + 1] - ao[gn[a]], gn[b]);
     for (int q = 0; q < Q; q++) {
       qp_tangent(S, xn, gradN + ((size_t)e * Q + q) * 3 * S, detJ[(size_t)e * Q + q] * qw[q], mat, K, C, want_vis);
       for (int a = 0; a < S; a++) for (int d = 0; d < 3; d++) {
@@ -410,11 +410,139 @@ void orc_gen_assemble_hessian(int S, int Q, int E, int N, const int *conn, const
     }
   }
   free(K); free(C);
+}
+
+/* H = M/h + h K + C_vis + h^2 rho J^T J for fixed-coefficient constraints (SyncedNewton.cu:214-341) */
+void orc_gen_assemble_hessian(int S, int Q, int E, int N, const int *conn, const double *x, const double *y,
+                              const double *z, const double *gradN, const double *detJ, const double *qw,
+                              const orc_material *mat, const int *mo, const int *mc, const double *mv,
+                              const int *fixed, int n_fixed, double h, double rho, const int *ro, const int *ci,
+                              double *val) {
+  gen_assemble_core(S, Q, E, N, conn, x, y, z, gradN, detJ, qw, mat, mo, mc, mv, mo, mc, h, ro, ci, val);
   for (int k = 0; k < 3 * n_fixed; k++) {
     const int dof = fixed[k / 3] * 3 + k % 3;
     const int p = bsearch_i(ci + ro[dof], ro[dof + 1] - ro[dof], dof);
     if (p >= 0) val[ro[dof] + p] += h * h * rho;
   }
+}
+
+/* ---- general linear constraints  c = J x - rhs  (kConstraintLinearCSR) ------------------------------------
+ * J: CSR over constraint rows, columns = 3*coef + component (ANCF3243Data.cuh:803-940). */
+
+/* Constraint-aware coefficient adjacency (SyncedNewton.cu:571-630): {i} + mass row i + every pair of coefficients
+ * that share a constraint row; sorted unique.  Returns nnz, *columns malloc'ed. */
+int orc_lin_adjacency(int N, const int *mo, const int *mc, int nc, const int *joff, const int *jcol, int *offsets,
+                      int **columns) {
+  size_t total = (size_t)N + (size_t)mo[N];
+  for (int r = 0; r < nc; r++) { size_t m = (size_t)(joff[r + 1] - joff[r]); total += m * m; }
+  uint64_t *keys = (uint64_t *)malloc((total ? total : 1) * sizeof(uint64_t));
+  size_t n = 0, nnz = 0;
+  for (int i = 0; i < N; i++) {
+    keys[n++] = ((uint64_t)(uint32_t)i << 32) | (uint32_t)i;
+    for (int k = mo[i]; k < mo[i + 1]; k++) keys[n++] = ((uint64_t)(uint32_t)i << 32) | (uint32_t)mc[k];
+  }
+  for (int r = 0; r < nc; r++)
+    for (int a = joff[r]; a < joff[r + 1]; a++)
+      for (int b = joff[r]; b < joff[r + 1]; b++)
+        keys[n++] = ((uint64_t)(uint32_t)(jcol[a] / 3) << 32) | (uint32_t)(jcol[b] / 3);
+  qsort(keys, n, sizeof(uint64_t), cmp_u64);
+  for (size_t k = 0; k < n; k++) if (k == 0 || keys[k] != keys[k - 1]) keys[nnz++] = keys[k];
+  int *cols = (int *)malloc((nnz ? nnz : 1) * sizeof(int));
+  memset(offsets, 0, sizeof(int) * ((size_t)N + 1));
+  for (size_t k = 0; k < nnz; k++) { cols[k] = (int)(keys[k] & 0xffffffffULL); offsets[(keys[k] >> 32) + 1]++; }
+  for (int i = 0; i < N; i++) offsets[i + 1] += offsets[i];
+  free(keys);
+  *columns = cols;
+  return (int)nnz;
+}
+
+/* c = J x - rhs  (ANCF3243DataFunc.cuh:477-499) */
+void orc_lin_constraint(int nc, const int *joff, const int *jcol, const double *jval, const double *rhs,
+                        const double *x, const double *y, const double *z, double *c) {
+  for (int r = 0; r < nc; r++) {
+    double sum = 0.0;
+    for (int k = joff[r]; k < joff[r + 1]; k++) {
+      const int coef = jcol[k] / 3, comp = jcol[k] % 3;
+      sum += jval[k] * (comp == 0 ? x[coef] : (comp == 1 ? y[coef] : z[coef]));
+    }
+    c[r] = sum - rhs[r];
+  }
+}
+
+/* g += h J^T (lam + rho c)  (SyncedNewton.cu:377-404; rows visited in ascending constraint id per DOF) */
+void orc_lin_grad_add(int nc, const int *joff, const int *jcol, const double *jval, const double *c,
+                      const double *lam, double h, double rho, double *g) {
+  for (int r = 0; r < nc; r++)
+    for (int k = joff[r]; k < joff[r + 1]; k++) g[jcol[k]] += h * jval[k] * (lam[r] + rho * c[r]);
+}
+
+/* H = M/h + h K + C_vis + h^2 rho J^T J on the constraint-aware pattern (SyncedNewton.cu:292-341) */
+void orc_gen_assemble_hessian_lin(int S, int Q, int E, int N, const int *conn, const double *x, const double *y,
+                                  const double *z, const double *gradN, const double *detJ, const double *qw,
+                                  const orc_material *mat, const int *mo, const int *mc, const double *mv,
+                                  const int *ao, const int *ac, int nc, const int *joff, const int *jcol,
+                                  const double *jval, double h, double rho, const int *ro, const int *ci,
+                                  double *val) {
+  gen_assemble_core(S, Q, E, N, conn, x, y, z, gradN, detJ, qw, mat, mo, mc, mv, ao, ac, h, ro, ci, val);
+  const double f = h * h * rho;
+  for (int r = 0; r < nc; r++)
+    for (int a = joff[r]; a < joff[r + 1]; a++)
+      for (int b = joff[r]; b < joff[r + 1]; b++) {
+        const int di = jcol[a], dj = jcol[b];
+        const int p = bsearch_i(ci + ro[di], ro[di + 1] - ro[di], dj);
+        if (p >= 0) val[ro[di] + p] += f * jval[a] * jval[b];
+      }
+}
+
+/* One implicit step with general linear constraints (the same ALM/Newton loop, SyncedNewton.cu:1147-1376, with
+ * compute_constraint_data in linear-CSR mode). lam has nc entries. */
+int orc_gen_newton_step_lin(int S, int Q, int E, int N, const int *conn, double *x, double *y, double *z,
+                            const double *gradN, const double *detJ, const double *qw, const orc_material *mat,
+                            const int *mo, const int *mc, const double *mv, int nc, const int *joff, const int *jcol,
+                            const double *jval, const double *rhs, const double *f_ext,
+                            const orc_newton_params *prm, double *v, double *v_prev, double *lam, double *stats) {
+  const int n = 3 * N;
+  const double h = prm->time_step, rho = prm->rho;
+  int *ao = (int *)malloc(sizeof(int) * ((size_t)N + 1)), *ac = NULL;
+  const int annz = orc_lin_adjacency(N, mo, mc, nc, joff, jcol, ao, &ac);
+  int *ro = (int *)malloc(sizeof(int) * (n + 1)), *ci = (int *)malloc(sizeof(int) * 9 * (size_t)annz);
+  orc_hessian_pattern(N, ao, ac, ro, ci);
+  double *H = (double *)malloc(sizeof(double) * (size_t)ro[n]), *xp = (double *)malloc(sizeof(double) * n);
+  double *P = (double *)malloc(sizeof(double) * 9 * (size_t)E * Q), *f_int = (double *)malloc(sizeof(double) * n);
+  double *g = (double *)malloc(sizeof(double) * n), *r = (double *)malloc(sizeof(double) * n), *dv = (double *)malloc(sizeof(double) * n);
+  double *c = (double *)calloc(nc > 0 ? nc : 1, sizeof(double));
+  memcpy(xp, x, sizeof(double) * N); memcpy(xp + N, y, sizeof(double) * N); memcpy(xp + 2 * N, z, sizeof(double) * N);
+  int status = 0, n_outer = 0, n_newton = 0;
+  double ng = 0, ncn = 0;
+  for (int outer = 0; outer < prm->max_outer && !status; outer++) {
+    n_outer++;
+    double ng0 = -1.0;
+    for (int it = 0; it < prm->max_inner; it++) {
+      orc_gen_compute_p(S, Q, E, conn, x, y, z, v, gradN, mat, NULL, P);
+      orc_gen_internal_force(S, Q, E, N, conn, P, gradN, detJ, qw, f_int);
+      orc_lin_constraint(nc, joff, jcol, jval, rhs, x, y, z, c);
+      orc_grad_L(N, mo, mc, mv, v, v_prev, f_int, f_ext, NULL, 0, NULL, NULL, h, rho, g);
+      orc_lin_grad_add(nc, joff, jcol, jval, c, lam, h, rho, g);
+      ng = 0; for (int i = 0; i < n; i++) ng += g[i] * g[i]; ng = sqrt(ng);
+      if (ng0 < 0) ng0 = ng;
+      if (ng < prm->inner_atol || (prm->inner_rtol > 0 && ng0 > 0 && ng <= prm->inner_rtol * ng0)) break;
+      for (int i = 0; i < n; i++) r[i] = -g[i];
+      orc_gen_assemble_hessian_lin(S, Q, E, N, conn, x, y, z, gradN, detJ, qw, mat, mo, mc, mv, ao, ac, nc, joff, jcol,
+                                   jval, h, rho, ro, ci, H);
+      status = orc_solve_spd_upper(n, ro, ci, H, r, dv);
+      if (status) break;
+      n_newton++;
+      for (int i = 0; i < n; i++) v[i] += dv[i];
+      for (int i = 0; i < N; i++) { x[i] = xp[i] + v[3 * i] * h; y[i] = xp[N + i] + v[3 * i + 1] * h; z[i] = xp[2 * N + i] + v[3 * i + 2] * h; }
+    }
+    memcpy(v_prev, v, sizeof(double) * n);
+    orc_lin_constraint(nc, joff, jcol, jval, rhs, x, y, z, c);
+    for (int k = 0; k < nc; k++) lam[k] += rho * c[k];
+    if (nc > 0) { ncn = 0; for (int k = 0; k < nc; k++) ncn += c[k] * c[k]; ncn = sqrt(ncn); if (ncn < prm->outer_tol) break; }
+  }
+  if (stats) { stats[0] = n_outer; stats[1] = n_newton; stats[2] = ng; stats[3] = ncn; }
+  free(ao); free(ac); free(ro); free(ci); free(H); free(xp); free(P); free(f_int); free(g); free(r); free(dv); free(c);
+  return status;
 }
 
 /* One implicit step for any element type with fixed-coefficient constraints (SyncedNewton.cu:1147-1261 is the

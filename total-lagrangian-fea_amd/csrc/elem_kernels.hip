@@ -409,6 +409,90 @@ void launch_constraint(hipStream_t s, int n_fixed, const int* fixed_nodes, const
                      xt, yt, zt, cons);
 }
 
+// ---- general linear constraints  c = J x - rhs  (ANCF3243DataFunc.cuh:477-499) ------------------------------
+// J is CSR over constraint rows with columns in the flattened DOF space (3*coef + component).
+__global__ void lin_constraint_kernel(int nc, const int* __restrict__ joff, const int* __restrict__ jcol,
+                                      const double* __restrict__ jval, const double* __restrict__ rhs,
+                                      const double* __restrict__ x, const double* __restrict__ y,
+                                      const double* __restrict__ z, double* __restrict__ c) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= nc) return;
+  double sum = 0.0;
+  for (int k = joff[r]; k < joff[r + 1]; k++) {
+    const int col = jcol[k], coef = col / 3, comp = col - 3 * coef;
+    const double v = comp == 0 ? x[coef] : (comp == 1 ? y[coef] : z[coef]);
+    sum += jval[k] * v;
+  }
+  c[r] = sum - rhs[r];
+}
+void launch_lin_constraint(hipStream_t s, int nc, const int* joff, const int* jcol, const double* jval,
+                           const double* rhs, const double* x, const double* y, const double* z, double* c) {
+  if (nc <= 0) return;
+  hipLaunchKernelGGL(lin_constraint_kernel, dim3((nc + 255) / 256), dim3(256), 0, s, nc, joff, jcol, jval, rhs, x, y, z, c);
+}
+
+// g[dof] += h * sum_k J^T[dof][k] (lambda_k + rho c_k)   (SyncedNewton.cu:377-404); J^T is CSR over DOF rows, its
+// entries in ascending constraint id (fixed summation order)
+__global__ void lin_constraint_grad_kernel(int ndof, const int* __restrict__ jtoff, const int* __restrict__ jtcol,
+                                           const double* __restrict__ jtval, const double* __restrict__ lam,
+                                           const double* __restrict__ c, double h, double rho,
+                                           double* __restrict__ g) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= ndof) return;
+  const int a = jtoff[i], b = jtoff[i + 1];
+  if (a == b) return;
+  double sum = 0.0;
+  for (int k = a; k < b; k++) {
+    const int r = jtcol[k];
+    sum += jtval[k] * (lam[r] + rho * c[r]);
+  }
+  g[i] += h * sum;
+}
+void launch_lin_constraint_grad(hipStream_t s, int ndof, const int* jtoff, const int* jtcol, const double* jtval,
+                                const double* lam, const double* c, double h, double rho, double* g) {
+  hipLaunchKernelGGL(lin_constraint_grad_kernel, dim3((ndof + 255) / 256), dim3(256), 0, s, ndof, jtoff, jtcol, jtval,
+                     lam, c, h, rho, g);
+}
+
+// H += h^2 rho J^T J  (assemble_sparse_hessian_constraints, SyncedNewton.cu:292-341).  The reference scatters per
+// constraint row with atomics; here ONE thread owns one DOF row of H (no atomics, fixed order): for every constraint
+// r in the row's J^T list, for every entry (dof_j, J_rj) of J's row r:  H[i][dof_j] += f J_ri J_rj.
+// H layout: node row n = i/3, component d = i%3: value (d, k, e) at 9 off[n] + d*3deg + 3k + e, k = position of
+// coefficient dof_j/3 in the node's sorted column list (the constraint-aware pattern holds every such pair).
+__global__ void lin_constraint_hessian_kernel(int ndof, const int* __restrict__ jtoff, const int* __restrict__ jtcol,
+                                              const double* __restrict__ jtval, const int* __restrict__ joff,
+                                              const int* __restrict__ jcol, const double* __restrict__ jval,
+                                              const int* __restrict__ off, const int* __restrict__ cols, double f,
+                                              double* __restrict__ H) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= ndof) return;
+  const int a = jtoff[i], b = jtoff[i + 1];
+  if (a == b) return;
+  const int n = i / 3, d = i - 3 * n;
+  const int o = off[n], deg = off[n + 1] - o;
+  double* Hrow = H + (size_t)9 * o + (size_t)d * 3 * deg;
+  for (int k = a; k < b; k++) {
+    const int r = jtcol[k];
+    const double Jri = jtval[k];
+    for (int m = joff[r]; m < joff[r + 1]; m++) {
+      const int dj = jcol[m], cj = dj / 3, e = dj - 3 * cj;
+      int lo = 0, hi = deg;  // lower_bound in the sorted column list
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (cols[o + mid] < cj) lo = mid + 1;
+        else hi = mid;
+      }
+      if (lo < deg && cols[o + lo] == cj) Hrow[3 * lo + e] += f * Jri * jval[m];
+    }
+  }
+}
+void launch_lin_constraint_hessian(hipStream_t s, int ndof, const int* jtoff, const int* jtcol, const double* jtval,
+                                   const int* joff, const int* jcol, const double* jval, const int* off,
+                                   const int* cols, double f, double* H) {
+  hipLaunchKernelGGL(lin_constraint_hessian_kernel, dim3((ndof + 255) / 256), dim3(256), 0, s, ndof, jtoff, jtcol, jtval,
+                     joff, jcol, jval, off, cols, f, H);
+}
+
 // Fused: f_int gather + constraints + grad L (SyncedNewton.cu:344-407).  A 32-lane half-wave per coefficient
 // row: lanes walk the mass row (coalesced values / columns, gathered velocities) and the row's element force
 // rows, then a fixed-order butterfly sums the six partials (deterministic).

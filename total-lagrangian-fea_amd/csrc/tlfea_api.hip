@@ -71,6 +71,16 @@ struct tlfea_t10_s {  // any element type; the name is kept for the ABI's first 
   double* d_cons = nullptr;
   int *d_fixed = nullptr, *d_fixed_slot = nullptr;
   std::vector<int> h_fixed;
+  // constraint mode: 0 none, 1 fixed coefficients (SetNodalFixed), 2 general linear rows (SetLinearConstraintsCSR);
+  // mode 2 keeps J (rows = constraints) and J^T (rows = DOFs, entries in ascending constraint id) in CSR
+  int cons_mode = 0;
+  std::vector<int> h_joff, h_jcol, h_jtoff, h_jtcol;
+  std::vector<double> h_jval, h_jtval, h_rhs;
+  int *d_joff = nullptr, *d_jcol = nullptr, *d_jtoff = nullptr, *d_jtcol = nullptr;
+  double *d_jval = nullptr, *d_jtval = nullptr, *d_rhs = nullptr;
+  // entries of the coefficient adjacency that exist only through a constraint row (not part of the mass pattern)
+  std::vector<char> h_extra;
+  int nnz_mass = 0;
   // sparsity (host copies are kept: the solver and the retrieve calls need them)
   std::vector<int> h_conn, h_off, h_cols, h_n2e_off, h_n2e;
   int *d_off = nullptr, *d_cols = nullptr, *d_n2e_off = nullptr, *d_n2e = nullptr, *d_n2e_pos = nullptr,
@@ -151,7 +161,8 @@ extern "C" int tlfea_t10_destroy(tlfea_t10_t h) {
   void* ptrs[] = {h->d_conn, h->d_x, h->d_y, h->d_z, h->d_xt, h->d_yt, h->d_zt, h->d_qx, h->d_qy, h->d_qz,
                   h->d_gradN, h->d_gradN_t, h->d_detJ, h->d_F, h->d_P, h->d_Fdot, h->d_Pvis, h->d_fbuf, h->d_fint,
                   h->d_fext, h->d_cons, h->d_fixed, h->d_fixed_slot, h->d_off, h->d_cols, h->d_n2e_off, h->d_n2e,
-                  h->d_n2e_pos, h->d_diagpos, h->d_mval};
+                  h->d_n2e_pos, h->d_diagpos, h->d_mval, h->d_joff, h->d_jcol, h->d_jtoff, h->d_jtcol, h->d_jval,
+                  h->d_jtval, h->d_rhs};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   delete h;
@@ -249,6 +260,7 @@ static int upload_fixed(tlfea_t10_t h, const int* nodes, int n_fixed) {
   if (n_fixed) HIP_TRY(hipMemcpy(h->d_fixed, nodes, (size_t)n_fixed * sizeof(int), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(h->d_fixed_slot, slot.data(), (size_t)h->N * sizeof(int), hipMemcpyHostToDevice));
   h->is_constraints_setup = true;
+  h->cons_mode = 1;
   h->is_j_csr_setup = h->is_cj_csr_setup = false;
   return 0;
 }
@@ -262,6 +274,74 @@ extern "C" int tlfea_t10_update_nodal_fixed(tlfea_t10_t h, const int* nodes, int
   if (!h) return fail("null handle");
   return upload_fixed(h, nodes, n_fixed);
 }
+// SetLinearConstraintsCSR (ANCF3243Data.cuh:810-940, ANCF3443Data.cuh same): c = J x - rhs over the flattened DOF
+// vector (3*coef + component).  Uploads J and builds J^T (counting sort by column: entries of a DOF row stay in
+// ascending constraint id, as the reference builds it).
+extern "C" int tlfea_t10_set_linear_constraints_csr(tlfea_t10_t h, int n_rows, const int* offsets, const int* columns,
+                                                    const double* values, const double* rhs) {
+  if (!h) return fail("null handle");
+  if (h->is_constraints_setup) return fail("CONSTRAINT is already set up.");
+  if (n_rows < 0 || !offsets || offsets[0] != 0) return fail("SetLinearConstraintsCSR: invalid offsets.");
+  const int nnz = offsets[n_rows];
+  for (int r = 0; r < n_rows; r++)
+    if (offsets[r + 1] < offsets[r]) return fail("SetLinearConstraintsCSR: invalid offsets.");
+  const int n_dofs = 3 * h->N;
+  for (int k = 0; k < nnz; k++)
+    if (columns[k] < 0 || columns[k] >= n_dofs) return fail("SetLinearConstraintsCSR: column out of range.");
+  // the coefficient adjacency (mass / Hessian pattern) must include the pairs a constraint row couples
+  if (h->is_csr_setup)
+    return fail("SetLinearConstraintsCSR must precede BuildMassCSRPattern / CalcMassMatrix (the Hessian pattern "
+                "includes the coefficient pairs coupled by constraint rows)");
+  h->n_fixed = 0;
+  h->n_constraint = n_rows;
+  h->cons_mode = 2;
+  h->h_joff.assign(offsets, offsets + n_rows + 1);
+  h->h_jcol.assign(columns, columns + nnz);
+  h->h_jval.assign(values, values + nnz);
+  h->h_rhs.assign(rhs, rhs + n_rows);
+  h->h_jtoff.assign((size_t)n_dofs + 1, 0);
+  h->h_jtcol.assign((size_t)nnz, 0);
+  h->h_jtval.assign((size_t)nnz, 0.0);
+  for (int k = 0; k < nnz; k++) h->h_jtoff[(size_t)columns[k] + 1]++;
+  for (int i = 0; i < n_dofs; i++) h->h_jtoff[(size_t)i + 1] += h->h_jtoff[i];
+  {
+    std::vector<int> cur(h->h_jtoff.begin(), h->h_jtoff.end() - 1);
+    for (int r = 0; r < n_rows; r++)
+      for (int k = offsets[r]; k < offsets[r + 1]; k++) {
+        const int o = cur[columns[k]]++;
+        h->h_jtcol[o] = r;
+        h->h_jtval[o] = values[k];
+      }
+  }
+  TRY(dmalloc(&h->d_cons, (size_t)std::max(1, n_rows)));
+  HIP_TRY(hipMemset(h->d_cons, 0, (size_t)std::max(1, n_rows) * sizeof(double)));
+  TRY(dmalloc(&h->d_rhs, (size_t)std::max(1, n_rows)));
+  TRY(dmalloc(&h->d_joff, (size_t)n_rows + 1));
+  TRY(dmalloc(&h->d_jcol, (size_t)std::max(1, nnz)));
+  TRY(dmalloc(&h->d_jval, (size_t)std::max(1, nnz)));
+  TRY(dmalloc(&h->d_jtoff, (size_t)n_dofs + 1));
+  TRY(dmalloc(&h->d_jtcol, (size_t)std::max(1, nnz)));
+  TRY(dmalloc(&h->d_jtval, (size_t)std::max(1, nnz)));
+  if (n_rows) HIP_TRY(hipMemcpy(h->d_rhs, rhs, (size_t)n_rows * sizeof(double), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(h->d_joff, offsets, ((size_t)n_rows + 1) * sizeof(int), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(h->d_jtoff, h->h_jtoff.data(), ((size_t)n_dofs + 1) * sizeof(int), hipMemcpyHostToDevice));
+  if (nnz) {
+    HIP_TRY(hipMemcpy(h->d_jcol, columns, (size_t)nnz * sizeof(int), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->d_jval, values, (size_t)nnz * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->d_jtcol, h->h_jtcol.data(), (size_t)nnz * sizeof(int), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->d_jtval, h->h_jtval.data(), (size_t)nnz * sizeof(double), hipMemcpyHostToDevice));
+  }
+  h->is_j_csr_setup = h->is_cj_csr_setup = true;
+  h->is_constraints_setup = true;
+  return 0;
+}
+// GetConstraintMode: 0 none, 1 kConstraintFixedCoefficients, 2 kConstraintLinearCSR
+extern "C" int tlfea_t10_get_constraint_mode(tlfea_t10_t h) { return h ? h->cons_mode : -1; }
+extern "C" int tlfea_t10_constraint_jac_nnz(tlfea_t10_t h) {
+  if (!h || !h->is_constraints_setup) return 0;
+  return h->cons_mode == 2 ? (int)h->h_jcol.size() : h->n_constraint;
+}
+
 extern "C" int tlfea_t10_update_positions(tlfea_t10_t h, const double* x, const double* y, const double* z, int n) {
   if (!h || n != h->N) return fail("Position vector size mismatch.");
   HIP_TRY(hipMemcpy(h->d_x, x, (size_t)n * sizeof(double), hipMemcpyHostToDevice));
@@ -309,22 +389,56 @@ extern "C" int tlfea_t10_build_mass_csr_pattern(tlfea_t10_t h) {
     for (int e = 0; e < E; e++)  // ascending e per node -> fixed summation order
       for (int a = 0; a < S; a++) n2e[cur[conn[(size_t)a * E + e]]++] = e * S + a;
   }
-  std::vector<int> deg(N, 0);
-  std::vector<std::vector<int>> rows;  // per-thread scratch would be enough, keep it simple & parallel
+  // coefficient pairs coupled by a general linear constraint row are adjacent too (SyncedNewton.cu:597-624):
+  // J^T J fills their 3x3 blocks.  cadj = per-coefficient list of such partners (CSR, unsorted, with duplicates).
+  std::vector<int> cadj_off(N + 1, 0), cadj;
+  if (h->cons_mode == 2 && h->n_constraint > 0) {
+    std::vector<int> row_coefs;
+    for (int pass = 0; pass < 2; pass++) {
+      std::vector<int> cur(cadj_off.begin(), cadj_off.end() - 1);
+      for (int r = 0; r < h->n_constraint; r++) {
+        row_coefs.clear();
+        for (int k = h->h_joff[r]; k < h->h_joff[r + 1]; k++) row_coefs.push_back(h->h_jcol[k] / 3);
+        std::sort(row_coefs.begin(), row_coefs.end());
+        row_coefs.erase(std::unique(row_coefs.begin(), row_coefs.end()), row_coefs.end());
+        for (int a : row_coefs)
+          for (int b : row_coefs) {
+            if (pass == 0) cadj_off[a + 1]++;
+            else cadj[cur[a]++] = b;
+          }
+      }
+      if (pass == 0) {
+        for (int i = 0; i < N; i++) cadj_off[i + 1] += cadj_off[i];
+        cadj.assign((size_t)cadj_off[N], 0);
+      }
+    }
+  }
+  std::vector<int> deg(N, 0), deg_elem(N, 0);
   h->h_off.assign(N + 1, 0);
-  std::vector<int> tmp_cols((size_t)E * S * S);  // upper bound, compacted below
   std::vector<size_t> tmp_off(N + 1, 0);
-  for (int i = 0; i < N; i++) tmp_off[i + 1] = tmp_off[i] + (size_t)(n2e_off[i + 1] - n2e_off[i]) * S;
+  for (int i = 0; i < N; i++)
+    tmp_off[i + 1] = tmp_off[i] + (size_t)(n2e_off[i + 1] - n2e_off[i]) * S + (size_t)(cadj_off[i + 1] - cadj_off[i]) + 1;
+  std::vector<int> tmp_cols(tmp_off[N]), tmp_elem(tmp_off[N]);  // upper bounds, compacted below
 #pragma omp parallel for schedule(dynamic, 1024)
   for (int i = 0; i < N; i++) {
     int* c = tmp_cols.data() + tmp_off[i];
+    int* ce = tmp_elem.data() + tmp_off[i];
     int n = 0;
     for (int k = n2e_off[i]; k < n2e_off[i + 1]; k++) {
       const int e = n2e[k] / S;
       for (int a = 0; a < S; a++) c[n++] = conn[(size_t)a * E + e];
     }
     std::sort(c, c + n);
-    deg[i] = (int)(std::unique(c, c + n) - c);
+    n = (int)(std::unique(c, c + n) - c);
+    std::copy(c, c + n, ce);  // the element-only adjacency == mass pattern
+    deg_elem[i] = n;
+    if (cadj_off[i + 1] > cadj_off[i]) {
+      for (int k = cadj_off[i]; k < cadj_off[i + 1]; k++) c[n++] = cadj[k];
+      c[n++] = i;  // the reference seeds every row with its diagonal (SyncedNewton.cu:577-580)
+      std::sort(c, c + n);
+      n = (int)(std::unique(c, c + n) - c);
+    }
+    deg[i] = n;
   }
   long long nnz = 0;
   int maxdeg = 0;
@@ -338,12 +452,21 @@ extern "C" int tlfea_t10_build_mass_csr_pattern(tlfea_t10_t h) {
   h->nnz_coef = (int)nnz;
   h->maxdeg = maxdeg;
   h->h_cols.resize((size_t)nnz);
+  h->h_extra.assign((size_t)nnz, 0);
   std::vector<int> pos((size_t)E * S * S), diagpos(N, 0);
-#pragma omp parallel for schedule(dynamic, 1024)
+  long long n_extra = 0;
+#pragma omp parallel for schedule(dynamic, 1024) reduction(+ : n_extra)
   for (int i = 0; i < N; i++) {
     const int* c = tmp_cols.data() + tmp_off[i];
+    const int* ce = tmp_elem.data() + tmp_off[i];
     int* dst = h->h_cols.data() + h->h_off[i];
     std::copy(c, c + deg[i], dst);
+    if (deg[i] != deg_elem[i])
+      for (int k = 0; k < deg[i]; k++)
+        if (!std::binary_search(ce, ce + deg_elem[i], dst[k])) {
+          h->h_extra[(size_t)h->h_off[i] + k] = 1;
+          n_extra++;
+        }
     diagpos[i] = (int)(std::lower_bound(dst, dst + deg[i], i) - dst);
     for (int k = n2e_off[i]; k < n2e_off[i + 1]; k++) {
       const int e = n2e[k] / S;
@@ -351,6 +474,7 @@ extern "C" int tlfea_t10_build_mass_csr_pattern(tlfea_t10_t h) {
         pos[(size_t)k * S + a] = (int)(std::lower_bound(dst, dst + deg[i], conn[(size_t)a * E + e]) - dst);
     }
   }
+  h->nnz_mass = (int)(nnz - n_extra);
   TRY(dmalloc(&h->d_off, (size_t)N + 1));
   TRY(dmalloc(&h->d_cols, (size_t)nnz));
   TRY(dmalloc(&h->d_n2e_off, (size_t)N + 1));
@@ -525,7 +649,11 @@ static int ancf_mass_host(tlfea_t10_t h) {
 extern "C" int tlfea_t10_calc_constraint_data(tlfea_t10_t h) {
   if (!h || !h->is_constraints_setup) return fail("constraint is not set up");
   if (h->n_constraint == 0) return 0;
-  launch_constraint(h->stream, h->n_fixed, h->d_fixed, h->d_x, h->d_y, h->d_z, h->d_xt, h->d_yt, h->d_zt, h->d_cons);
+  if (h->cons_mode == 2)
+    launch_lin_constraint(h->stream, h->n_constraint, h->d_joff, h->d_jcol, h->d_jval, h->d_rhs, h->d_x, h->d_y, h->d_z,
+                          h->d_cons);
+  else
+    launch_constraint(h->stream, h->n_fixed, h->d_fixed, h->d_x, h->d_y, h->d_z, h->d_xt, h->d_yt, h->d_zt, h->d_cons);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipDeviceSynchronize());
   return 0;
@@ -584,7 +712,7 @@ extern "C" int tlfea_t10_is_constraint_setup(tlfea_t10_t h) { return h && h->is_
 
 extern "C" int tlfea_t10_mass_csr_nnz(tlfea_t10_t h, int* nnz) {
   if (!h || !nnz) return fail("null argument");
-  *nnz = h->is_csr_setup ? h->nnz_coef : 0;
+  *nnz = h->is_csr_setup ? h->nnz_mass : 0;
   return 0;
 }
 extern "C" int tlfea_t10_retrieve_mass_csr(tlfea_t10_t h, int* offsets, int* columns, double* values) {
@@ -593,9 +721,25 @@ extern "C" int tlfea_t10_retrieve_mass_csr(tlfea_t10_t h, int* offsets, int* col
     std::fill(offsets, offsets + h->N + 1, 0);
     return 0;
   }
-  std::copy(h->h_off.begin(), h->h_off.end(), offsets);
-  std::copy(h->h_cols.begin(), h->h_cols.end(), columns);
-  HIP_TRY(hipMemcpy(values, h->d_mval, (size_t)h->nnz_coef * sizeof(double), hipMemcpyDeviceToHost));
+  if (h->nnz_mass == h->nnz_coef) {
+    std::copy(h->h_off.begin(), h->h_off.end(), offsets);
+    std::copy(h->h_cols.begin(), h->h_cols.end(), columns);
+    HIP_TRY(hipMemcpy(values, h->d_mval, (size_t)h->nnz_coef * sizeof(double), hipMemcpyDeviceToHost));
+    return 0;
+  }
+  // the internal adjacency also holds the pairs coupled by constraint rows; the mass CSR is the element part only
+  std::vector<double> mv((size_t)h->nnz_coef);
+  HIP_TRY(hipMemcpy(mv.data(), h->d_mval, mv.size() * sizeof(double), hipMemcpyDeviceToHost));
+  int o = 0;
+  for (int i = 0; i < h->N; i++) {
+    offsets[i] = o;
+    for (int k = h->h_off[i]; k < h->h_off[i + 1]; k++)
+      if (!h->h_extra[k]) {
+        columns[o] = h->h_cols[k];
+        values[o++] = mv[k];
+      }
+  }
+  offsets[h->N] = o;
   return 0;
 }
 #define D2H(dst, src, n) HIP_TRY(hipMemcpy(dst, src, (size_t)(n) * sizeof(*(dst)), hipMemcpyDeviceToHost))
@@ -625,6 +769,12 @@ extern "C" int tlfea_t10_retrieve_constraint_data(tlfea_t10_t h, double* c) {
 }
 extern "C" int tlfea_t10_retrieve_constraint_jac_csr(tlfea_t10_t h, int* offsets, int* columns, double* values) {
   if (!h->is_constraints_setup) return fail("constraint is not set up");
+  if (h->cons_mode == 2) {  // RetrieveConstraintJacobianCSRToCPU (ANCF3243Data.cuh:1056-1091)
+    std::copy(h->h_joff.begin(), h->h_joff.end(), offsets);
+    std::copy(h->h_jcol.begin(), h->h_jcol.end(), columns);
+    std::copy(h->h_jval.begin(), h->h_jval.end(), values);
+    return 0;
+  }
   for (int k = 0; k < h->n_constraint; k++) {  // FEAT10Data.cu:443-459
     offsets[k] = k;
     columns[k] = h->h_fixed[k / 3] * 3 + k % 3;
@@ -636,6 +786,12 @@ extern "C" int tlfea_t10_retrieve_constraint_jac_csr(tlfea_t10_t h, int* offsets
 extern "C" int tlfea_t10_retrieve_constraint_jact_csr(tlfea_t10_t h, int* offsets, int* columns, double* values) {
   if (!h->is_constraints_setup) return fail("constraint is not set up");
   const int rows = 3 * h->N;
+  if (h->cons_mode == 2) {
+    std::copy(h->h_jtoff.begin(), h->h_jtoff.end(), offsets);
+    std::copy(h->h_jtcol.begin(), h->h_jtcol.end(), columns);
+    std::copy(h->h_jtval.begin(), h->h_jtval.end(), values);
+    return 0;
+  }
   std::fill(offsets, offsets + rows + 1, 0);
   for (int k = 0; k < h->n_constraint; k++) offsets[h->h_fixed[k / 3] * 3 + k % 3 + 1]++;
   for (int r = 0; r < rows; r++) offsets[r + 1] += offsets[r];
@@ -885,6 +1041,8 @@ extern "C" int tlfea_newton_set_interface(tlfea_newton_t s, const int* iface_nod
   s->stream = fn ? nullptr : s->stream_own;
   if (!fn) return 0;
   tlfea_t10_t d = s->d;
+  if (d->cons_mode == 2)
+    return fail("tlfea_newton_set_interface: general linear constraints are not supported on the multi-GPU path");
   const size_t N = s->N;
   for (int k = 0; k < n_local; k++)
     if (iface_nodes[k] < 0 || iface_nodes[k] >= s->N || iface_slots[k] < 0 || iface_slots[k] >= n_global)
@@ -1027,9 +1185,17 @@ static int eval_gradient(tlfea_newton_t s, double* norm_g) {
   }
   {
     StageTimer t(s, 1);
+    const bool pinned = d->is_constraints_setup && d->cons_mode == 1;
     launch_grad(s->stream, s->N, d->inc(), d->d_fbuf, d->d_mval, s->d_v, s->d_vprev, d->d_fext, d->d_x, d->d_y, d->d_z,
-                d->d_xt, d->d_yt, d->d_zt, d->is_constraints_setup ? d->d_fixed_slot : nullptr, s->d_lam, s->d_nw, p.time_step,
-                p.rho, d->d_fint, d->d_cons, s->d_g);
+                d->d_xt, d->d_yt, d->d_zt, pinned ? d->d_fixed_slot : nullptr, s->d_lam, s->d_nw, p.time_step, p.rho,
+                d->d_fint, d->d_cons, s->d_g);
+    if (d->cons_mode == 2 && d->n_constraint > 0) {
+      // general linear rows: c = J x - rhs, then g += h J^T (lambda + rho c)   (SyncedNewton.cu:377-404)
+      launch_lin_constraint(s->stream, d->n_constraint, d->d_joff, d->d_jcol, d->d_jval, d->d_rhs, d->d_x, d->d_y, d->d_z,
+                            d->d_cons);
+      launch_lin_constraint_grad(s->stream, 3 * s->N, d->d_jtoff, d->d_jtcol, d->d_jtval, s->d_lam, d->d_cons,
+                                 p.time_step, p.rho, s->d_g);
+    }
     HIP_TRY(hipGetLastError());
     // each rank's g holds only its own elements' forces and its share of M, f_ext, constraints on
     // partition-boundary nodes: sum the boundary entries over ranks (nothing else is exchanged)
@@ -1050,9 +1216,12 @@ static int assemble(tlfea_newton_t s) {
   }
   {
     StageTimer t(s, 3);
+    const bool pinned = d->is_constraints_setup && d->cons_mode == 1;
     launch_assemble_rows(s->stream, s->N, d->S, d->maxdeg, d->inc(), s->d_Kbuf, d->d_mval, 1.0 / p.time_step,
-                         d->is_constraints_setup ? d->d_fixed_slot : nullptr, s->d_nw,
-                         p.time_step * p.time_step * p.rho, s->d_H);
+                         pinned ? d->d_fixed_slot : nullptr, s->d_nw, p.time_step * p.time_step * p.rho, s->d_H);
+    if (d->cons_mode == 2 && d->n_constraint > 0)  // + h^2 rho J^T J  (SyncedNewton.cu:292-341)
+      launch_lin_constraint_hessian(s->stream, 3 * s->N, d->d_jtoff, d->d_jtcol, d->d_jtval, d->d_joff, d->d_jcol,
+                                    d->d_jval, d->d_off, d->d_cols, p.time_step * p.time_step * p.rho, s->d_H);
     HIP_TRY(hipGetLastError());
     t.stop();
   }
@@ -1431,7 +1600,7 @@ extern "C" int tlfea_newton_time_kernels(tlfea_newton_t s, int reps, double* out
         launch_tangent_blocks(s->stream, d->view(), d->mat, p.time_step, s->d_Kbuf);
       else if (k == 2)
         launch_assemble_rows(s->stream, N, d->S, d->maxdeg, d->inc(), s->d_Kbuf, d->d_mval, 1.0 / p.time_step,
-                             d->is_constraints_setup ? d->d_fixed_slot : nullptr, s->d_nw,
+                             (d->is_constraints_setup && d->cons_mode == 1) ? d->d_fixed_slot : nullptr, s->d_nw,
                              p.time_step * p.time_step * p.rho, s->d_H);
       else if (k == 3)  // the CG iteration's launch (beta from the reduction slots as in the solver; p ping-pongs)
         launch_spmv_dir_dot(s->stream, N, d->inc(), s->d_H, s->d_zv, (r & 1) ? s->d_p2 : s->d_p, 0, part(s, 1), part(s, 0),
@@ -1539,8 +1708,12 @@ extern "C" int tlfea_newton_solve(tlfea_newton_t s) {
     HIP_TRY(hipMemcpyAsync(s->d_vprev, s->d_v, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice,
                            s->stream));                                    // every OUTER iteration (:1122)
     if (s->n_constraints_global > 0) {
-      launch_constraint(s->stream, d->n_fixed, d->d_fixed, d->d_x, d->d_y, d->d_z, d->d_xt, d->d_yt, d->d_zt,
-                        d->d_cons);
+      if (d->cons_mode == 2)
+        launch_lin_constraint(s->stream, d->n_constraint, d->d_joff, d->d_jcol, d->d_jval, d->d_rhs, d->d_x, d->d_y,
+                              d->d_z, d->d_cons);
+      else
+        launch_constraint(s->stream, d->n_fixed, d->d_fixed, d->d_x, d->d_y, d->d_z, d->d_xt, d->d_yt, d->d_zt,
+                          d->d_cons);
       launch_dual_update(s->stream, s->n_constraints, d->d_cons, p.rho, s->d_lam);  // lambda += rho c (:470-481)
       TRY(device_norm(s, d->d_cons, s->d_wc, s->n_constraints, &norm_c));  // replicated rows weigh 1/multiplicity
       if (s->verbose) std::printf("  outer %d ||c|| = %.6e\n", outer, norm_c);
@@ -1563,6 +1736,10 @@ extern "C" int tlfea_newton_set_velocity(tlfea_newton_t s, const double* v, cons
   const size_t nb = 3 * (size_t)s->N * sizeof(double);
   HIP_TRY(hipMemcpy(s->d_v, v, nb, hipMemcpyHostToDevice));
   if (v_prev) HIP_TRY(hipMemcpy(s->d_vprev, v_prev, nb, hipMemcpyHostToDevice));
+  return 0;
+}
+extern "C" int tlfea_newton_set_lambda(tlfea_newton_t s, const double* lam) {
+  if (s->n_constraints) HIP_TRY(hipMemcpy(s->d_lam, lam, (size_t)s->n_constraints * sizeof(double), hipMemcpyHostToDevice));
   return 0;
 }
 extern "C" int tlfea_newton_retrieve_lambda(tlfea_newton_t s, double* lam) {

@@ -72,6 +72,14 @@ void launch_grad(hipStream_t s, int N, const Incidence& inc, const double* fbuf,
                  const int* fixed_slot, const double* lam, const double* nw, double h, double rho,
                  double* f_int, double* cons, double* g);
 void launch_fint_gather(hipStream_t s, int N, const Incidence& inc, const double* fbuf, double* f_int);
+// general linear constraints c = J x - rhs (CSR over constraint rows, columns = 3*coef + component)
+void launch_lin_constraint(hipStream_t s, int nc, const int* joff, const int* jcol, const double* jval,
+                           const double* rhs, const double* x, const double* y, const double* z, double* c);
+void launch_lin_constraint_grad(hipStream_t s, int ndof, const int* jtoff, const int* jtcol, const double* jtval,
+                                const double* lam, const double* c, double h, double rho, double* g);
+void launch_lin_constraint_hessian(hipStream_t s, int ndof, const int* jtoff, const int* jtcol, const double* jtval,
+                                   const int* joff, const int* jcol, const double* jval, const int* off,
+                                   const int* cols, double f, double* H);
 void launch_constraint(hipStream_t s, int n_fixed, const int* fixed_nodes, const double* x, const double* y,
                        const double* z, const double* xt, const double* yt, const double* zt, double* cons);
 

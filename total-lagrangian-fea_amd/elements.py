@@ -65,6 +65,24 @@ class GPU_FEAT10_Data:
         fx = np.ascontiguousarray(fixed_nodes, dtype=np.int32)
         check(self._lib.tlfea_t10_set_nodal_fixed(self._h, ip(fx), int(fx.size)))
 
+    def SetLinearConstraintsCSR(self, j_offsets, j_columns, j_values, rhs):
+        """General linear constraints c = J x - rhs (ANCF3243Data.cuh:810-940); columns = 3*coef + component."""
+        off = np.ascontiguousarray(j_offsets, dtype=np.int32)
+        col = np.ascontiguousarray(j_columns, dtype=np.int32)
+        val, r = _f64(j_values), _f64(rhs)
+        if off.size == 0 or off[0] != 0:
+            raise ValueError("SetLinearConstraintsCSR: invalid offsets.")
+        if r.size + 1 != off.size:
+            raise ValueError("SetLinearConstraintsCSR: offsets/rhs size mismatch.")
+        if col.size != val.size:
+            raise ValueError("SetLinearConstraintsCSR: columns/values size mismatch.")
+        if off[-1] != col.size:
+            raise ValueError("SetLinearConstraintsCSR: offsets.back != nnz.")
+        check(self._lib.tlfea_t10_set_linear_constraints_csr(self._h, int(r.size), ip(off), ip(col), dp(val), dp(r)))
+
+    def GetConstraintMode(self):
+        return int(self._lib.tlfea_t10_get_constraint_mode(self._h))
+
     def UpdateNodalFixed(self, fixed_nodes):
         fx = np.ascontiguousarray(fixed_nodes, dtype=np.int32)
         check(self._lib.tlfea_t10_update_nodal_fixed(self._h, ip(fx), int(fx.size)))
@@ -194,14 +212,14 @@ class GPU_FEAT10_Data:
         return c
 
     def RetrieveConstraintJacobianCSRToCPU(self):
-        nc = self.get_n_constraint()
-        off, col, val = np.zeros(nc + 1, dtype=np.int32), np.zeros(nc, dtype=np.int32), np.zeros(nc)
+        nc, nnz = self.get_n_constraint(), int(self._lib.tlfea_t10_constraint_jac_nnz(self._h))
+        off, col, val = np.zeros(nc + 1, dtype=np.int32), np.zeros(nnz, dtype=np.int32), np.zeros(nnz)
         check(self._lib.tlfea_t10_retrieve_constraint_jac_csr(self._h, ip(off), ip(col), dp(val)))
         return off, col, val
 
     def RetrieveConstraintJacobianTransposeCSRToCPU(self):
-        nc = self.get_n_constraint()
-        off, col, val = np.zeros(3 * self.n_coef + 1, dtype=np.int32), np.zeros(nc, dtype=np.int32), np.zeros(nc)
+        nnz = int(self._lib.tlfea_t10_constraint_jac_nnz(self._h))
+        off, col, val = np.zeros(3 * self.n_coef + 1, dtype=np.int32), np.zeros(nnz, dtype=np.int32), np.zeros(nnz)
         check(self._lib.tlfea_t10_retrieve_constraint_jact_csr(self._h, ip(off), ip(col), dp(val)))
         return off, col, val
 

@@ -177,3 +177,261 @@ def structured_3443_plate(nx, ny, L, W):
     n0 = (ej * (nx + 1) + ei).reshape(-1)
     conn = np.stack([n0, n0 + 1, n0 + nx + 2, n0 + nx + 1], axis=1).astype(np.int32)
     return x, y, z, conn
+
+
+# ---- general linear constraints + ANCF mesh files (mesh_utils.h:105-245, mesh_utils.cc:170-1010) ----------------
+class LinearConstraintCSR:
+    """c[row] = sum_j values[j] * dof(columns[j]) - rhs[row]; columns = 3*coef + component (mesh_utils.h:104-127)."""
+
+    def __init__(self, offsets=None, columns=None, values=None, rhs=None):
+        self.offsets = np.asarray([] if offsets is None else offsets, dtype=np.int32)
+        self.columns = np.asarray([] if columns is None else columns, dtype=np.int32)
+        self.values = np.asarray([] if values is None else values, dtype=np.float64)
+        self.rhs = np.asarray([] if rhs is None else rhs, dtype=np.float64)
+
+    def NumRows(self):
+        return int(self.rhs.size)
+
+    def NumNonZeros(self):
+        return int(self.columns.size)
+
+    def Empty(self):
+        return self.rhs.size == 0
+
+
+class LinearConstraintBuilder:
+    """Row-by-row builder of a LinearConstraintCSR (mesh_utils.cc:173-246): zero coefficients are dropped, an empty
+    row or a column outside [0, n_dofs) is an error."""
+
+    def __init__(self, n_dofs, initial=None):
+        if n_dofs <= 0:
+            raise ValueError("LinearConstraintBuilder: n_dofs must be > 0")
+        self._n_dofs = int(n_dofs)
+        self._offsets, self._columns, self._values, self._rhs = [0], [], [], []
+        if initial is not None:
+            if len(initial.offsets) != initial.NumRows() + 1:
+                raise ValueError("LinearConstraintBuilder: initial offsets size mismatch")
+            if len(initial.values) != initial.NumNonZeros():
+                raise ValueError("LinearConstraintBuilder: initial nnz mismatch")
+            if initial.offsets[0] != 0 or initial.offsets[-1] != initial.NumNonZeros():
+                raise ValueError("LinearConstraintBuilder: initial CSR offsets invalid")
+            self._offsets = [int(v) for v in initial.offsets]
+            self._columns = [int(v) for v in initial.columns]
+            self._values = [float(v) for v in initial.values]
+            self._rhs = [float(v) for v in initial.rhs]
+
+    def n_dofs(self):
+        return self._n_dofs
+
+    def num_rows(self):
+        return len(self._rhs)
+
+    def nnz(self):
+        return len(self._columns)
+
+    def AddRow(self, entries, rhs):
+        if len(entries) == 0:
+            raise ValueError("LinearConstraintBuilder::AddRow: empty row")
+        for col, val in entries:
+            if col < 0 or col >= self._n_dofs:
+                raise IndexError("LinearConstraintBuilder::AddRow: col out of range")
+            if val == 0.0:
+                continue
+            self._columns.append(int(col))
+            self._values.append(float(val))
+        self._rhs.append(float(rhs))
+        self._offsets.append(len(self._columns))
+        return len(self._rhs) - 1
+
+    def AddFixedDof(self, col, rhs):
+        return self.AddRow([(col, 1.0)], rhs)
+
+    def ToCSR(self):
+        return LinearConstraintCSR(self._offsets, self._columns, self._values, self._rhs)
+
+
+def _ancf_dof_col(node_id, coef_slot, component):
+    return (node_id * 4 + coef_slot) * 3 + component
+
+
+def AppendANCFVectorEqualityConstraint(builder, node_a, node_b, coef_slot):
+    """r(b, slot) - r(a, slot) = 0, three rows (mesh_utils.cc:262-275 / :330-343)."""
+    if coef_slot < 0 or coef_slot > 3:
+        raise IndexError("AppendANCFVectorEqualityConstraint: coef_slot out of range")
+    for c in range(3):
+        builder.AddRow([(_ancf_dof_col(node_b, coef_slot, c), 1.0), (_ancf_dof_col(node_a, coef_slot, c), -1.0)], 0.0)
+
+
+def AppendANCFVectorWeldedConstraint(builder, node_a, node_b, coef_slot, Q):
+    """r(b, slot) - Q r(a, slot) = 0 with Q row-major 3x3 (mesh_utils.cc:277-299 / :345-367)."""
+    if coef_slot < 0 or coef_slot > 3:
+        raise IndexError("AppendANCFVectorWeldedConstraint: coef_slot out of range")
+    Q = np.asarray(Q, dtype=np.float64).reshape(3, 3)
+    for row in range(3):
+        entries = [(_ancf_dof_col(node_b, coef_slot, row), 1.0)]
+        for k in range(3):
+            w = -Q[row, k]
+            if w == 0.0:
+                continue
+            entries.append((_ancf_dof_col(node_a, coef_slot, k), w))
+        builder.AddRow(entries, 0.0)
+
+
+def AppendANCFFixedCoefficient(builder, coef_index, x12_ref, y12_ref, z12_ref):
+    """Component-wise equality of one coefficient to the reference arrays (mesh_utils.cc:301-315)."""
+    if coef_index < 0 or coef_index >= len(x12_ref):
+        raise IndexError("AppendANCFFixedCoefficient: coef_index out of range")
+    builder.AddFixedDof(coef_index * 3 + 0, x12_ref[coef_index])
+    builder.AddFixedDof(coef_index * 3 + 1, y12_ref[coef_index])
+    builder.AddFixedDof(coef_index * 3 + 2, z12_ref[coef_index])
+
+
+# the reference has one copy of each helper per element family; the DOF numbering is the same
+AppendANCF3243VectorEqualityConstraint = AppendANCF3443VectorEqualityConstraint = AppendANCFVectorEqualityConstraint
+AppendANCF3243VectorWeldedConstraint = AppendANCF3443VectorWeldedConstraint = AppendANCFVectorWeldedConstraint
+AppendANCF3243FixedCoefficient = AppendANCFFixedCoefficient
+
+
+class ANCFMesh:
+    """ANCF3243Mesh / ANCF3443Mesh (mesh_utils.h:165-214)."""
+
+    def __init__(self):
+        self.version = 0
+        self.grid_nx = self.grid_ny = self.grid_L = self.grid_origin = None
+        self.n_nodes = self.n_elements = 0
+        self.node_family, self.element_family = [], []
+        self.x12 = self.y12 = self.z12 = None
+        self.element_L = self.element_W = self.element_H = None
+        self.element_connectivity = None
+        self.constraints = LinearConstraintCSR()
+
+
+def _records(path):
+    with open(path) as fh:
+        for line in fh:
+            line = line.split("#", 1)[0].strip()
+            if line:
+                yield line
+
+
+def _read_ancf_mesh(path, tag, nn):
+    """Shared reader of `.ancf3243mesh` (nn = 2) and `.ancf3443mesh` (nn = 4): sections `nodes N` (id family x0..x3
+    y0..y3 z0..z3), `elements M` (3243: id family n0 n1; 3443: id family L W H n0..n3), optional `constraints K`
+    (`pinned a b` -> position equality; `welded a b q00..q22` -> position equality + Q-mapped gradients).
+    Raises ValueError with the reference's message on malformed input (the reference returns false + message)."""
+    fn = "ReadANCF%sMeshFromFile" % tag
+    rec = _records(path)
+    out = ANCFMesh()
+
+    def nxt(what):
+        try:
+            return next(rec).split()
+        except StopIteration:
+            raise ValueError("%s: %s" % (fn, what))
+
+    t = nxt("empty file")
+    if len(t) != 2 or t[0] != "ancf%s_mesh" % tag:
+        raise ValueError("%s: expected header 'ancf%s_mesh <version>'" % (fn, tag))
+    try:
+        out.version = int(t[1])
+    except ValueError:
+        out.version = 0
+    if out.version <= 0:
+        raise ValueError("%s: invalid mesh version" % fn)
+    t = nxt("missing nodes section")
+    if t[0] == "grid" and tag == "3243":
+        if len(t) != 11 or t[1] != "nx" or t[3] != "ny" or t[5] != "L" or t[7] != "origin":
+            raise ValueError("%s: invalid grid line" % fn)
+        out.grid_nx, out.grid_ny, out.grid_L = int(t[2]), int(t[4]), float(t[6])
+        out.grid_origin = np.array([float(t[8]), float(t[9]), float(t[10])])
+        t = nxt("missing nodes section")
+    elif t[0] in ("tire", "meta") and tag == "3443":
+        t = nxt("missing nodes section")
+    if len(t) != 2 or t[0] != "nodes" or not t[1].lstrip("-").isdigit() or int(t[1]) <= 0:
+        raise ValueError("%s: invalid nodes header" % fn)
+    n_nodes = out.n_nodes = int(t[1])
+    out.node_family = [""] * n_nodes
+    out.x12, out.y12, out.z12 = np.zeros(4 * n_nodes), np.zeros(4 * n_nodes), np.zeros(4 * n_nodes)
+    seen = np.zeros(n_nodes, dtype=bool)
+    for _ in range(n_nodes):
+        t = nxt("unexpected EOF in nodes")
+        if len(t) != 14:
+            raise ValueError("%s: invalid node line (expected 14 tokens)" % fn)
+        nid = int(t[0])
+        if nid < 0 or nid >= n_nodes:
+            raise ValueError("%s: node id out of range" % fn)
+        if seen[nid]:
+            raise ValueError("%s: duplicate node id" % fn)
+        seen[nid] = True
+        out.node_family[nid] = t[1]
+        v = [float(a) for a in t[2:14]]
+        out.x12[4 * nid:4 * nid + 4] = v[0:4]
+        out.y12[4 * nid:4 * nid + 4] = v[4:8]
+        out.z12[4 * nid:4 * nid + 4] = v[8:12]
+    t = nxt("missing elements section")
+    if len(t) != 2 or t[0] != "elements" or int(t[1]) <= 0:
+        raise ValueError("%s: invalid elements header" % fn)
+    n_el = out.n_elements = int(t[1])
+    out.element_connectivity = np.zeros((n_el, nn), dtype=np.int32)
+    out.element_family = [""] * n_el
+    if nn == 4:
+        out.element_L, out.element_W, out.element_H = np.zeros(n_el), np.zeros(n_el), np.zeros(n_el)
+    seen = np.zeros(n_el, dtype=bool)
+    ntok = 4 if nn == 2 else 9
+    for _ in range(n_el):
+        t = nxt("unexpected EOF in elements")
+        if len(t) != ntok:
+            raise ValueError("%s: invalid element line (expected %d tokens)" % (fn, ntok))
+        eid = int(t[0])
+        if eid < 0 or eid >= n_el:
+            raise ValueError("%s: element id out of range" % fn)
+        if seen[eid]:
+            raise ValueError("%s: duplicate element id" % fn)
+        seen[eid] = True
+        out.element_family[eid] = t[1]
+        if nn == 4:
+            out.element_L[eid], out.element_W[eid], out.element_H[eid] = float(t[2]), float(t[3]), float(t[4])
+        nodes = [int(a) for a in t[ntok - nn:]]
+        if min(nodes) < 0 or max(nodes) >= n_nodes:
+            raise ValueError("%s: element node id out of range" % fn)
+        out.element_connectivity[eid] = nodes
+    try:
+        t = next(rec).split()
+    except StopIteration:
+        return out  # no constraints section
+    if len(t) != 2 or t[0] != "constraints" or int(t[1]) < 0:
+        raise ValueError("%s: invalid constraints header" % fn)
+    builder = LinearConstraintBuilder(12 * n_nodes)
+    for _ in range(int(t[1])):
+        t = nxt("unexpected EOF in constraints")
+        if t[0] == "pinned":
+            if len(t) != 3:
+                raise ValueError("%s: pinned expects 'pinned a b'" % fn)
+            a, b = int(t[1]), int(t[2])
+            if min(a, b) < 0 or max(a, b) >= n_nodes:
+                raise ValueError("%s: pinned node id out of range" % fn)
+            AppendANCFVectorEqualityConstraint(builder, a, b, 0)
+        elif t[0] == "welded":
+            if len(t) != 12:
+                raise ValueError("%s: welded expects 'welded a b q00..q22'" % fn)
+            a, b = int(t[1]), int(t[2])
+            if min(a, b) < 0 or max(a, b) >= n_nodes:
+                raise ValueError("%s: welded node id out of range" % fn)
+            Q = np.array([float(v) for v in t[3:12]]).reshape(3, 3)
+            AppendANCFVectorEqualityConstraint(builder, a, b, 0)      # position continuity (no rotation)
+            for slot in (1, 2, 3):                                    # gradient continuity with the Q mapping
+                AppendANCFVectorWeldedConstraint(builder, a, b, slot, Q)
+        else:
+            raise ValueError("%s: unknown constraint type '%s'" % (fn, t[0]))
+    out.constraints = builder.ToCSR()
+    return out
+
+
+def ReadANCF3243MeshFromFile(path):
+    """mesh_utils.cc:444-736"""
+    return _read_ancf_mesh(path, "3243", 2)
+
+
+def ReadANCF3443MeshFromFile(path):
+    """mesh_utils.cc:738-1010"""
+    return _read_ancf_mesh(path, "3443", 4)

@@ -140,6 +140,11 @@ class SyncedNewtonSolver:
         vp = np.ascontiguousarray(v_prev, dtype=np.float64) if v_prev is not None else None
         check(self._lib.tlfea_newton_set_velocity(self._h, dp(v), dp(vp)))
 
+    def SetLambda(self, lam):
+        lam = np.ascontiguousarray(lam, dtype=np.float64)
+        assert lam.size == self.n_constraints
+        check(self._lib.tlfea_newton_set_lambda(self._h, dp(lam)))
+
     def RetrieveLambdaToCPU(self):
         lam = np.zeros(self.n_constraints)
         check(self._lib.tlfea_newton_retrieve_lambda(self._h, dp(lam)))
