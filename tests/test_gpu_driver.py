@@ -67,3 +67,35 @@ def test_cpp_ancf3243_cantilever_config_a(tmp_path):
     for step in range(4):
         o.newton_step(prm)
         assert abs(rows[step, 1] - o.z[tip]) <= 1e-10 * abs(o.z[tip] - z[tip]) + 8e-16 * max(1.0, abs(o.z[tip]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("joint", ["welded", "pinned"])
+def test_cpp_ancf3243_net_driver(joint):
+    """lib_bin/mesh_deform/test_ancf3243_net_newton.cc flow through the C++ facade (mesh reader, LinearConstraintBuilder,
+    corner clamps as AddFixedDof rows, SetLinearConstraintsCSR) vs the oracle: centre deflection per step."""
+    from tests.test_gpu_linear_constraints import make_pair, net_problem
+    from tests.test_linear_constraints import NET_P, NET_W
+    drv = os.path.join(os.path.dirname(DRIVER), "test_ancf3243_net_newton")
+    if not os.path.exists(drv):
+        subprocess.check_call(["make", "-C", os.path.dirname(DRIVER)])
+    path = NET_W if joint == "welded" else NET_P
+    out = subprocess.run([drv, f"--joint={joint}", "--steps=2", f"--mesh={path}"], capture_output=True, text=True,
+                         timeout=300)
+    assert out.returncode == 0, out.stderr
+    lines = out.stdout.strip().splitlines()
+    k = lines.index("step,centre_z,constraint_norm")
+    rows = np.array([[float(v) for v in ln.split(",")] for ln in lines[k + 1:]])
+    prob = net_problem(path)
+    kind, m, (L, W, H), csr, f_ext, mk, prm = prob
+    o = orc.AncfOracle(kind, m.x12, m.y12, m.z12, m.element_connectivity, L, W, H,
+                       orc.svk(mk["E"], mk["nu"], rho0=mk["rho0"], eta=mk["eta"], lamd=mk["lamd"]), f_ext=f_ext)
+    o.calc_dsdu_pre()
+    o.calc_mass()
+    o.set_linear_constraints(csr.offsets, csr.columns, csr.values, csr.rhs)
+    centre = int(np.where(f_ext != 0)[0][0] // 3)
+    for step in range(2):
+        o.newton_step_lin(orc.NewtonParams(*prm))
+        ref = o.z[centre]
+        assert abs(rows[step, 1] - ref) <= 1e-10 * np.max(np.abs(o.z - m.z12)) + 8e-16 * max(1.0, abs(ref))
+        assert rows[step, 2] < 1e-6

@@ -253,6 +253,292 @@ inline void ANCF3443_generate_beam_coordinates(int n_beam, tlfea::VectorXd& x12,
     }
   }
 }
+
+// ---- general linear constraints + ANCF mesh files (mesh_utils.h:100-245, mesh_utils.cc:170-1010) ----------------
+struct LinearConstraintCSR {  // c[row] = sum_j values[j] * dof(columns[j]) - rhs[row]; columns = 3*coef + component
+  std::vector<int> offsets, columns;
+  std::vector<double> values;
+  tlfea::VectorXd rhs;
+  int NumRows() const { return rhs.size(); }
+  int NumNonZeros() const { return static_cast<int>(columns.size()); }
+  bool Empty() const { return rhs.size() == 0; }
+};
+
+class LinearConstraintBuilder {  // mesh_utils.cc:173-246
+ public:
+  explicit LinearConstraintBuilder(int n_dofs) : n_dofs_(n_dofs) {
+    if (n_dofs_ <= 0) throw std::invalid_argument("LinearConstraintBuilder: n_dofs must be > 0");
+    offsets_.push_back(0);
+  }
+  LinearConstraintBuilder(int n_dofs, const LinearConstraintCSR& initial)
+      : n_dofs_(n_dofs), offsets_(initial.offsets), columns_(initial.columns), values_(initial.values) {
+    if (n_dofs_ <= 0) throw std::invalid_argument("LinearConstraintBuilder: n_dofs must be > 0");
+    if (static_cast<int>(offsets_.size()) != initial.NumRows() + 1)
+      throw std::invalid_argument("LinearConstraintBuilder: initial offsets size mismatch");
+    if (static_cast<int>(values_.size()) != initial.NumNonZeros())
+      throw std::invalid_argument("LinearConstraintBuilder: initial nnz mismatch");
+    if (offsets_.empty() || offsets_.front() != 0 || offsets_.back() != static_cast<int>(columns_.size()))
+      throw std::invalid_argument("LinearConstraintBuilder: initial CSR offsets invalid");
+    for (int i = 0; i < initial.rhs.size(); i++) rhs_.push_back(initial.rhs(i));
+  }
+  int n_dofs() const { return n_dofs_; }
+  int num_rows() const { return static_cast<int>(rhs_.size()); }
+  int nnz() const { return static_cast<int>(columns_.size()); }
+  int AddRow(const std::vector<std::pair<int, double>>& entries, double rhs) {
+    if (entries.empty()) throw std::invalid_argument("LinearConstraintBuilder::AddRow: empty row");
+    for (const auto& e : entries) {
+      if (e.first < 0 || e.first >= n_dofs_) throw std::out_of_range("LinearConstraintBuilder::AddRow: col out of range");
+      if (e.second == 0.0) continue;
+      columns_.push_back(e.first);
+      values_.push_back(e.second);
+    }
+    rhs_.push_back(rhs);
+    offsets_.push_back(static_cast<int>(columns_.size()));
+    return static_cast<int>(rhs_.size()) - 1;
+  }
+  int AddFixedDof(int col, double rhs) { return AddRow({{col, 1.0}}, rhs); }
+  LinearConstraintCSR ToCSR() const {
+    LinearConstraintCSR out;
+    out.offsets = offsets_;
+    out.columns = columns_;
+    out.values = values_;
+    out.rhs.resize(static_cast<int>(rhs_.size()));
+    for (size_t i = 0; i < rhs_.size(); i++) out.rhs(static_cast<int>(i)) = rhs_[i];
+    return out;
+  }
+
+ private:
+  int n_dofs_;
+  std::vector<int> offsets_, columns_;
+  std::vector<double> values_, rhs_;
+};
+
+inline int ANCFDofCol(int node_id, int coef_slot, int component) { return (node_id * 4 + coef_slot) * 3 + component; }
+// r(b,slot) - r(a,slot) = 0  (mesh_utils.cc:262-275, :330-343)
+inline void AppendANCF3243VectorEqualityConstraint(LinearConstraintBuilder& b, int node_a, int node_b, int coef_slot) {
+  if (coef_slot < 0 || coef_slot > 3) throw std::out_of_range("AppendANCF3243VectorEqualityConstraint: coef_slot out of range");
+  for (int c = 0; c < 3; ++c)
+    b.AddRow({{ANCFDofCol(node_b, coef_slot, c), 1.0}, {ANCFDofCol(node_a, coef_slot, c), -1.0}}, 0.0);
+}
+// r(b,slot) - Q r(a,slot) = 0, Q row-major 3x3  (mesh_utils.cc:277-299, :345-367)
+inline void AppendANCF3243VectorWeldedConstraint(LinearConstraintBuilder& b, int node_a, int node_b, int coef_slot,
+                                                 const double Q[9]) {
+  if (coef_slot < 0 || coef_slot > 3) throw std::out_of_range("AppendANCF3243VectorWeldedConstraint: coef_slot out of range");
+  for (int row = 0; row < 3; ++row) {
+    std::vector<std::pair<int, double>> entries;
+    entries.push_back({ANCFDofCol(node_b, coef_slot, row), 1.0});
+    for (int k = 0; k < 3; ++k) {
+      const double w = -Q[3 * row + k];
+      if (w == 0.0) continue;
+      entries.push_back({ANCFDofCol(node_a, coef_slot, k), w});
+    }
+    b.AddRow(entries, 0.0);
+  }
+}
+inline void AppendANCF3443VectorEqualityConstraint(LinearConstraintBuilder& b, int a, int nb, int slot) {
+  AppendANCF3243VectorEqualityConstraint(b, a, nb, slot);
+}
+inline void AppendANCF3443VectorWeldedConstraint(LinearConstraintBuilder& b, int a, int nb, int slot, const double Q[9]) {
+  AppendANCF3243VectorWeldedConstraint(b, a, nb, slot, Q);
+}
+// component-wise equality of one coefficient to the reference arrays (mesh_utils.cc:301-315)
+inline void AppendANCF3243FixedCoefficient(LinearConstraintBuilder& b, int coef_index, const tlfea::VectorXd& x12_ref,
+                                           const tlfea::VectorXd& y12_ref, const tlfea::VectorXd& z12_ref) {
+  if (coef_index < 0 || coef_index >= x12_ref.size() || coef_index >= y12_ref.size() || coef_index >= z12_ref.size())
+    throw std::out_of_range("AppendANCF3243FixedCoefficient: coef_index out of range");
+  b.AddFixedDof(coef_index * 3 + 0, x12_ref(coef_index));
+  b.AddFixedDof(coef_index * 3 + 1, y12_ref(coef_index));
+  b.AddFixedDof(coef_index * 3 + 2, z12_ref(coef_index));
+}
+
+struct ANCF3243Mesh {  // mesh_utils.h:165-184 (std::optional members are plain values + a has_grid flag here)
+  int version = 0;
+  bool has_grid = false;
+  int grid_nx = 0, grid_ny = 0;
+  double grid_L = 0.0, grid_origin[3] = {0, 0, 0};
+  int n_nodes = 0, n_elements = 0;
+  std::vector<std::string> node_family;
+  tlfea::VectorXd x12, y12, z12;
+  tlfea::MatrixXi element_connectivity;  // n_elements x 2
+  LinearConstraintCSR constraints;
+};
+struct ANCF3443Mesh {  // mesh_utils.h:194-214
+  int version = 0;
+  int n_nodes = 0, n_elements = 0;
+  std::vector<std::string> node_family, element_family;
+  tlfea::VectorXd x12, y12, z12, element_L, element_W, element_H;
+  tlfea::MatrixXi element_connectivity;  // n_elements x 4
+  LinearConstraintCSR constraints;
+};
+
+namespace detail {
+inline bool next_record(std::ifstream& f, std::vector<std::string>& tok) {
+  std::string line;
+  while (std::getline(f, line)) {
+    const size_t p = line.find('#');
+    if (p != std::string::npos) line.erase(p);
+    std::istringstream iss(line);
+    tok.clear();
+    std::string w;
+    while (iss >> w) tok.push_back(w);
+    if (!tok.empty()) return true;
+  }
+  return false;
+}
+inline bool to_int(const std::string& s, int& out) {
+  try {
+    size_t idx = 0;
+    const int v = std::stoi(s, &idx);
+    if (idx != s.size()) return false;
+    out = v;
+    return true;
+  } catch (...) {
+    return false;
+  }
+}
+inline bool to_double(const std::string& s, double& out) {
+  try {
+    size_t idx = 0;
+    const double v = std::stod(s, &idx);
+    if (idx != s.size()) return false;
+    out = v;
+    return true;
+  } catch (...) {
+    return false;
+  }
+}
+// shared body of the two readers: nn = nodes per element (2 | 4); 3443 element lines carry L W H
+template <class Mesh>
+bool read_ancf_mesh(const std::string& path, const char* tag, int nn, Mesh& out, std::string* error, bool* has_grid,
+                    int* gnx, int* gny, double* gL, double* gorigin, tlfea::VectorXd* eL, tlfea::VectorXd* eW,
+                    tlfea::VectorXd* eH, std::vector<std::string>* efam) {
+  const std::string fn = std::string("ReadANCF") + tag + "MeshFromFile: ";
+  auto fail = [&](const std::string& m) {
+    if (error) *error = fn + m;
+    return false;
+  };
+  std::ifstream file(path);
+  if (!file.is_open()) return fail("failed to open " + path);
+  std::vector<std::string> t;
+  if (!next_record(file, t)) return fail("empty file");
+  if (t.size() != 2 || t[0] != std::string("ancf") + tag + "_mesh")
+    return fail(std::string("expected header 'ancf") + tag + "_mesh <version>'");
+  if (!to_int(t[1], out.version) || out.version <= 0) return fail("invalid mesh version");
+  if (!next_record(file, t)) return fail("missing nodes section");
+  if (has_grid && t[0] == "grid") {
+    if (t.size() != 11 || t[1] != "nx" || t[3] != "ny" || t[5] != "L" || t[7] != "origin") return fail("invalid grid line");
+    if (!to_int(t[2], *gnx) || !to_int(t[4], *gny) || !to_double(t[6], *gL) || !to_double(t[8], gorigin[0]) ||
+        !to_double(t[9], gorigin[1]) || !to_double(t[10], gorigin[2]))
+      return fail("failed to parse grid values");
+    *has_grid = true;
+    if (!next_record(file, t)) return fail("missing nodes section");
+  } else if (!has_grid && (t[0] == "tire" || t[0] == "meta")) {
+    if (!next_record(file, t)) return fail("missing nodes section");
+  }
+  int n_nodes = 0;
+  if (t.size() != 2 || t[0] != "nodes" || !to_int(t[1], n_nodes) || n_nodes <= 0) return fail("invalid nodes header");
+  out.n_nodes = n_nodes;
+  out.node_family.assign(static_cast<size_t>(n_nodes), "");
+  out.x12.resize(4 * n_nodes);
+  out.y12.resize(4 * n_nodes);
+  out.z12.resize(4 * n_nodes);
+  std::vector<bool> seen(static_cast<size_t>(n_nodes), false);
+  for (int i = 0; i < n_nodes; ++i) {
+    if (!next_record(file, t)) return fail("unexpected EOF in nodes");
+    if (t.size() != 14) return fail("invalid node line (expected 14 tokens)");
+    int id = -1;
+    if (!to_int(t[0], id) || id < 0 || id >= n_nodes) return fail("node id out of range");
+    if (seen[id]) return fail("duplicate node id");
+    seen[id] = true;
+    out.node_family[id] = t[1];
+    double v[12];
+    for (int k = 0; k < 12; ++k)
+      if (!to_double(t[2 + k], v[k])) return fail("failed to parse node dofs");
+    for (int k = 0; k < 4; ++k) {
+      out.x12(4 * id + k) = v[k];
+      out.y12(4 * id + k) = v[4 + k];
+      out.z12(4 * id + k) = v[8 + k];
+    }
+  }
+  if (!next_record(file, t)) return fail("missing elements section");
+  int n_el = 0;
+  if (t.size() != 2 || t[0] != "elements" || !to_int(t[1], n_el) || n_el <= 0) return fail("invalid elements header");
+  out.n_elements = n_el;
+  out.element_connectivity.resize(n_el, nn);
+  if (eL) {
+    eL->resize(n_el);
+    eW->resize(n_el);
+    eH->resize(n_el);
+    efam->assign(static_cast<size_t>(n_el), "");
+  }
+  std::vector<bool> seen_e(static_cast<size_t>(n_el), false);
+  const size_t ntok = eL ? 9 : 4;
+  for (int i = 0; i < n_el; ++i) {
+    if (!next_record(file, t)) return fail("unexpected EOF in elements");
+    if (t.size() != ntok) return fail("invalid element line (expected " + std::to_string(ntok) + " tokens)");
+    int id = -1;
+    if (!to_int(t[0], id) || id < 0 || id >= n_el) return fail("element id out of range");
+    if (seen_e[id]) return fail("duplicate element id");
+    seen_e[id] = true;
+    if (eL) {
+      (*efam)[id] = t[1];
+      double l = 0, w = 0, hh = 0;
+      if (!to_double(t[2], l) || !to_double(t[3], w) || !to_double(t[4], hh)) return fail("failed to parse element L/W/H");
+      (*eL)(id) = l;
+      (*eW)(id) = w;
+      (*eH)(id) = hh;
+    }
+    for (int k = 0; k < nn; ++k) {
+      int n = -1;
+      if (!to_int(t[ntok - nn + k], n) || n < 0 || n >= n_nodes) return fail("element node id out of range");
+      out.element_connectivity(id, k) = n;
+    }
+  }
+  if (!next_record(file, t)) {
+    out.constraints = LinearConstraintCSR{};
+    return true;
+  }
+  int n_c = 0;
+  if (t.size() != 2 || t[0] != "constraints" || !to_int(t[1], n_c) || n_c < 0) return fail("invalid constraints header");
+  LinearConstraintBuilder builder(12 * n_nodes);
+  for (int i = 0; i < n_c; ++i) {
+    if (!next_record(file, t)) return fail("unexpected EOF in constraints");
+    int a = -1, b = -1;
+    if (t[0] == "pinned") {
+      if (t.size() != 3) return fail("pinned expects 'pinned a b'");
+      if (!to_int(t[1], a) || !to_int(t[2], b) || a < 0 || b < 0 || a >= n_nodes || b >= n_nodes)
+        return fail("pinned node id out of range");
+      AppendANCF3243VectorEqualityConstraint(builder, a, b, 0);
+    } else if (t[0] == "welded") {
+      if (t.size() != 12) return fail("welded expects 'welded a b q00..q22'");
+      if (!to_int(t[1], a) || !to_int(t[2], b) || a < 0 || b < 0 || a >= n_nodes || b >= n_nodes)
+        return fail("welded node id out of range");
+      double Q[9];
+      for (int k = 0; k < 9; ++k)
+        if (!to_double(t[3 + k], Q[k])) return fail("welded failed to parse Q");
+      AppendANCF3243VectorEqualityConstraint(builder, a, b, 0);  // position continuity (no rotation)
+      for (int slot = 1; slot <= 3; ++slot) AppendANCF3243VectorWeldedConstraint(builder, a, b, slot, Q);
+    } else {
+      return fail("unknown constraint type '" + t[0] + "'");
+    }
+  }
+  out.constraints = builder.ToCSR();
+  return true;
+}
+}  // namespace detail
+
+// mesh_utils.cc:444-736
+inline bool ReadANCF3243MeshFromFile(const std::string& path, ANCF3243Mesh& out, std::string* error = nullptr) {
+  out = ANCF3243Mesh();
+  return detail::read_ancf_mesh(path, "3243", 2, out, error, &out.has_grid, &out.grid_nx, &out.grid_ny, &out.grid_L,
+                                out.grid_origin, nullptr, nullptr, nullptr, nullptr);
+}
+// mesh_utils.cc:738-1010
+inline bool ReadANCF3443MeshFromFile(const std::string& path, ANCF3443Mesh& out, std::string* error = nullptr) {
+  out = ANCF3443Mesh();
+  return detail::read_ancf_mesh(path, "3443", 4, out, error, nullptr, nullptr, nullptr, nullptr, nullptr,
+                                &out.element_L, &out.element_W, &out.element_H, &out.element_family);
+}
 }  // namespace ANCFCPUUtils
 
 enum ElementType { TYPE_3243, TYPE_3443, TYPE_T10 };  // ElementBase.h:20
@@ -410,6 +696,43 @@ struct GPU_ANCF_DataBase : public GPU_FEAT10_Data {
   }
   void Initialize() { TLFEA_HANDLE_ERROR(tlfea_ancf_create(kind_, n_nodes_, n_elem, &h)); }
   void CalcDsDuPre() { TLFEA_HANDLE_ERROR(tlfea_ancf_calc_dsdu_pre(h)); }
+  // ANCF3243Data.cuh:810-940: same argument checks and messages, std::cerr + return on misuse
+  enum ConstraintMode { kConstraintNone = 0, kConstraintFixedCoefficients = 1, kConstraintLinearCSR = 2 };
+  void SetLinearConstraintsCSR(const std::vector<int>& j_offsets, const std::vector<int>& j_columns,
+                               const std::vector<double>& j_values, const tlfea::VectorXd& rhs) {
+    if (j_offsets.empty() || j_offsets.front() != 0) {
+      std::cerr << "SetLinearConstraintsCSR: invalid offsets." << std::endl;
+      return;
+    }
+    if (rhs.size() + 1 != static_cast<int>(j_offsets.size())) {
+      std::cerr << "SetLinearConstraintsCSR: offsets/rhs size mismatch." << std::endl;
+      return;
+    }
+    if (j_columns.size() != j_values.size()) {
+      std::cerr << "SetLinearConstraintsCSR: columns/values size mismatch." << std::endl;
+      return;
+    }
+    if (j_offsets.back() != static_cast<int>(j_columns.size())) {
+      std::cerr << "SetLinearConstraintsCSR: offsets.back != nnz." << std::endl;
+      return;
+    }
+    TLFEA_SOFT(tlfea_t10_set_linear_constraints_csr(h, rhs.size(), j_offsets.data(), j_columns.data(), j_values.data(),
+                                                    rhs.data()));
+    n_constraint = tlfea_t10_get_n_constraint(h);
+  }
+  int GetConstraintMode() const { return tlfea_t10_get_constraint_mode(h); }
+  void RetrieveConstraintJacobianCSRToCPU(std::vector<int>& offsets, std::vector<int>& columns,
+                                          std::vector<double>& values) {
+    const int nnz = tlfea_t10_constraint_jac_nnz(h);
+    offsets.assign(static_cast<size_t>(n_constraint) + 1, 0);
+    columns.assign(static_cast<size_t>(nnz), 0);
+    values.assign(static_cast<size_t>(nnz), 0.0);
+    TLFEA_SOFT(tlfea_t10_retrieve_constraint_jac_csr(h, offsets.data(), columns.data(), values.data()));
+  }
+  void RetrieveConstraintDataToCPU(tlfea::VectorXd& c) {
+    c.resize(n_constraint);
+    TLFEA_SOFT(tlfea_t10_retrieve_constraint_data(h, c.data()));
+  }
   int n_beam;
 
  protected:
