@@ -215,6 +215,11 @@ typedef int (*tlfea_allreduce_fn)(void *user, double *d_buf, int n);
 int tlfea_newton_set_interface(tlfea_newton_t s, const int *iface_nodes, const int *iface_slots, int n_local,
                                int n_global, const double *node_weight /*N*/, tlfea_allreduce_fn fn,
                                void *user, int sync_before_callback);
+/* Owners of the replicated partition-boundary nodes: owned[N] = 1 where this rank owns the node (every node has exactly
+ * one owner over all ranks; interior nodes: 1).  Makes the polynomial preconditioner rank-local (block-Jacobi over ranks:
+ * no exchange inside the polynomial, one packed all-reduce per CG iteration for its result) instead of one exchange per
+ * polynomial step.  Call after tlfea_newton_set_interface. */
+int tlfea_newton_set_interface_owners(tlfea_newton_t s, const int *owned);
 
 #ifdef __cplusplus
 }

@@ -147,6 +147,8 @@ def main():
     ap.add_argument("--mesh", default="box")
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--out", default="")
+    ap.add_argument("--precond", default="exchange", choices=("local", "exchange"),
+                    help="rank-local polynomial preconditioner (owners set) or one exchange per polynomial step")
     args = ap.parse_args()
     import torch
     import torch.distributed as dist
@@ -171,14 +173,17 @@ def main():
         s = tl.SyncedNewtonSolver(d, d.get_n_constraint())
         s.SetParameters(tl.SyncedNewtonParams(1e-4, 0.0, 1e-6, 1e14, 5, 12, 1e-3))
         s.SetLinSolveOpts(tl.LinSolveOpts(1e-13, 20000, 10))
-        par.attach(s, part, torch, dist)
+        par.attach(s, part, torch, dist, local_preconditioner=(args.precond == "local"))
         if os.environ.get("TLFEA_VERBOSE"):
             s.SetVerbose(1)
         counts = []
+        pcg_iters = 0
         for _ in range(args.steps):
             s.Solve()
             st = s.GetStats()
             counts.append((st["outer"], st["newton"]))
+            pcg_iters += int(st["pcg_iters"])
+        n_collectives = s.n_collectives
         x_loc = np.stack(d.RetrievePositionToCPU(), axis=1)
         del s
         d.Destroy()
@@ -208,6 +213,8 @@ def main():
                   and [tuple(c) for c in counts] == ref_counts)
         report = dict(err=err, disp=disp, max_dup=max_dup, counts=counts, ref_counts=ref_counts, ok=ok,
                       n_iface=part.n_global_iface)
+        if args.engine != "oracle":
+            report.update(collectives=n_collectives, pcg_iters=pcg_iters)
         print(json.dumps(report), flush=True)
         if args.out:
             json.dump(report, open(args.out, "w"))

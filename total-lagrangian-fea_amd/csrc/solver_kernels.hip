@@ -517,9 +517,14 @@ void launch_lp_scale(hipStream_t s, int N, const double* D, const double* Dinv, 
   hipLaunchKernelGGL(lp_scale_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, D, Dinv, sc, Dinv_s);
 }
 
+// own / Dglob (multi-GPU, rank-local preconditioner): the copy is the block of the ASSEMBLED matrix on the nodes this
+// rank owns -- rows and columns of replicated nodes owned by another rank are dropped (identity on their diagonal),
+// and the diagonal blocks of owned partition-boundary nodes come from Dglob, the block diagonal summed over ranks
+// (off-diagonal boundary-boundary blocks keep this rank's part only: still symmetric positive definite).
 template <typename HT>
 __global__ __launch_bounds__(256) void lp_convert_kernel(int N, Incidence inc, const double* __restrict__ Hval,
-                                                        const double* __restrict__ sc, Blk8<HT>* __restrict__ B8,
+                                                        const double* __restrict__ sc, const int* __restrict__ own,
+                                                        const double* __restrict__ Dglob, Blk8<HT>* __restrict__ B8,
                                                         HT* __restrict__ B1) {
   const int l32 = threadIdx.x & 31;
   const int i = blockIdx.x * 8 + (threadIdx.x >> 5);  // 8 node rows per workgroup, 32 lanes per row
@@ -527,16 +532,21 @@ __global__ __launch_bounds__(256) void lp_convert_kernel(int N, Incidence inc, c
   const int off0 = inc.off[i], deg = inc.off[i + 1] - off0, row = 3 * deg;
   const double* Hi = Hval + (size_t)9 * off0;
   const double si[3] = {sc[3 * i], sc[3 * i + 1], sc[3 * i + 2]};
+  const bool own_i = !own || own[i];
   for (int k = l32; k < deg; k += 32) {
     const int c = inc.cols[off0 + k];
     const double sj[3] = {sc[3 * c], sc[3 * c + 1], sc[3 * c + 2]};
+    const bool keep = own_i && (!own || own[c]);
+    const bool diag = own && c == i;
     Blk8<HT> b;
     HT last = (HT)0;
 #pragma unroll
     for (int d = 0; d < 3; d++)
 #pragma unroll
       for (int e = 0; e < 3; e++) {
-        const HT v = (HT)(Hi[(size_t)d * row + 3 * k + e] * si[d] * sj[e]);
+        double h = diag ? (own_i ? Dglob[(size_t)9 * i + 3 * d + e] * si[d] * sj[e] : (d == e ? 1.0 : 0.0))
+                        : (keep ? Hi[(size_t)d * row + 3 * k + e] * si[d] * sj[e] : 0.0);
+        const HT v = (HT)h;
         if (3 * d + e < 8) b.v[3 * d + e] = v;
         else last = v;
       }
@@ -545,13 +555,29 @@ __global__ __launch_bounds__(256) void lp_convert_kernel(int N, Incidence inc, c
   }
 }
 
-void launch_lp_convert(hipStream_t s, int N, const Incidence& inc, const double* Hval, const double* sc, void* B8,
-                       void* B1, int bits) {
+void launch_lp_convert(hipStream_t s, int N, const Incidence& inc, const double* Hval, const double* sc, const int* own,
+                       const double* Dglob, void* B8, void* B1, int bits) {
   const dim3 g((N + 7) / 8), b(256);
   if (bits == 16)
-    hipLaunchKernelGGL((lp_convert_kernel<_Float16>), g, b, 0, s, N, inc, Hval, sc, (Blk8<_Float16>*)B8, (_Float16*)B1);
+    hipLaunchKernelGGL((lp_convert_kernel<_Float16>), g, b, 0, s, N, inc, Hval, sc, own, Dglob, (Blk8<_Float16>*)B8,
+                       (_Float16*)B1);
   else
-    hipLaunchKernelGGL((lp_convert_kernel<float>), g, b, 0, s, N, inc, Hval, sc, (Blk8<float>*)B8, (float*)B1);
+    hipLaunchKernelGGL((lp_convert_kernel<float>), g, b, 0, s, N, inc, Hval, sc, own, Dglob, (Blk8<float>*)B8,
+                       (float*)B1);
+}
+
+// sc_mask = own ? sc : 0 : scaling into / out of the polynomial that also drops the nodes another rank owns
+__global__ void mask_scale_kernel(int N, const double* __restrict__ sc, const int* __restrict__ own,
+                                  double* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const double m = own[i] ? 1.0 : 0.0;
+  out[3 * i] = m * sc[3 * i];
+  out[3 * i + 1] = m * sc[3 * i + 1];
+  out[3 * i + 2] = m * sc[3 * i + 2];
+}
+void launch_mask_scale(hipStream_t s, int N, const double* sc, const int* own, double* out) {
+  hipLaunchKernelGGL(mask_scale_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, sc, own, out);
 }
 
 // MODE 0: Chebyshev step (as cheb_step_kernel, scaled space); MODE 1: last step (returns z = S z^ and the r.z

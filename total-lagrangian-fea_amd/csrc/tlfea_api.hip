@@ -878,6 +878,11 @@ struct tlfea_newton_s {
   int n_if_loc = 0, n_if_glob = 0;  // local interface nodes / slots of the global exchange buffer
   int *d_if_node = nullptr, *d_if_slot = nullptr;
   double *d_ibuf = nullptr, *d_w = nullptr, *d_nw = nullptr, *d_wc = nullptr, *d_D = nullptr;
+  // rank-local polynomial preconditioner (multi-GPU): 1 for the nodes this rank owns (every replicated node has
+  // exactly one owner), and the scaling vector masked by it
+  int* d_own = nullptr;
+  double* d_sc_mask = nullptr;
+  double lam_max_loc = 0.0;
   bool sync_before_cb = true;
   tlfea_allreduce_fn ar = nullptr;
   void* ar_user = nullptr;
@@ -921,7 +926,7 @@ static void cg_graphs_destroy(tlfea_newton_t s);
 extern "C" int tlfea_newton_destroy(tlfea_newton_t s) {
   if (!s) return 0;
   void* ptrs[] = {s->d_v, s->d_vprev, s->d_lam, s->d_g, s->d_dv, s->d_r, s->d_b, s->d_eigv, s->d_cd, s->d_cd2, s->d_cres, s->d_xp, s->d_yp, s->d_zp, s->d_H,
-                  s->d_Kbuf, s->d_Dinv, s->d_p, s->d_p2, s->d_q, s->d_zv, s->d_parts, s->d_scal, s->d_if_node, s->d_if_slot, s->d_ibuf, s->d_w, s->d_nw, s->d_wc, s->d_D, s->d_B8, s->d_B1, s->d_sc, s->d_Dinv_s, s->d_cz, s->d_cz2, s->d_cres2, s->d_f32};
+                  s->d_Kbuf, s->d_Dinv, s->d_p, s->d_p2, s->d_q, s->d_zv, s->d_parts, s->d_scal, s->d_if_node, s->d_if_slot, s->d_ibuf, s->d_w, s->d_nw, s->d_wc, s->d_D, s->d_B8, s->d_B1, s->d_sc, s->d_Dinv_s, s->d_cz, s->d_cz2, s->d_cres2, s->d_f32, s->d_own, s->d_sc_mask};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   for (auto& e : s->ev)
@@ -1039,6 +1044,10 @@ extern "C" int tlfea_newton_set_interface(tlfea_newton_t s, const int* iface_nod
   s->n_constraints_global = s->n_constraints;
   HIP_TRY(hipStreamSynchronize(s->stream));
   s->stream = fn ? nullptr : s->stream_own;
+  if (s->d_own) {
+    (void)hipFree(s->d_own);
+    s->d_own = nullptr;
+  }
   if (!fn) return 0;
   tlfea_t10_t d = s->d;
   if (d->cons_mode == 2)
@@ -1072,6 +1081,21 @@ extern "C" int tlfea_newton_set_interface(tlfea_newton_t s, const int* iface_nod
   if (fn(user, s->d_ibuf, 1)) return fail("interface all-reduce callback failed");
   HIP_TRY(hipMemcpy(&cnt, s->d_ibuf, sizeof(double), hipMemcpyDeviceToHost));
   s->n_constraints_global = (int)(cnt + 0.5);
+  return 0;
+}
+
+// Which of the replicated partition-boundary nodes this rank OWNS (exactly one owner per node over all ranks; interior
+// nodes are owned by definition).  With owners set, the polynomial preconditioner becomes rank-local: each rank
+// applies it to the block of the matrix on its own nodes with no exchange inside, and ONE packed all-reduce per CG
+// iteration sums the result on the boundary (block-Jacobi over ranks; the CG around it restores the coupling).  Without
+// owners every polynomial step exchanges its SpMV result (deg-1 collectives per CG iteration instead of one).
+extern "C" int tlfea_newton_set_interface_owners(tlfea_newton_t s, const int* owned) {
+  if (!s || !owned) return fail("null argument");
+  if (!s->ar) return fail("tlfea_newton_set_interface_owners: set the interface first");
+  if (!s->d_own) TRY(dmalloc(&s->d_own, (size_t)s->N));
+  if (!s->d_sc_mask) TRY(dmalloc(&s->d_sc_mask, 3 * (size_t)s->N));
+  HIP_TRY(hipMemcpy(s->d_own, owned, (size_t)s->N * sizeof(int), hipMemcpyHostToDevice));
+  s->lam_max_loc = 0.0;
   return 0;
 }
 
@@ -1264,15 +1288,45 @@ static int lp_build(tlfea_newton_t s) {
     s->lp_bits_alloc = bits;
   }
   launch_lp_scale(s->stream, s->N, s->d_D, s->d_Dinv, s->d_sc, s->d_Dinv_s);
-  launch_lp_convert(s->stream, s->N, d->inc(), s->d_H, s->d_sc, s->d_B8, s->d_B1, bits);
-  if (!s->ar) launch_to_float(s->stream, (size_t)9 * s->N, s->d_Dinv_s, s->d_f32 + (size_t)18 * s->N);
+  const bool local = s->ar && s->d_own;  // rank-local preconditioner on the owned nodes
+  launch_lp_convert(s->stream, s->N, d->inc(), s->d_H, s->d_sc, local ? s->d_own : nullptr, s->d_D, s->d_B8, s->d_B1,
+                    bits);
+  if (local) launch_mask_scale(s->stream, s->N, s->d_sc, s->d_own, s->d_sc_mask);
+  if (!s->ar || local) launch_to_float(s->stream, (size_t)9 * s->N, s->d_Dinv_s, s->d_f32 + (size_t)18 * s->N);
   HIP_TRY(hipGetLastError());
   return 0;
 }
 
 // lambda_max(D^-1 H) by power iteration (warm-started from the previous solve's vector; H changes little between
 // Newton iterations).  Power iteration converges from below, hence the safety factor.
+// Rank-local variant: lambda_max of the scaled local block (the fp16/fp32 copy itself), no exchange.
+static int estimate_lam_max_local(tlfea_newton_t s) {
+  tlfea_t10_t d = s->d;
+  const int N = s->N, n = 3 * N, bits = cheb_bits_eff(s);
+  const bool cold = !(s->lam_max_loc > 0.0);
+  const int iters = cold ? 16 : 4;
+  // start vector: the masked scaling itself (positive on every owned DOF) when cold, else the last iterate
+  if (cold) HIP_TRY(hipMemcpyAsync(s->d_eigv, s->d_sc_mask, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
+  for (int k = 0; k <= iters; k++) {
+    if (k > 0) {
+      launch_cheb_lp(s->stream, N, d->nnz_coef, d->inc(), s->d_B8, s->d_B1, bits, s->d_Dinv_s, s->d_sc, s->d_eigv,
+                     s->d_coef, s->d_cd2, nullptr, nullptr, nullptr, nullptr, s->d_r, nullptr, s->d_q, 2);
+      launch_apply_dinv(s->stream, N, s->d_Dinv_s, s->d_q, s->d_eigv);
+    }
+    launch_norm2(s->stream, s->d_eigv, nullptr, n, part(s, 5), s->d_scal);
+    launch_scale_inv_sqrt(s->stream, n, s->d_scal, s->d_eigv);
+  }
+  double ss = 0.0;
+  TRY(fetch_scalar(s, s->d_scal, &ss));
+  if (!(ss > 0.0)) return fail("lambda_max estimate failed");
+  const char* fe = std::getenv("TLFEA_CHEB_LMAX_SCALE");
+  s->lam_max_loc = std::sqrt(ss) * (fe ? std::atof(fe) : 1.0);
+  s->lam_max = s->lam_max_loc;
+  return 0;
+}
+
 static int estimate_lam_max(tlfea_newton_t s, const double* d_b) {
+  if (s->ar && s->d_own && cheb_bits_eff(s) != 64) return estimate_lam_max_local(s);
   tlfea_t10_t d = s->d;
   const int N = s->N, n = 3 * N;
   const bool cold = !(s->lam_max > 0.0);
@@ -1332,9 +1386,12 @@ static int cheb_apply(tlfea_newton_t s, const double* d_r, double* d_z, double* 
   const bool lp = bits != 64;
   const double* Dinv = lp ? s->d_Dinv_s : s->d_Dinv;
   const double* sc = lp ? s->d_sc : nullptr;
-  if (lp && !s->ar) {
-    // single GPU: the whole polynomial in single precision (cheb32_kernel); d, z, res ping-pong so that a row's
-    // stores never order against loads of other rows; the last step returns z = S z^ in fp64 and the r.z slots
+  const bool local = s->ar && s->d_own;
+  if (lp && (!s->ar || local)) {
+    // single GPU, or rank-local on the owned nodes: the whole polynomial in single precision (cheb32_kernel); d, z,
+    // res ping-pong so that a row's stores never order against loads of other rows; the last step returns
+    // z = S z^ in fp64 and the r.z slots.  Rank-local: the masked scaling zeroes r and z on nodes another rank owns.
+    if (local) sc = s->d_sc_mask;
     const size_t n = 3 * (size_t)N;
     float *f_d = s->d_f32, *f_d2 = f_d + n, *f_z = f_d2 + n, *f_z2 = f_z + n, *f_r = f_z2 + n, *f_r2 = f_r + n;
     const float* Dinv_f = f_r2 + n;
@@ -1347,6 +1404,8 @@ static int cheb_apply(tlfea_newton_t s, const double* d_r, double* d_z, double* 
       std::swap(f_z, f_z2);
       std::swap(f_r, f_r2);
     }
+    // every node's z comes from its owner (zero elsewhere), r.z = sum over owners: one collective for both
+    if (local) TRY(iface_sum(s, d_z, 3, rz_part, kNPart));
     return 0;
   }
   // multi-GPU LP path: fp64 vectors, q = Hs d summed over ranks between the SpMV and the vector update
@@ -1397,7 +1456,7 @@ static int enqueue_cg_iteration(tlfea_newton_t s, double* d_x, bool first, int c
   if (deg > 1) {
     // polynomial preconditioner: z = Cheb(r), r.z slots -> part(cur)   (deg-1 SpMV launches, no reductions)
     TRY(cheb_apply(s, s->d_r, s->d_zv, part(s, cur)));
-    if (s->ar) TRY(parts_sum(s, part(s, cur)));
+    if (s->ar && !(s->d_own && cheb_bits_eff(s) != 64)) TRY(parts_sum(s, part(s, cur)));
   }
   if (s->profiling) (void)hipEventRecord(s->ev[4], s->stream);
   // beta = rz(cur)/rz(1-cur); p = z + beta p; q = H p; partials of p.q
@@ -1558,7 +1617,7 @@ extern "C" int tlfea_newton_get_linsolve_info(tlfea_newton_t s, int* cheb_degree
   if (!s) return fail("null argument");
   if (cheb_degree) *cheb_degree = cheb_degree_eff(s);
   if (cheb_bits) *cheb_bits = cheb_bits_eff(s);
-  if (cheb_vector_bits) *cheb_vector_bits = (cheb_bits_eff(s) != 64 && !s->ar) ? 32 : 64;
+  if (cheb_vector_bits) *cheb_vector_bits = (cheb_bits_eff(s) != 64 && (!s->ar || s->d_own)) ? 32 : 64;
   return 0;
 }
 extern "C" int tlfea_newton_eval_gradient(tlfea_newton_t s, double* norm_g) {

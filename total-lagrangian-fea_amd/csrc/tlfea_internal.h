@@ -109,8 +109,9 @@ void launch_cheb_update(hipStream_t s, int N, const double* Dinv, const double* 
                         const double* sc, double* rz_part, bool last);
 // low-precision (fp16/fp32) scaled block-CSR copy of H for the polynomial preconditioner
 void launch_lp_scale(hipStream_t s, int N, const double* D, const double* Dinv, double* sc, double* Dinv_s);
-void launch_lp_convert(hipStream_t s, int N, const Incidence& inc, const double* Hval, const double* sc, void* B8,
-                       void* B1, int bits);
+void launch_lp_convert(hipStream_t s, int N, const Incidence& inc, const double* Hval, const double* sc, const int* own,
+                       const double* Dglob, void* B8, void* B1, int bits);
+void launch_mask_scale(hipStream_t s, int N, const double* sc, const int* own, double* out);
 // the polynomial in single precision (single-GPU path): fp32 vectors, fp16/fp32 matrix, fp32 accumulation
 void launch_to_float(hipStream_t s, size_t n, const double* a, float* b);
 void launch_cheb32_init(hipStream_t s, int N, const float* Dinv_f, const double* r, const double* sc,

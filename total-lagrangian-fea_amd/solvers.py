@@ -187,7 +187,20 @@ class SyncedNewtonSolver:
                 print("allreduce callback failed:", repr(exc), flush=True)
                 return 1
 
-        self._cb = ALLREDUCE_FN(_cb)
+        self.n_collectives = 0
+
+        def _cb_counted(user, ptr, n):
+            self.n_collectives += 1
+            return _cb(user, ptr, n)
+
+        self._cb = ALLREDUCE_FN(_cb_counted)
         check(self._lib.tlfea_newton_set_interface(self._h, ip(nodes), ip(slots), int(nodes.size),
                                                    int(n_global_iface), dp(w), self._cb, None,
                                                    int(sync_before_callback)))
+
+    def SetInterfaceOwners(self, node_owned):
+        """node_owned[n_coef] = 1 where this rank owns the node (one owner per replicated node over all ranks):
+        switches the polynomial preconditioner to its rank-local form (see tlfea_c.h)."""
+        own = np.ascontiguousarray(node_owned, dtype=np.int32)
+        assert own.size == self.n_coef
+        check(self._lib.tlfea_newton_set_interface_owners(self._h, ip(own)))
