@@ -828,7 +828,8 @@ void launch_tangent_blocks(hipStream_t s, const ElemView& m, const Material& mat
 // H layout == the reference's DOF-level CSR (SyncedNewton.cu:163-205): for node i with deg
 // neighbours, values[9*off[i] + d*3*deg + 3*k + e] = H(3i+d, 3*cols[off[i]+k]+e).
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void assemble_rows_kernel(int N, int S, Incidence inc, const double* __restrict__ Kbuf,
+template <int S>
+__global__ __launch_bounds__(64) void assemble_rows_kernel(int N, Incidence inc, const double* __restrict__ Kbuf,
                                                           const double* __restrict__ mval, double inv_h,
                                                           const int* __restrict__ fixed_slot,
                                                           const double* __restrict__ nw, double penalty,
@@ -839,7 +840,7 @@ __global__ __launch_bounds__(64) void assemble_rows_kernel(int N, int S, Inciden
   const int off0 = inc.off[i];
   const int deg = inc.off[i + 1] - off0;
   const int n9 = 9 * deg, row = 3 * deg;
-  const int npair = S * (S + 1) / 2;
+  constexpr int npair = S * (S + 1) / 2;
   for (int t = lane; t < n9; t += 64) acc[t] = 0.0;
   __syncthreads();
   // M/h on the xyz-diagonal of every block (SyncedNewton.cu:214-259)
@@ -854,19 +855,51 @@ __global__ __launch_bounds__(64) void assemble_rows_kernel(int N, int S, Inciden
   if (lane < 3 && fixed_slot && fixed_slot[i] >= 0)
     acc[lane * row + 3 * inc.diagpos[i] + lane] += (nw ? nw[i] : 1.0) * penalty;
   __syncthreads();
+  // The node's incident elements, ascending (fixed summation order).  A row is a chain of dependent memory
+  // round trips (incidence code -> block values / column slots -> LDS add): the loads of a whole CHUNK of
+  // elements are issued before the first add, branch-free (elements past the end repeat the last one and are
+  // skipped at the add), so the row pays two round trips per chunk instead of two per element.
+  constexpr int kChunk = 8;
+  constexpr int kPass = (9 * S + 63) / 64;
   const int k0 = inc.n2e_off[i], k1 = inc.n2e_off[i + 1];
-  for (int k = k0; k < k1; k++) {
-    const int code = inc.n2e[k];
-    const int e = code / S, il = code - e * S;
-    const double* Ke = Kbuf + (size_t)e * (npair * 9);
-    const int* pos = inc.n2e_pos + (size_t)k * S;
-    for (int t = lane; t < 9 * S; t += 64) {
-      const int j = t / 9, dd = (t % 9) / 3, ee = t % 3;
-      const double val =
-          (il <= j) ? Ke[pair_index(S, il, j) * 9 + dd * 3 + ee] : Ke[pair_index(S, j, il) * 9 + ee * 3 + dd];
-      acc[dd * row + 3 * pos[j] + ee] += val;
+  // this lane's fixed share of an (element, local node) block row: entries t = lane + 64 u
+  int tj[kPass], tdd[kPass], tee[kPass];
+#pragma unroll
+  for (int u = 0; u < kPass; u++) {
+    const int t = min(lane + 64 * u, 9 * S - 1);
+    tj[u] = t / 9;
+    tdd[u] = (t % 9) / 3;
+    tee[u] = t % 3;
+  }
+  for (int kc = k0; kc < k1; kc += kChunk) {
+    const int klast = k1 - 1;
+    int code[kChunk];
+#pragma unroll
+    for (int c = 0; c < kChunk; c++) code[c] = inc.n2e[min(kc + c, klast)];
+    double v[kChunk][kPass];
+    int pj[kChunk][kPass];
+#pragma unroll
+    for (int c = 0; c < kChunk; c++) {
+      const int e = code[c] / S, il = code[c] - e * S;
+      const double* Ke = Kbuf + (size_t)e * (npair * 9);
+      const int* pos = inc.n2e_pos + (size_t)min(kc + c, klast) * S;
+#pragma unroll
+      for (int u = 0; u < kPass; u++) {
+        const int j = tj[u];
+        v[c][u] = (il <= j) ? Ke[pair_index(S, il, j) * 9 + tdd[u] * 3 + tee[u]]
+                            : Ke[pair_index(S, j, il) * 9 + tee[u] * 3 + tdd[u]];
+        pj[c][u] = pos[j];
+      }
     }
-    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < kChunk; c++) {
+      if (kc + c < k1) {
+#pragma unroll
+        for (int u = 0; u < kPass; u++)
+          if (lane + 64 * u < 9 * S) acc[tdd[u] * row + 3 * pj[c][u] + tee[u]] += v[c][u];
+      }
+      __syncthreads();
+    }
   }
   double* out = Hval + (size_t)9 * off0;
   for (int t = lane; t < n9; t += 64) out[t] = acc[t];
@@ -876,8 +909,15 @@ void launch_assemble_rows(hipStream_t s, int N, int S, int maxdeg, const Inciden
                           const double* mval, double inv_h, const int* fixed_slot, const double* nw, double penalty,
                           double* Hval) {
   const size_t lds = (size_t)9 * maxdeg * sizeof(double);
-  hipLaunchKernelGGL(assemble_rows_kernel, dim3(N), dim3(64), lds, s, N, S, inc, Kbuf, mval, inv_h, fixed_slot, nw,
-                     penalty, Hval);
+  if (S == 10)
+    hipLaunchKernelGGL((assemble_rows_kernel<10>), dim3(N), dim3(64), lds, s, N, inc, Kbuf, mval, inv_h, fixed_slot, nw,
+                       penalty, Hval);
+  else if (S == 8)
+    hipLaunchKernelGGL((assemble_rows_kernel<8>), dim3(N), dim3(64), lds, s, N, inc, Kbuf, mval, inv_h, fixed_slot, nw,
+                       penalty, Hval);
+  else
+    hipLaunchKernelGGL((assemble_rows_kernel<16>), dim3(N), dim3(64), lds, s, N, inc, Kbuf, mval, inv_h, fixed_slot, nw,
+                       penalty, Hval);
 }
 
 // ------------------------------------------------------------------------------------------------
