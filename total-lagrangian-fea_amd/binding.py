@@ -4,7 +4,7 @@ import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtlfea_hip.so")
+LIB_PATH = os.environ.get("TLFEA_LIB_PATH") or os.path.join(_HERE, "libtlfea_hip.so")  # override: A/B experiments
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "tlfea_c.h")
 _LIB = None
 

@@ -815,8 +815,52 @@ void launch_to_float(hipStream_t s, size_t n, const double* a, float* b) {
   hipLaunchKernelGGL(to_float_kernel, dim3((unsigned)std::min<size_t>(4096, (n + 255) / 256)), dim3(256), 0, s, n, a, b);
 }
 
-template <typename HT, int L, bool LAST, bool TILED>
-__global__ __launch_bounds__(1024) void cheb32_kernel(int N, Incidence inc, const Blk8<HT>* __restrict__ B8,
+// One lane's two blocks of a round of a row (branch-free: lanes past the end of the row re-read its first block, which
+// is always there, and are masked) ...
+template <typename HT, int L>
+struct C32Round {
+  Blk8<HT> a, b;
+  HT a8, b8;
+  int ca, cb;
+  float ma, mb;
+  __device__ __forceinline__ void load(const Incidence& inc, const Blk8<HT>* __restrict__ B8,
+                                       const HT* __restrict__ B1, int base, int deg, int k) {
+    const int ga = base + (k < deg ? k : 0), gb = base + (k + L < deg ? k + L : 0);
+    ma = k < deg ? 1.f : 0.f;
+    mb = k + L < deg ? 1.f : 0.f;
+    ca = inc.cols[ga];
+    cb = inc.cols[gb];
+    a = B8[ga];
+    b = B8[gb];
+    a8 = B1[ga];
+    b8 = B1[gb];
+  }
+};
+// ... and their contribution to the lane's three row sums once the gathered vector entries x (block a), y (block b)
+// are back
+template <typename HT, int L>
+__device__ __forceinline__ void c32_fma(const C32Round<HT, L>& R, const float (&x)[3], const float (&y)[3], float& s0,
+                                        float& s1, float& s2) {
+  const float x0 = R.ma * x[0], x1 = R.ma * x[1], x2 = R.ma * x[2];
+  const float y0 = R.mb * y[0], y1 = R.mb * y[1], y2 = R.mb * y[2];
+  s0 += (float)R.a.v[0] * x0 + (float)R.a.v[1] * x1 + (float)R.a.v[2] * x2;
+  s1 += (float)R.a.v[3] * x0 + (float)R.a.v[4] * x1 + (float)R.a.v[5] * x2;
+  s2 += (float)R.a.v[6] * x0 + (float)R.a.v[7] * x1 + (float)R.a8 * x2;
+  s0 += (float)R.b.v[0] * y0 + (float)R.b.v[1] * y1 + (float)R.b.v[2] * y2;
+  s1 += (float)R.b.v[3] * y0 + (float)R.b.v[4] * y1 + (float)R.b.v[5] * y2;
+  s2 += (float)R.b.v[6] * y0 + (float)R.b.v[7] * y1 + (float)R.b8 * y2;
+}
+
+// TWO: a lane group works on two rows at a time (i and i + stride).  A row is three dependent memory phases (offsets +
+// epilogue operands -> columns + blocks -> gathered vector entries); two independent rows per group double the bytes
+// in flight per wavefront at each phase.  Pays on large meshes (config C/D: -2..-4 %), costs parallelism on small
+// ones (config B: +4 %), so the launcher picks by size.  All loads of the common path (first round) are branch-free,
+// so they issue back to back.
+// Rows are swept in tiles (see cheb_lp_kernel).  TPB threads per workgroup: 256 for the ordinary steps -- the grid is
+// sized to what is resident at once (occupancy x CUs) so that the sweep stays one narrow window; 1024 for the last
+// step, whose r.z partials must fit the kNPart reduction slots.
+template <typename HT, int L, bool LAST, int TPB, bool TWO>
+__global__ __launch_bounds__(TPB) void cheb32_kernel(int N, Incidence inc, const Blk8<HT>* __restrict__ B8,
                                                      const HT* __restrict__ B1, const float* __restrict__ Dinv_f,
                                                      const double* __restrict__ sc, const float* __restrict__ d_old,
                                                      const double* __restrict__ coef, float* __restrict__ d_new,
@@ -826,76 +870,112 @@ __global__ __launch_bounds__(1024) void cheb32_kernel(int N, Incidence inc, cons
                                                      double* __restrict__ rz_part) {
   __shared__ double sh[32];
   const float c1 = (float)coef[0], c2 = (float)coef[1];
-  constexpr int G = 1024 / L;
+  constexpr int G = TPB / L;
   const int lane = threadIdx.x & (L - 1), grp = threadIdx.x / L;
   const int c = lane < 3 ? lane : 0;
-  int i, r1, stride;
-  if (TILED) {  // see cheb_lp_kernel
-    i = blockIdx.x * G + grp;
-    r1 = N;
-    stride = gridDim.x * G;
-  } else {
-    const int rows_per_block = (N + gridDim.x - 1) / gridDim.x;
-    const int r0 = blockIdx.x * rows_per_block;
-    i = r0 + grp;
-    r1 = min(N, r0 + rows_per_block);
-    stride = G;
-  }
+  const int r1 = N, stride = gridDim.x * G;
+  int i = blockIdx.x * G + grp;
   double rz = 0.0;
-  for (; i < r1; i += stride) {
-    const int base = inc.off[i], deg = inc.off[i + 1] - base;
-    // operands lanes 0..2 need to finish component c of the row: requested first, back before the reduction is done
-    float e0 = 0.f, e1 = 0.f, e2 = 0.f, D0 = 0.f, D1 = 0.f, D2 = 0.f, dc = 0.f, zc = 0.f;
-    if (lane < 3) {
-      e0 = res[3 * i];
-      e1 = res[3 * i + 1];
-      e2 = res[3 * i + 2];
-      const float* D = Dinv_f + (size_t)9 * i + 3 * c;
-      D0 = D[0];
-      D1 = D[1];
-      D2 = D[2];
-      dc = d_old[3 * i + c];
-      zc = z[3 * i + c];
+  for (; i < r1; i += (TWO ? 2 : 1) * stride) {
+    const bool two = TWO && i + stride < r1;
+    const int iA = i, iB = two ? i + stride : i;  // without a second row the first is shadowed (stores masked)
+    // phase 1: offsets and the operands lanes 0..2 need to finish component c of each row
+    const int baseA = inc.off[iA], degA = inc.off[iA + 1] - baseA;
+    const int baseB = inc.off[iB], degB = inc.off[iB + 1] - baseB;
+    float eA0 = 0.f, eA1 = 0.f, eA2 = 0.f, eB0 = 0.f, eB1 = 0.f, eB2 = 0.f, DA0 = 0.f, DA1 = 0.f, DA2 = 0.f, DB0 = 0.f,
+          DB1 = 0.f, DB2 = 0.f, dcA = 0.f, zcA = 0.f, dcB = 0.f, zcB = 0.f;
+    if (TWO || lane < 3) {  // TWO: branch-free (every lane loads, the group's addresses coincide); else lanes 0..2 only
+      eA0 = res[3 * iA];
+      eA1 = res[3 * iA + 1];
+      eA2 = res[3 * iA + 2];
+      const float* DA = Dinv_f + (size_t)9 * iA + 3 * c;
+      DA0 = DA[0];
+      DA1 = DA[1];
+      DA2 = DA[2];
+      dcA = d_old[3 * iA + c];
+      zcA = z[3 * iA + c];
+      if (TWO) {
+        eB0 = res[3 * iB];
+        eB1 = res[3 * iB + 1];
+        eB2 = res[3 * iB + 2];
+        const float* DB = Dinv_f + (size_t)9 * iB + 3 * c;
+        DB0 = DB[0];
+        DB1 = DB[1];
+        DB2 = DB[2];
+        dcB = d_old[3 * iB + c];
+        zcB = z[3 * iB + c];
+      }
     }
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
-    for (int k = lane; k < deg; k += 2 * L) {
-      // lanes past the end of the row read its first block and are masked
-      const int ga = base + k, gb = base + (k + L < deg ? k + L : 0);
-      const float mb = k + L < deg ? 1.f : 0.f;
-      const int ca = inc.cols[ga], cb = inc.cols[gb];
-      const Blk8<HT> a = B8[ga], b = B8[gb];
-      const HT a8 = B1[ga], b8 = B1[gb];
-      const float* xa = d_old + 3 * (size_t)ca;
-      const float* xb = d_old + 3 * (size_t)cb;
-      const float x0 = xa[0], x1 = xa[1], x2 = xa[2];
-      const float y0 = mb * xb[0], y1 = mb * xb[1], y2 = mb * xb[2];
-      s0 += (float)a.v[0] * x0 + (float)a.v[1] * x1 + (float)a.v[2] * x2;
-      s1 += (float)a.v[3] * x0 + (float)a.v[4] * x1 + (float)a.v[5] * x2;
-      s2 += (float)a.v[6] * x0 + (float)a.v[7] * x1 + (float)a8 * x2;
-      s0 += (float)b.v[0] * y0 + (float)b.v[1] * y1 + (float)b.v[2] * y2;
-      s1 += (float)b.v[3] * y0 + (float)b.v[4] * y1 + (float)b.v[5] * y2;
-      s2 += (float)b.v[6] * y0 + (float)b.v[7] * y1 + (float)b8 * y2;
+    // phase 2: first round of both rows
+    C32Round<HT, L> RA, RB;
+    RA.load(inc, B8, B1, baseA, degA, lane);
+    if (TWO) RB.load(inc, B8, B1, baseB, degB, lane);
+    else RB = RA;
+    // phase 3: gathers
+    float xA[3], yA[3], xB[3], yB[3];
+    {
+      const float* pa = d_old + 3 * (size_t)RA.ca;
+      const float* pb = d_old + 3 * (size_t)RA.cb;
+      const float* qa = d_old + 3 * (size_t)RB.ca;
+      const float* qb = d_old + 3 * (size_t)RB.cb;
+#pragma unroll
+      for (int j = 0; j < 3; j++) {
+        xA[j] = pa[j];
+        yA[j] = pb[j];
+        xB[j] = TWO ? qa[j] : 0.f;
+        yB[j] = TWO ? qb[j] : 0.f;
+      }
+    }
+    float sA0 = 0.f, sA1 = 0.f, sA2 = 0.f, sB0 = 0.f, sB1 = 0.f, sB2 = 0.f;
+    c32_fma<HT, L>(RA, xA, yA, sA0, sA1, sA2);
+    if (TWO) c32_fma<HT, L>(RB, xB, yB, sB0, sB1, sB2);
+    // further rounds of long rows (more than 2 L blocks)
+    for (int k = lane + 2 * L; k < degA; k += 2 * L) {
+      C32Round<HT, L> T;
+      T.load(inc, B8, B1, baseA, degA, k);
+      const float* pa = d_old + 3 * (size_t)T.ca;
+      const float* pb = d_old + 3 * (size_t)T.cb;
+      const float x[3] = {pa[0], pa[1], pa[2]}, y[3] = {pb[0], pb[1], pb[2]};
+      c32_fma<HT, L>(T, x, y, sA0, sA1, sA2);
+    }
+    for (int k = lane + 2 * L; TWO && k < degB; k += 2 * L) {
+      C32Round<HT, L> T;
+      T.load(inc, B8, B1, baseB, degB, k);
+      const float* pa = d_old + 3 * (size_t)T.ca;
+      const float* pb = d_old + 3 * (size_t)T.cb;
+      const float x[3] = {pa[0], pa[1], pa[2]}, y[3] = {pb[0], pb[1], pb[2]};
+      c32_fma<HT, L>(T, x, y, sB0, sB1, sB2);
     }
 #pragma unroll
     for (int o = L / 2; o > 0; o >>= 1) {
-      s0 += __shfl_xor(s0, o);
-      s1 += __shfl_xor(s1, o);
-      s2 += __shfl_xor(s2, o);
+      sA0 += __shfl_xor(sA0, o);
+      sA1 += __shfl_xor(sA1, o);
+      sA2 += __shfl_xor(sA2, o);
+      if (TWO) {
+        sB0 += __shfl_xor(sB0, o);
+        sB1 += __shfl_xor(sB1, o);
+        sB2 += __shfl_xor(sB2, o);
+      }
     }
     if (lane < 3) {
-      e0 -= s0;
-      e1 -= s1;
-      e2 -= s2;
-      const float dn = c1 * dc + c2 * (D0 * e0 + D1 * e1 + D2 * e2);
-      const float zn = zc + dn;
-      d_new[3 * i + c] = dn;
-      if (LAST) {
-        const double zt = sc[3 * i + c] * (double)zn;
-        z_out[3 * i + c] = zt;
-        rz += r[3 * i + c] * zt;
-      } else {
-        z_new[3 * i + c] = zn;
-        res_new[3 * i + c] = (c == 0) ? e0 : ((c == 1) ? e1 : e2);
+#pragma unroll
+      for (int w = 0; w < 2; w++) {
+        if (w == 1 && !two) break;
+        const int iw = w ? iB : iA;
+        const float e0 = (w ? eB0 : eA0) - (w ? sB0 : sA0), e1 = (w ? eB1 : eA1) - (w ? sB1 : sA1),
+                    e2 = (w ? eB2 : eA2) - (w ? sB2 : sA2);
+        const float dn = c1 * (w ? dcB : dcA) +
+                         c2 * ((w ? DB0 : DA0) * e0 + (w ? DB1 : DA1) * e1 + (w ? DB2 : DA2) * e2);
+        const float zn = (w ? zcB : zcA) + dn;
+        d_new[3 * iw + c] = dn;
+        if (LAST) {
+          const double zt = sc[3 * iw + c] * (double)zn;
+          z_out[3 * iw + c] = zt;
+          rz += r[3 * iw + c] * zt;
+        } else {
+          z_new[3 * iw + c] = zn;
+          res_new[3 * iw + c] = (c == 0) ? e0 : ((c == 1) ? e1 : e2);
+        }
       }
     }
   }
@@ -907,37 +987,52 @@ __global__ __launch_bounds__(1024) void cheb32_kernel(int N, Incidence inc, cons
   }
 }
 
+template <typename K>
+static int resident_blocks(K kernel, int tpb) {  // workgroups of this kernel resident on the device at once
+  int per_cu = 0, dev = 0, cus = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, tpb, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+  (void)hipGetDevice(&dev);
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+  return per_cu * cus;
+}
+
+template <typename T, int LL>
+static void launch_cheb32_t(hipStream_t s, int N, const Incidence& inc, const void* B8, const void* B1,
+                            const float* Dinv_f, const double* sc, const float* d_old, const double* coef,
+                            float* d_new, const float* z, float* z_new, const float* res, float* res_new,
+                            const double* r, double* z_out, double* rz_part, bool last) {
+#define TLFEA_C32_ARGS N, inc, (const Blk8<T>*)B8, (const T*)B1, Dinv_f, sc, d_old, coef, d_new, z, z_new, res, res_new, r, z_out, rz_part
+  if (last) {
+    constexpr int TPB = 1024, G = TPB / LL;
+    const dim3 g(std::max(1, std::min(kNPart, (N + G - 1) / G))), b(TPB);
+    hipLaunchKernelGGL((cheb32_kernel<T, LL, true, TPB, false>), g, b, 0, s, TLFEA_C32_ARGS);
+  } else if (N > 200000) {  // bandwidth regime: two rows per lane group, 256-thread workgroups, resident grid
+    constexpr int TPB = 256, G = TPB / LL;
+    static const int resident = resident_blocks(cheb32_kernel<T, LL, false, TPB, true>, TPB);
+    const dim3 g(std::max(1, std::min(resident, (N + 2 * G - 1) / (2 * G)))), b(TPB);
+    hipLaunchKernelGGL((cheb32_kernel<T, LL, false, TPB, true>), g, b, 0, s, TLFEA_C32_ARGS);
+  } else {  // latency regime: as many independent groups as there are rows
+    constexpr int TPB = 1024, G = TPB / LL;
+    const dim3 g(std::max(1, std::min(kNPart, (N + G - 1) / G))), b(TPB);
+    hipLaunchKernelGGL((cheb32_kernel<T, LL, false, TPB, false>), g, b, 0, s, TLFEA_C32_ARGS);
+  }
+#undef TLFEA_C32_ARGS
+}
+
 void launch_cheb32(hipStream_t s, int N, int nnz_coef, const Incidence& inc, const void* B8, const void* B1, int bits,
                    const float* Dinv_f, const double* sc, const float* d_old, const double* coef, float* d_new,
                    const float* z, float* z_new, const float* res, float* res_new, const double* r, double* z_out,
                    double* rz_part, bool last) {
-  const int L = lp_lanes(N, nnz_coef);
-  const dim3 g(std::max(1, std::min(kNPart, (N + 1024 / L - 1) / (1024 / L)))), b(1024);
-  const bool tiled = row_map_tiled();
-#define TLFEA_C32(T, LL, LA, TI)                                                                                    \
-  hipLaunchKernelGGL((cheb32_kernel<T, LL, LA, TI>), g, b, 0, s, N, inc, (const Blk8<T>*)B8, (const T*)B1, Dinv_f, sc, \
-                     d_old, coef, d_new, z, z_new, res, res_new, r, z_out, rz_part)
-#define TLFEA_C32_T(T, LL, LA)             \
-  do {                                     \
-    if (tiled) TLFEA_C32(T, LL, LA, true); \
-    else TLFEA_C32(T, LL, LA, false);      \
-  } while (0)
-#define TLFEA_C32_LA(T, LL)                \
-  do {                                     \
-    if (last) TLFEA_C32_T(T, LL, true);    \
-    else TLFEA_C32_T(T, LL, false);        \
-  } while (0)
-#define TLFEA_C32_L(T)                     \
-  do {                                     \
-    if (L == 8) TLFEA_C32_LA(T, 8);        \
-    else if (L == 16) TLFEA_C32_LA(T, 16); \
-    else TLFEA_C32_LA(T, 32);              \
-  } while (0)
-  if (bits == 16) TLFEA_C32_L(_Float16);
-  else TLFEA_C32_L(float);
-#undef TLFEA_C32_L
-#undef TLFEA_C32_LA
-#undef TLFEA_C32_T
+  const int L = lp_lanes(N, nnz_coef) >= 32 ? 32 : 16;
+#define TLFEA_C32(T, LL) \
+  launch_cheb32_t<T, LL>(s, N, inc, B8, B1, Dinv_f, sc, d_old, coef, d_new, z, z_new, res, res_new, r, z_out, rz_part, last)
+  if (bits == 16) {
+    if (L == 32) TLFEA_C32(_Float16, 32);
+    else TLFEA_C32(_Float16, 16);
+  } else {
+    if (L == 32) TLFEA_C32(float, 32);
+    else TLFEA_C32(float, 16);
+  }
 #undef TLFEA_C32
 }
 
