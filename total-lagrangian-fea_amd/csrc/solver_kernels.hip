@@ -1112,6 +1112,55 @@ __global__ __launch_bounds__(256) void pcg_update_noz_kernel(int N, const double
     for (int k = gridDim.x + threadIdx.x; k < kNPart; k += blockDim.x) rr_part[k] = 0.0;
 }
 
+// pcg_update_noz + cheb32_init of the NEXT iteration's polynomial in one launch (single-GPU low-precision path): the
+// updated residual is scaled and block-Jacobi-preconditioned into the fp32 start vectors d, z^, res^ while it is
+// still in registers.  One launch less per CG iteration (about 4 % of an iteration on small meshes).
+__global__ __launch_bounds__(256) void pcg_update_init32_kernel(
+    int N, const double* __restrict__ p, const double* __restrict__ q, const double* __restrict__ rz_part_old,
+    const double* __restrict__ pq_part, double* __restrict__ x, double* __restrict__ r, double* __restrict__ rr_part,
+    double* __restrict__ indefinite, const float* __restrict__ Dinv_f, const double* __restrict__ sc,
+    const double* __restrict__ coef, float* __restrict__ d, float* __restrict__ z, float* __restrict__ res) {
+  __shared__ double sh[32];
+  double rz_old, pq;
+  sum_slots2(rz_part_old, pq_part, rz_old, pq, sh);
+  const double alpha = pq != 0.0 ? rz_old / pq : 0.0;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && rz_old < 0.0) indefinite[0] = 1.0;
+  const float inv_theta = (float)coef[0];
+  double rr = 0.0;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < N; i += gridDim.x * 256) {
+    float rs[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      x[3 * i + c] += alpha * p[3 * i + c];
+      const double rv = r[3 * i + c] - alpha * q[3 * i + c];
+      r[3 * i + c] = rv;
+      rr += rv * rv;
+      rs[c] = (float)(rv * sc[3 * i + c]);
+    }
+    const float* D = Dinv_f + (size_t)9 * i;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      const float v = (D[3 * c] * rs[0] + D[3 * c + 1] * rs[1] + D[3 * c + 2] * rs[2]) * inv_theta;
+      d[3 * i + c] = v;
+      z[3 * i + c] = v;
+      res[3 * i + c] = rs[c];
+    }
+  }
+  const double t = block_sum(rr, sh);
+  if (threadIdx.x == 0) rr_part[blockIdx.x] = t;
+  if (blockIdx.x == 0)
+    for (int k = gridDim.x + threadIdx.x; k < kNPart; k += blockDim.x) rr_part[k] = 0.0;
+}
+
+void launch_pcg_update_init32(hipStream_t s, int N, const double* p, const double* q, const double* rz_part_old,
+                              const double* pq_part, double* x, double* r, double* rr_part, double* indefinite,
+                              const float* Dinv_f, const double* sc, const double* coef, float* d, float* z,
+                              float* res) {
+  const int n_blocks = std::max(1, std::min(kNPart, (N + 255) / 256));
+  hipLaunchKernelGGL(pcg_update_init32_kernel, dim3(n_blocks), dim3(256), 0, s, N, p, q, rz_part_old, pq_part, x, r,
+                     rr_part, indefinite, Dinv_f, sc, coef, d, z, res);
+}
+
 void launch_pcg_update_noz(hipStream_t s, int N, const double* w, const double* p, const double* q,
                            const double* rz_part_old, const double* pq_part, double* x, double* r, double* rr_part,
                            double* indefinite) {

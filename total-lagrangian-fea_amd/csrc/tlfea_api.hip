@@ -1378,7 +1378,7 @@ static int cheb_upload_coefficients(tlfea_newton_t s) {
 }
 
 // z = p_deg(D^-1 H) D^-1 r on [lmax/kappa, lmax]; the last step leaves the r.z slots in rz_part
-static int cheb_apply(tlfea_newton_t s, const double* d_r, double* d_z, double* rz_part) {
+static int cheb_apply(tlfea_newton_t s, const double* d_r, double* d_z, double* rz_part, bool init_done = false) {
   tlfea_t10_t d = s->d;
   const int N = s->N, deg = cheb_degree_eff(s);
   double *d_old = s->d_cd, *d_new = s->d_cd2;
@@ -1395,7 +1395,8 @@ static int cheb_apply(tlfea_newton_t s, const double* d_r, double* d_z, double* 
     const size_t n = 3 * (size_t)N;
     float *f_d = s->d_f32, *f_d2 = f_d + n, *f_z = f_d2 + n, *f_z2 = f_z + n, *f_r = f_z2 + n, *f_r2 = f_r + n;
     const float* Dinv_f = f_r2 + n;
-    launch_cheb32_init(s->stream, N, Dinv_f, d_r, sc, s->d_coef, f_d, f_z, f_r);
+    // init_done: the previous iteration's update kernel already wrote the start vectors (pcg_update_init32_kernel)
+    if (!init_done) launch_cheb32_init(s->stream, N, Dinv_f, d_r, sc, s->d_coef, f_d, f_z, f_r);
     for (int k = 1; k < deg; k++) {
       const bool last = (k == deg - 1);
       launch_cheb32(s->stream, N, d->nnz_coef, d->inc(), s->d_B8, s->d_B1, bits, Dinv_f, sc, f_d, s->d_coef + 2 * k, f_d2,
@@ -1453,9 +1454,11 @@ static int enqueue_cg_iteration(tlfea_newton_t s, double* d_x, bool first, int c
   double* pq_part = part(s, 2);
   double *p_old = s->d_p, *p_new = s->d_p2;
   if (fused && cur) std::swap(p_old, p_new);
+  // single-GPU fp32 polynomial: its start vectors come out of the previous iteration's update kernel
+  const bool fuse_init = deg > 1 && cheb_bits_eff(s) != 64 && !s->ar;
   if (deg > 1) {
     // polynomial preconditioner: z = Cheb(r), r.z slots -> part(cur)   (deg-1 SpMV launches, no reductions)
-    TRY(cheb_apply(s, s->d_r, s->d_zv, part(s, cur)));
+    TRY(cheb_apply(s, s->d_r, s->d_zv, part(s, cur), fuse_init && !first));
     if (s->ar && !(s->d_own && cheb_bits_eff(s) != 64)) TRY(parts_sum(s, part(s, cur)));
   }
   if (s->profiling) (void)hipEventRecord(s->ev[4], s->stream);
@@ -1479,8 +1482,15 @@ static int enqueue_cg_iteration(tlfea_newton_t s, double* d_x, bool first, int c
   if (s->ar) TRY(iface_sum(s, s->d_q, 3, pq_part, kNPart));  // boundary rows of q + p.q slots, one collective
   if (deg > 1) {
     // alpha = rz(cur)/pq; x += alpha p; r -= alpha q; r.r slots
-    launch_pcg_update_noz(s->stream, N, w, fused ? p_new : p_old, s->d_q, part(s, cur), pq_part, d_x, s->d_r, part(s, 3),
-                          s->d_scal + 3);
+    if (fuse_init) {
+      const size_t n = 3 * (size_t)N;
+      float* f = s->d_f32;  // d, z^, res^ start buffers of cheb_apply and (SDS)^-1
+      launch_pcg_update_init32(s->stream, N, fused ? p_new : p_old, s->d_q, part(s, cur), pq_part, d_x, s->d_r,
+                               part(s, 3), s->d_scal + 3, f + 6 * n, s->d_sc, s->d_coef, f, f + 2 * n, f + 4 * n);
+    } else {
+      launch_pcg_update_noz(s->stream, N, w, fused ? p_new : p_old, s->d_q, part(s, cur), pq_part, d_x, s->d_r,
+                            part(s, 3), s->d_scal + 3);
+    }
     if (s->ar) TRY(parts_sum(s, part(s, 3)));
   } else {
     // ... and z = Dinv r with the new r.z slots into part(1-cur)

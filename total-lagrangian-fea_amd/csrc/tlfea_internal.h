@@ -125,6 +125,10 @@ void launch_cheb_lp(hipStream_t s, int N, int nnz_coef, const Incidence& inc, co
                     const double* Dinv_s, const double* sc, const double* d_old, const double* coef, double* d_new,
                     const double* z, double* z_new, const double* res, double* res_new, const double* r,
                     const double* w, double* out, int mode);
+void launch_pcg_update_init32(hipStream_t s, int N, const double* p, const double* q, const double* rz_part_old,
+                              const double* pq_part, double* x, double* r, double* rr_part, double* indefinite,
+                              const float* Dinv_f, const double* sc, const double* coef, float* d, float* z,
+                              float* res);
 void launch_pcg_update_noz(hipStream_t s, int N, const double* w, const double* p, const double* q,
                            const double* rz_part_old, const double* pq_part, double* x, double* r, double* rr_part,
                            double* indefinite);
