@@ -221,6 +221,30 @@ int tlfea_newton_set_interface(tlfea_newton_t s, const int *iface_nodes, const i
  * polynomial step.  Call after tlfea_newton_set_interface. */
 int tlfea_newton_set_interface_owners(tlfea_newton_t s, const int *owned);
 
+/* ---- SyncedAdamWNocoopSolver (SyncedAdamWNocoop.cuh:22-198, SyncedAdamWNocoop.cu:262-500) ------------------------
+ * First-order ALM solver on the same velocity unknowns: per inner iteration one AdamW moment update, x = x_prev + dt v,
+ * compute_p + internal force + constraints + grad L (the Newton solver's own residual path).  Single GPU. */
+typedef struct tlfea_adamw_s *tlfea_adamw_t;
+typedef struct { /* SyncedAdamWParams, field order of SyncedAdamW.cuh:27-34 */
+  double lr, beta1, beta2, eps, weight_decay, lr_decay;
+  double inner_tol, outer_tol, rho;
+  int max_outer, max_inner;
+  double time_step;
+  int convergence_check_interval;
+  double inner_rtol;
+} tlfea_adamw_params;
+int tlfea_adamw_create(tlfea_t10_t data, int n_constraints, tlfea_adamw_t *out); /* ctor SyncedAdamWNocoop.cuh:24-104 */
+int tlfea_adamw_destroy(tlfea_adamw_t a);
+int tlfea_adamw_setup(tlfea_adamw_t a);                                           /* Setup :180-198 */
+int tlfea_adamw_set_parameters(tlfea_adamw_t a, const tlfea_adamw_params *p);     /* SetParameters :147-178 (also zeroes v, v_prev, lambda) */
+int tlfea_adamw_solve(tlfea_adamw_t a);                                           /* Solve()/OneStepAdamWNocoop SyncedAdamWNocoop.cu:262-500 */
+double *tlfea_adamw_velocity_guess_device_ptr(tlfea_adamw_t a);
+int tlfea_adamw_retrieve_velocity(tlfea_adamw_t a, double *v);
+int tlfea_adamw_retrieve_lambda(tlfea_adamw_t a, double *lam);
+/* out6: outer iterations, inner iterations (total), last ||g||, last ||c||, inner-converged flag, device ms */
+int tlfea_adamw_get_stats(tlfea_adamw_t a, double *out6);
+int tlfea_adamw_set_verbose(tlfea_adamw_t a, int v);
+
 #ifdef __cplusplus
 }
 #endif

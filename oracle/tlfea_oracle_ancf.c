@@ -591,3 +591,86 @@ int orc_gen_newton_step(int S, int Q, int E, int N, const int *conn, double *x, 
   free(ro); free(ci); free(H); free(xp); free(P); free(f_int); free(g); free(r); free(dv); free(c);
   return status;
 }
+
+
+/* ---- SyncedAdamWNocoopSolver::OneStepAdamWNocoop (SyncedAdamWNocoop.cu:262-500) for any element type ---------
+ * First-order ALM loop on the velocities with fixed-coefficient constraints.  Follows the reference line by line:
+ * m, v moments and g are zeroed every OUTER iteration (:344-346); lr = lr0 lr_decay^(inner+1), t = inner+2 (:358-361);
+ * the velocity update reads the gradient of the PREVIOUS inner iteration (zero in the first, :363-364, :140-174);
+ * convergence is tested every check interval with tol_abs = inner_tol (1 + ||v||) or inner_rtol ||g0|| (:387-424);
+ * after the inner loop v_prev = v (:438) and lambda += rho dt c TWICE (adamw_dual_update_kernel, :260-264); the outer
+ * loop stops when ||c|| < outer_tol AND the inner loop converged (:460-472); without constraints one outer pass.
+ * State in/out: x,y,z, v, v_prev, lam.  stats: outer iterations, inner iterations (total), last ||g||, last ||c||,
+ * last inner flag. */
+typedef struct {
+  double lr, beta1, beta2, eps, weight_decay, lr_decay;
+  double inner_tol, outer_tol, rho;
+  int max_outer, max_inner;
+  double time_step;
+  int convergence_check_interval;
+  double inner_rtol;
+} orc_adamw_params;
+
+int orc_gen_adamw_step(int S, int Q, int E, int N, const int *conn, double *x, double *y, double *z,
+                       const double *xt, const double *yt, const double *zt, const double *gradN,
+                       const double *detJ, const double *qw, const orc_material *mat, const int *mo, const int *mc,
+                       const double *mv, const int *fixed, int n_fixed, const double *f_ext,
+                       const orc_adamw_params *prm, double *v, double *v_prev, double *lam, double *stats) {
+  const int n = 3 * N, nc = 3 * n_fixed;
+  const double dt = prm->time_step, rho = prm->rho;
+  const int check_every = prm->convergence_check_interval > 0 ? prm->convergence_check_interval : 1;
+  const int max_outer = nc > 0 ? prm->max_outer : 1;
+  double *xp = (double *)malloc(sizeof(double) * n), *P = (double *)malloc(sizeof(double) * 9 * (size_t)E * Q);
+  double *f_int = (double *)malloc(sizeof(double) * n), *g = (double *)malloc(sizeof(double) * n);
+  double *m = (double *)malloc(sizeof(double) * n), *va = (double *)malloc(sizeof(double) * n);
+  double *c = (double *)calloc(nc > 0 ? nc : 1, sizeof(double));
+  memcpy(xp, x, sizeof(double) * N); memcpy(xp + N, y, sizeof(double) * N); memcpy(xp + 2 * N, z, sizeof(double) * N);
+  int outer_flag = 0, inner_flag = 0, n_outer = 0, n_inner = 0;
+  double ng = 0.0, ncn = 0.0;
+  for (int outer = 0; outer < max_outer; outer++) {
+    if (outer_flag) break;
+    n_outer++;
+    memset(g, 0, sizeof(double) * n); memset(m, 0, sizeof(double) * n); memset(va, 0, sizeof(double) * n);
+    inner_flag = 0;
+    double ng0 = -1.0;
+    for (int inner = 0; inner < prm->max_inner; inner++) {
+      if (inner_flag) break;
+      n_inner++;
+      const double lr = prm->lr * pow(prm->lr_decay, inner + 1), t = (double)(inner + 2);
+      const double inv1 = 1.0 / (1.0 - pow(prm->beta1, t)), inv2 = 1.0 / (1.0 - pow(prm->beta2, t));
+      for (int i = 0; i < n; i++) {
+        const double mt = prm->beta1 * m[i] + (1.0 - prm->beta1) * g[i];
+        const double vt = prm->beta2 * va[i] + (1.0 - prm->beta2) * g[i] * g[i];
+        m[i] = mt; va[i] = vt;
+        v[i] = v[i] - lr * ((mt * inv1) / (sqrt(vt * inv2) + prm->eps) + prm->weight_decay * v[i]);
+      }
+      for (int i = 0; i < N; i++) { x[i] = xp[i] + dt * v[3 * i]; y[i] = xp[N + i] + dt * v[3 * i + 1]; z[i] = xp[2 * N + i] + dt * v[3 * i + 2]; }
+      orc_gen_compute_p(S, Q, E, conn, x, y, z, v, gradN, mat, NULL, P);
+      orc_gen_internal_force(S, Q, E, N, conn, P, gradN, detJ, qw, f_int);
+      for (int k = 0; k < n_fixed; k++) { c[3 * k] = x[fixed[k]] - xt[fixed[k]]; c[3 * k + 1] = y[fixed[k]] - yt[fixed[k]]; c[3 * k + 2] = z[fixed[k]] - zt[fixed[k]]; }
+      orc_grad_L(N, mo, mc, mv, v, v_prev, f_int, f_ext, fixed, n_fixed, c, lam, dt, rho, g);
+      if (inner % check_every == 0) {
+        double nv = 0.0;
+        ng = 0.0;
+        for (int i = 0; i < n; i++) { ng += g[i] * g[i]; nv += v[i] * v[i]; }
+        ng = sqrt(ng); nv = sqrt(nv);
+        if (ng0 < 0.0) ng0 = ng;
+        const double tol_abs = prm->inner_tol * (1.0 + nv);
+        const double tol_rel = (prm->inner_rtol > 0.0 && ng0 > 0.0) ? prm->inner_rtol * ng0 : 0.0;
+        if (ng <= tol_abs || (tol_rel > 0.0 && ng <= tol_rel)) inner_flag = 1;
+      }
+    }
+    memcpy(v_prev, v, sizeof(double) * n);
+    for (int i = 0; i < N; i++) { x[i] = xp[i] + dt * v[3 * i]; y[i] = xp[N + i] + dt * v[3 * i + 1]; z[i] = xp[2 * N + i] + dt * v[3 * i + 2]; }
+    if (nc > 0) {
+      for (int k = 0; k < n_fixed; k++) { c[3 * k] = x[fixed[k]] - xt[fixed[k]]; c[3 * k + 1] = y[fixed[k]] - yt[fixed[k]]; c[3 * k + 2] = z[fixed[k]] - zt[fixed[k]]; }
+      for (int k = 0; k < nc; k++) { lam[k] += rho * dt * c[k]; lam[k] += rho * dt * c[k]; }
+      ncn = 0.0; for (int k = 0; k < nc; k++) ncn += c[k] * c[k]; ncn = sqrt(ncn);
+      if (ncn < prm->outer_tol && inner_flag) outer_flag = 1;
+    }
+  }
+  for (int i = 0; i < N; i++) { x[i] = xp[i] + dt * v[3 * i]; y[i] = xp[N + i] + dt * v[3 * i + 1]; z[i] = xp[2 * N + i] + dt * v[3 * i + 2]; }
+  if (stats) { stats[0] = n_outer; stats[1] = n_inner; stats[2] = ng; stats[3] = ncn; stats[4] = inner_flag; }
+  free(xp); free(P); free(f_int); free(g); free(m); free(va); free(c);
+  return 0;
+}

@@ -99,3 +99,21 @@ def test_cpp_ancf3243_net_driver(joint):
         ref = o.z[centre]
         assert abs(rows[step, 1] - ref) <= 1e-10 * np.max(np.abs(o.z - m.z12)) + 8e-16 * max(1.0, abs(ref))
         assert rows[step, 2] < 1e-6
+
+
+@pytest.mark.gpu
+def test_cpp_ancf3243_driver_adamw(tmp_path):
+    """`--solver=adamw` of the beam_sag driver (test_ancf3243.cc:373-389: zero damping, SyncedAdamWNocoopParams
+    {2e-4,.9,.999,1e-8,1e-4,.998,1e-1,1e-6,1e14,5,500,dt,10,0}) through the C++ facade: runs, writes the CSV schema and
+    the tip starts to move down-force-wise (tight parity of this solver is in tests/test_gpu_ancf.py)."""
+    drv = os.path.join(os.path.dirname(DRIVER), "test_ancf3243")
+    subprocess.check_call(["make", "-C", os.path.dirname(DRIVER)])
+    csv = tmp_path / "tip.csv"
+    out = subprocess.run([drv, "--solver=adamw", "--steps=2", "--n_elements=6", f"--csv_path={csv}"],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    assert open(csv).readline().strip() == "step,tip_z"
+    rows = np.loadtxt(csv, delimiter=",", skiprows=1)
+    assert rows.shape == (2, 2) and rows[1, 1] > rows[0, 1] > 0.0      # tip force is +z (3100 N)
+    bad = subprocess.run([drv, "--solver=vbd"], capture_output=True, text=True)
+    assert bad.returncode == 1 and "Invalid --solver" in bad.stderr

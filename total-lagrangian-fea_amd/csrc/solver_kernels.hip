@@ -1240,6 +1240,43 @@ void launch_dual_update(hipStream_t s, int nc, const double* cons, double rho, d
 
 // ---- partition-interface pack/unpack (multi-GPU exchange buffers) --------------------------------
 // buf[dim*slot + c] <-> field[dim*node + c]; slots index the GLOBAL interface list, identical on all ranks
+// ---- SyncedAdamWNocoop (SyncedAdamWNocoop.cu:140-189) --------------------------------------------------------
+// m, v moments and the velocity update of one inner iteration; lr, 1/(1-beta1^t), 1/(1-beta2^t) from the host loop
+__global__ void adamw_update_velocity_kernel(int n, const double* __restrict__ g, double beta1, double beta2,
+                                             double eps, double weight_decay, double lr, double inv_1mb1t,
+                                             double inv_1mb2t, double* __restrict__ m, double* __restrict__ va,
+                                             double* __restrict__ v) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double gi = g[i], vi = v[i];
+  const double mt = beta1 * m[i] + (1.0 - beta1) * gi;
+  const double vt = beta2 * va[i] + (1.0 - beta2) * gi * gi;
+  const double m_hat = mt * inv_1mb1t, v_hat = vt * inv_1mb2t;
+  m[i] = mt;
+  va[i] = vt;
+  v[i] = vi - lr * (m_hat / (sqrt(v_hat) + eps) + weight_decay * vi);
+}
+void launch_adamw_update_velocity(hipStream_t s, int n, const double* g, double beta1, double beta2, double eps,
+                                  double weight_decay, double lr, double inv_1mb1t, double inv_1mb2t, double* m,
+                                  double* va, double* v) {
+  hipLaunchKernelGGL(adamw_update_velocity_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, g, beta1, beta2, eps,
+                     weight_decay, lr, inv_1mb1t, inv_1mb2t, m, va, v);
+}
+// x = x_prev + dt v   (adamw_update_positions_from_prev_kernel)
+__global__ void positions_from_prev_kernel(int N, const double* __restrict__ v, const double* __restrict__ xp,
+                                           const double* __restrict__ yp, const double* __restrict__ zp, double dt,
+                                           double* __restrict__ x, double* __restrict__ y, double* __restrict__ z) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  x[i] = xp[i] + dt * v[3 * i];
+  y[i] = yp[i] + dt * v[3 * i + 1];
+  z[i] = zp[i] + dt * v[3 * i + 2];
+}
+void launch_positions_from_prev(hipStream_t s, int N, const double* v, const double* xp, const double* yp,
+                                const double* zp, double dt, double* x, double* y, double* z) {
+  hipLaunchKernelGGL(positions_from_prev_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, v, xp, yp, zp, dt, x, y, z);
+}
+
 __global__ void pack_kernel(int n, int dim, const int* __restrict__ node, const int* __restrict__ slot,
                             const double* __restrict__ src, double* __restrict__ buf) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;

@@ -1224,7 +1224,7 @@ static int eval_gradient(tlfea_newton_t s, double* norm_g) {
     // each rank's g holds only its own elements' forces and its share of M, f_ext, constraints on
     // partition-boundary nodes: sum the boundary entries over ranks (nothing else is exchanged)
     TRY(iface_sum(s, s->d_g, 3));
-    TRY(device_norm(s, s->d_g, s->d_w, 3 * s->N, norm_g));
+    if (norm_g) TRY(device_norm(s, s->d_g, s->d_w, 3 * s->N, norm_g));  // first-order solvers test only now and then
     t.stop();
   }
   return 0;
@@ -1832,5 +1832,146 @@ extern "C" int tlfea_newton_get_stage_ms(tlfea_newton_t s, double* ms, double* c
 extern "C" int tlfea_newton_begin_step(tlfea_newton_t s) {
   TRY(begin_step(s));
   HIP_TRY(hipMemcpyAsync(s->d_vprev, s->d_v, 3 * (size_t)s->N * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
+  return 0;
+}
+
+
+// =================================================================================================
+// SyncedAdamWNocoopSolver (SyncedAdamWNocoop.cuh:22-198, SyncedAdamWNocoop.cu:262-500): first-order ALM solver on the
+// same velocity unknowns.  It needs the residual / gradient path only (compute_p + internal force + constraints +
+// grad L: the same functions the Newton solver calls), so it is a thin loop around the Newton core's gradient
+// evaluation plus the AdamW moment update; no Hessian is built or allocated.
+struct tlfea_adamw_s {
+  tlfea_newton_t core = nullptr;
+  tlfea_adamw_params prm{2e-4, 0.9, 0.999, 1e-8, 1e-4, 0.998, 1e-1, 1e-6, 1e14, 5, 500, 1e-3, 10, 0.0};
+  double *d_m = nullptr, *d_va = nullptr;
+  double stats[6] = {0, 0, 0, 0, 0, 0};  // outer iterations, inner iterations (total), ||g||, ||c||, inner flag, ms
+  int verbose = 0;
+};
+
+extern "C" int tlfea_adamw_create(tlfea_t10_t data, int n_constraints, tlfea_adamw_t* out) {
+  if (!data || !out) return fail("tlfea_adamw_create: null argument");
+  auto* a = new tlfea_adamw_s();
+  TRY(tlfea_newton_create(data, n_constraints, &a->core));
+  const size_t n = 3 * (size_t)a->core->N;
+  TRY(dmalloc(&a->d_m, n));
+  TRY(dmalloc(&a->d_va, n));
+  HIP_TRY(hipMemset(a->d_m, 0, n * sizeof(double)));
+  HIP_TRY(hipMemset(a->d_va, 0, n * sizeof(double)));
+  *out = a;
+  return 0;
+}
+extern "C" int tlfea_adamw_destroy(tlfea_adamw_t a) {
+  if (!a) return 0;
+  if (a->d_m) (void)hipFree(a->d_m);
+  if (a->d_va) (void)hipFree(a->d_va);
+  (void)tlfea_newton_destroy(a->core);
+  delete a;
+  return 0;
+}
+extern "C" int tlfea_adamw_setup(tlfea_adamw_t a) {  // Setup(): zero state (SyncedAdamWNocoop.cuh:180-198)
+  const size_t n = 3 * (size_t)a->core->N;
+  TRY(tlfea_newton_setup(a->core));
+  HIP_TRY(hipMemset(a->d_m, 0, n * sizeof(double)));
+  HIP_TRY(hipMemset(a->d_va, 0, n * sizeof(double)));
+  return 0;
+}
+extern "C" int tlfea_adamw_set_parameters(tlfea_adamw_t a, const tlfea_adamw_params* p) {
+  if (!a || !p) return fail("null argument");
+  a->prm = *p;
+  // the reference's SetParameters also clears v_guess, v_prev and lambda (SyncedAdamWNocoop.cuh:175-177)
+  tlfea_newton_t s = a->core;
+  const size_t n = 3 * (size_t)s->N;
+  HIP_TRY(hipMemset(s->d_v, 0, n * sizeof(double)));
+  HIP_TRY(hipMemset(s->d_vprev, 0, n * sizeof(double)));
+  HIP_TRY(hipMemset(s->d_lam, 0, (size_t)std::max(1, s->n_constraints) * sizeof(double)));
+  return 0;
+}
+extern "C" int tlfea_adamw_set_verbose(tlfea_adamw_t a, int v) {
+  a->verbose = v;
+  return 0;
+}
+extern "C" double* tlfea_adamw_velocity_guess_device_ptr(tlfea_adamw_t a) { return a->core->d_v; }
+extern "C" int tlfea_adamw_retrieve_velocity(tlfea_adamw_t a, double* v) { return tlfea_newton_retrieve_velocity(a->core, v); }
+extern "C" int tlfea_adamw_retrieve_lambda(tlfea_adamw_t a, double* lam) { return tlfea_newton_retrieve_lambda(a->core, lam); }
+extern "C" int tlfea_adamw_get_stats(tlfea_adamw_t a, double* out6) {
+  std::copy(a->stats, a->stats + 6, out6);
+  return 0;
+}
+
+// OneStepAdamWNocoop (SyncedAdamWNocoop.cu:262-500)
+extern "C" int tlfea_adamw_solve(tlfea_adamw_t a) {
+  tlfea_newton_t s = a->core;
+  tlfea_t10_t d = s->d;
+  const tlfea_adamw_params& p = a->prm;
+  if (!d->is_csr_setup) return fail("SyncedAdamWNocoop: CalcMassMatrix() must precede Solve() (the gradient uses the mass CSR)");
+  if (s->ar) return fail("SyncedAdamWNocoop: single-GPU path only");
+  const int N = s->N, n = 3 * N;
+  const double dt = p.time_step;
+  // the core evaluates grad L with ITS parameters: time step and rho of this solver
+  s->prm.time_step = dt;
+  s->prm.rho = p.rho;
+  const int check_every = p.convergence_check_interval > 0 ? p.convergence_check_interval : 1;
+  const int max_outer = s->n_constraints > 0 ? p.max_outer : 1;
+  hipEvent_t e0 = s->ev[2], e1 = s->ev[3];
+  HIP_TRY(hipEventRecord(e0, s->stream));
+  TRY(begin_step(s));  // x_prev = x   (adamw_save_prev_pos_kernel)
+  int outer_flag = 0, n_outer = 0, n_inner_total = 0, inner_flag = 0;
+  double norm_g = 0.0, norm_c = 0.0;
+  for (int outer = 0; outer < max_outer; outer++) {
+    if (outer_flag) break;
+    n_outer++;
+    HIP_TRY(hipMemsetAsync(s->d_g, 0, (size_t)n * sizeof(double), s->stream));
+    HIP_TRY(hipMemsetAsync(a->d_m, 0, (size_t)n * sizeof(double), s->stream));
+    HIP_TRY(hipMemsetAsync(a->d_va, 0, (size_t)n * sizeof(double), s->stream));
+    inner_flag = 0;
+    double norm_g0 = -1.0;
+    for (int inner = 0; inner < p.max_inner; inner++) {
+      if (inner_flag) break;
+      n_inner_total++;
+      const double lr = p.lr * std::pow(p.lr_decay, inner + 1);
+      const double t = (double)(inner + 2);
+      const double inv1 = 1.0 / (1.0 - std::pow(p.beta1, t)), inv2 = 1.0 / (1.0 - std::pow(p.beta2, t));
+      launch_adamw_update_velocity(s->stream, n, s->d_g, p.beta1, p.beta2, p.eps, p.weight_decay, lr, inv1, inv2, a->d_m,
+                                   a->d_va, s->d_v);
+      launch_positions_from_prev(s->stream, N, s->d_v, s->d_xp, s->d_yp, s->d_zp, dt, d->d_x, d->d_y, d->d_z);
+      const bool check = (inner % check_every) == 0;
+      TRY(eval_gradient(s, check ? &norm_g : nullptr));  // compute_p, f_int, constraints, grad L
+      if (check) {
+        double norm_v = 0.0;
+        TRY(device_norm(s, s->d_v, nullptr, n, &norm_v));
+        if (norm_g0 < 0.0) norm_g0 = norm_g;
+        const double tol_abs = p.inner_tol * (1.0 + norm_v);
+        const double tol_rel = (p.inner_rtol > 0.0 && norm_g0 > 0.0) ? p.inner_rtol * norm_g0 : 0.0;
+        if (a->verbose)
+          std::printf("outer iter: %d, inner iter: %d  lr: %.6e norm_g: %.17g norm_v: %.17g\n", outer, inner, lr, norm_g,
+                      norm_v);
+        if (norm_g <= tol_abs || (tol_rel > 0.0 && norm_g <= tol_rel)) inner_flag = 1;
+      }
+    }
+    HIP_TRY(hipMemcpyAsync(s->d_vprev, s->d_v, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
+    launch_positions_from_prev(s->stream, N, s->d_v, s->d_xp, s->d_yp, s->d_zp, dt, d->d_x, d->d_y, d->d_z);
+    if (s->n_constraints > 0) {
+      if (d->cons_mode == 2)
+        launch_lin_constraint(s->stream, d->n_constraint, d->d_joff, d->d_jcol, d->d_jval, d->d_rhs, d->d_x, d->d_y,
+                              d->d_z, d->d_cons);
+      else
+        launch_constraint(s->stream, d->n_fixed, d->d_fixed, d->d_x, d->d_y, d->d_z, d->d_xt, d->d_yt, d->d_zt, d->d_cons);
+      // adamw_dual_update_kernel adds rho*dt*c TWICE (SyncedAdamWNocoop.cu:260-264): reproduced as written
+      launch_dual_update(s->stream, s->n_constraints, d->d_cons, p.rho * dt, s->d_lam);
+      launch_dual_update(s->stream, s->n_constraints, d->d_cons, p.rho * dt, s->d_lam);
+      TRY(device_norm(s, d->d_cons, nullptr, s->n_constraints, &norm_c));
+      if (a->verbose) std::printf("norm_constraint: %.17g\n", norm_c);
+      if (norm_c < p.outer_tol && inner_flag) outer_flag = 1;
+    }
+  }
+  launch_positions_from_prev(s->stream, N, s->d_v, s->d_xp, s->d_yp, s->d_zp, dt, d->d_x, d->d_y, d->d_z);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(e1, s->stream));
+  HIP_TRY(hipEventSynchronize(e1));
+  float ms = 0.f;
+  HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+  a->stats[0] = n_outer; a->stats[1] = n_inner_total; a->stats[2] = norm_g; a->stats[3] = norm_c;
+  a->stats[4] = inner_flag; a->stats[5] = ms;
   return 0;
 }

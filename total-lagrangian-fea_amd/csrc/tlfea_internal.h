@@ -138,6 +138,11 @@ void launch_scale_inv_sqrt(hipStream_t s, int n, const double* sumsq, double* v)
 void launch_newton_update(hipStream_t s, int N, const double* dv, double* v, const double* xp, const double* yp,
                           const double* zp, double h, double* x, double* y, double* z);
 void launch_axpy_neg(hipStream_t s, int n, const double* g, double* r);
+void launch_adamw_update_velocity(hipStream_t s, int n, const double* g, double beta1, double beta2, double eps,
+                                  double weight_decay, double lr, double inv_1mb1t, double inv_1mb2t, double* m,
+                                  double* va, double* v);
+void launch_positions_from_prev(hipStream_t s, int N, const double* v, const double* xp, const double* yp,
+                                const double* zp, double dt, double* x, double* y, double* z);
 void launch_dual_update(hipStream_t s, int nc, const double* cons, double rho, double* lam);
 void launch_pack(hipStream_t s, int n, int dim, const int* node, const int* slot, const double* src, double* buf);
 void launch_unpack(hipStream_t s, int n, int dim, const int* node, const int* slot, const double* buf, double* dst);

@@ -4,6 +4,7 @@
 //   ./test_ancf3243 --steps=50 --dt=1e-3 [--n_elements=30] [--tip_force_z=3100] [--csv_path=out.csv]
 #include <iomanip>
 #include <limits>
+#include <memory>
 
 #include "tlfea_facade.h"
 
@@ -16,7 +17,7 @@ bool StartsWith(const std::string& s, const std::string& p) { return s.rfind(p, 
 int main(int argc, char** argv) {
   int steps = 50, n_elements = 30;
   double dt = 1e-3, tip_fz = kTipFz;
-  std::string csv_path;
+  std::string csv_path, solver_kind = "newton";
   for (int i = 1; i < argc; i++) {
     const std::string a = argv[i];
     if (StartsWith(a, "--steps=")) steps = std::atoi(a.c_str() + 8);
@@ -25,7 +26,13 @@ int main(int argc, char** argv) {
     else if (StartsWith(a, "--tip_force_z=")) tip_fz = std::atof(a.c_str() + 14);
     else if (StartsWith(a, "--csv_path=")) csv_path = a.substr(11);
     else if (a == "--csv") csv_path = "tip_z_history_ancf3243_newton.csv";
-    else if (StartsWith(a, "--solver=")) { if (a.substr(9) != "newton") { std::cerr << "only --solver=newton is built\n"; return 1; } }
+    else if (StartsWith(a, "--solver=")) {
+      solver_kind = a.substr(9);
+      if (solver_kind != "newton" && solver_kind != "adamw") {
+        std::cerr << "Invalid --solver (built: newton | adamw): " << solver_kind << std::endl;
+        return 1;
+      }
+    }
     else { std::cerr << "Unknown argument: " << a << std::endl; return 1; }
   }
   if (tlfea_device_count() <= 0) {
@@ -52,7 +59,8 @@ int main(int argc, char** argv) {
              Quadrature::gauss_zeta_2, Quadrature::weight_xi_m_6, Quadrature::weight_xi_3, Quadrature::weight_eta_2,
              Quadrature::weight_zeta_2, h_x12, h_y12, h_z12, conn);
   data.SetDensity(kRho0);
-  data.SetDamping(1e5, 1e5);  // Newton branch (:287-291)
+  if (solver_kind == "newton") data.SetDamping(1e5, 1e5);  // test_ancf3243.cc:286-291
+  else data.SetDamping(0.0, 0.0);
   data.SetSVK(kE, kNu);
   data.CalcDsDuPre();
   data.CalcMassMatrix();
@@ -63,9 +71,20 @@ int main(int argc, char** argv) {
   data.CalcInternalForce();
 
   SyncedNewtonParams params = {1e-4, 0.0, 1e-6, 1e14, 5, 10, dt};  // :329
-  SyncedNewtonSolver solver(&data, data.get_n_constraint());
-  solver.Setup();
-  solver.SetParameters(&params);
+  SyncedAdamWNocoopParams aparams = {2e-4, 0.9, 0.999, 1e-8, 1e-4, 0.998, 1e-1, 1e-6, 1e14, 5, 500, dt, 10, 0.0};  // :374-376
+  std::unique_ptr<SolverBase> solver_ptr;
+  if (solver_kind == "newton") {
+    auto* sv = new SyncedNewtonSolver(&data, data.get_n_constraint());
+    sv->Setup();
+    sv->SetParameters(&params);
+    solver_ptr.reset(sv);
+  } else {
+    auto* sv = new SyncedAdamWNocoopSolver(&data, data.get_n_constraint());
+    sv->Setup();
+    sv->SetParameters(&aparams);
+    solver_ptr.reset(sv);
+  }
+  SolverBase& solver = *solver_ptr;
   std::vector<double> tip_z;
   for (int step = 0; step < steps; ++step) {
     solver.Solve();

@@ -842,3 +842,36 @@ class SyncedNewtonSolver : public SolverBase {
  private:
   tlfea_newton_t s_ = nullptr;
 };
+
+// SyncedAdamWNocoopSolver (SyncedAdamWNocoop.cuh:20-198); SyncedAdamWParams field order of SyncedAdamW.cuh:27-34
+struct SyncedAdamWParams {
+  double lr, beta1, beta2, eps, weight_decay, lr_decay;
+  double inner_tol, outer_tol, rho;
+  int max_outer, max_inner;
+  double time_step;
+  int convergence_check_interval;
+  double inner_rtol;
+};
+using SyncedAdamWNocoopParams = SyncedAdamWParams;
+
+class SyncedAdamWNocoopSolver : public SolverBase {
+ public:
+  SyncedAdamWNocoopSolver(ElementBase* data, int n_constraints) {
+    TLFEA_HANDLE_ERROR(tlfea_adamw_create(static_cast<GPU_FEAT10_Data*>(data)->h, n_constraints, &a_));
+  }
+  ~SyncedAdamWNocoopSolver() override { tlfea_adamw_destroy(a_); }
+  void Setup() { TLFEA_HANDLE_ERROR(tlfea_adamw_setup(a_)); }
+  void SetParameters(void* params) override {
+    const SyncedAdamWNocoopParams* p = static_cast<SyncedAdamWNocoopParams*>(params);
+    tlfea_adamw_params c{p->lr, p->beta1, p->beta2, p->eps, p->weight_decay, p->lr_decay, p->inner_tol, p->outer_tol,
+                         p->rho, p->max_outer, p->max_inner, p->time_step, p->convergence_check_interval, p->inner_rtol};
+    TLFEA_HANDLE_ERROR(tlfea_adamw_set_parameters(a_, &c));
+  }
+  void OneStepAdamWNocoop() { TLFEA_HANDLE_ERROR(tlfea_adamw_solve(a_)); }
+  void Solve() override { OneStepAdamWNocoop(); }
+  double* GetVelocityGuessDevicePtr() const { return tlfea_adamw_velocity_guess_device_ptr(a_); }
+  void SetVerbose(int v) { tlfea_adamw_set_verbose(a_, v); }
+
+ private:
+  tlfea_adamw_t a_ = nullptr;
+};

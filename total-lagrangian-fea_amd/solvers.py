@@ -4,7 +4,7 @@ from dataclasses import dataclass
 
 import numpy as np
 
-from .binding import ALLREDUCE_FN, LinSolveOptsC, NewtonParams, check, dp, ip, load_library
+from .binding import ALLREDUCE_FN, AdamWParamsC, LinSolveOptsC, NewtonParams, check, dp, ip, load_library
 
 
 @dataclass
@@ -204,3 +204,77 @@ class SyncedNewtonSolver:
         own = np.ascontiguousarray(node_owned, dtype=np.int32)
         assert own.size == self.n_coef
         check(self._lib.tlfea_newton_set_interface_owners(self._h, ip(own)))
+
+
+@dataclass
+class SyncedAdamWNocoopParams:
+    """SyncedAdamWParams, field order of SyncedAdamW.cuh:27-34 (drivers: test_ancf3243.cc:374-376)."""
+    lr: float = 2e-4
+    beta1: float = 0.9
+    beta2: float = 0.999
+    eps: float = 1e-8
+    weight_decay: float = 1e-4
+    lr_decay: float = 0.998
+    inner_tol: float = 1e-1
+    outer_tol: float = 1e-6
+    rho: float = 1e14
+    max_outer: int = 5
+    max_inner: int = 500
+    time_step: float = 1e-3
+    convergence_check_interval: int = 10
+    inner_rtol: float = 0.0
+
+
+class SyncedAdamWNocoopSolver:
+    """SyncedAdamWNocoopSolver (SyncedAdamWNocoop.cuh:22-198): first-order ALM solver on the element kernels."""
+
+    def __init__(self, data, n_constraints):
+        self._lib = load_library()
+        self._data = data
+        self.n_coef = data.get_n_coef()
+        self.n_constraints = int(n_constraints)
+        self._h = C.c_void_p()
+        check(self._lib.tlfea_adamw_create(data._h, self.n_constraints, C.byref(self._h)))
+
+    def __del__(self):
+        try:
+            if self._h:
+                self._lib.tlfea_adamw_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def Setup(self):
+        check(self._lib.tlfea_adamw_setup(self._h))
+
+    def SetParameters(self, p):
+        c = AdamWParamsC(p.lr, p.beta1, p.beta2, p.eps, p.weight_decay, p.lr_decay, p.inner_tol, p.outer_tol, p.rho,
+                         p.max_outer, p.max_inner, p.time_step, p.convergence_check_interval, p.inner_rtol)
+        check(self._lib.tlfea_adamw_set_parameters(self._h, C.byref(c)))
+
+    def Solve(self):
+        check(self._lib.tlfea_adamw_solve(self._h))
+
+    OneStepAdamWNocoop = Solve
+
+    def SetVerbose(self, v):
+        check(self._lib.tlfea_adamw_set_verbose(self._h, int(v)))
+
+    def GetVelocityGuessDevicePtr(self):
+        self._lib.tlfea_adamw_velocity_guess_device_ptr.restype = C.c_void_p
+        return self._lib.tlfea_adamw_velocity_guess_device_ptr(self._h)
+
+    def RetrieveVelocityToCPU(self):
+        v = np.zeros(3 * self.n_coef)
+        check(self._lib.tlfea_adamw_retrieve_velocity(self._h, dp(v)))
+        return v
+
+    def RetrieveLambdaToCPU(self):
+        lam = np.zeros(self.n_constraints)
+        check(self._lib.tlfea_adamw_retrieve_lambda(self._h, dp(lam)))
+        return lam
+
+    def GetStats(self):
+        st = np.zeros(6)
+        check(self._lib.tlfea_adamw_get_stats(self._h, dp(st)))
+        return dict(outer=int(st[0]), inner=int(st[1]), norm_g=st[2], norm_c=st[3], inner_flag=int(st[4]), ms=st[5])
