@@ -61,6 +61,8 @@ def main():
                          "(clock ramp / first-touch events of a fresh process), then the state is reset")
     ap.add_argument("--local-precond", action="store_true",
                     help="multi-GPU: rank-local polynomial preconditioner (fewer collectives, 3-4x more CG iterations)")
+    ap.add_argument("--precond", type=int, default=0, choices=(0, 1, 2),
+                    help="0 auto, 1 Chebyshev polynomial, 2 two-level p-multigrid (T10, one GPU)")
     ap.add_argument("--cheb-kappa", type=float, default=0.0, help="polynomial interval [lmax/kappa, lmax] (0 = default)")
     ap.add_argument("--cheb-bits", type=int, default=0, choices=(0, 16, 32, 64),
                     help="matrix precision streamed by the Chebyshev steps (0 = auto = fp16 scaled copy)")
@@ -105,7 +107,7 @@ def main():
         part = par.slab_partition_structured(w["X"], lx * rank, lx * (rank + 1), rank, world)
         w["f_ext"] = (w["f_ext"].reshape(-1, 3) * part.node_weight[:, None]).reshape(-1)  # this rank's share
     d, s = wl.make_engine(tl, w)
-    s.SetLinSolveOpts(tl.LinSolveOpts(args.rel_tol, args.max_pcg, 25, args.cheb_deg, args.cheb_kappa, args.cheb_bits))
+    s.SetLinSolveOpts(tl.LinSolveOpts(args.rel_tol, args.max_pcg, 25, args.cheb_deg, args.cheb_kappa, args.cheb_bits, args.precond))
     if world > 1:
         par.attach(s, part, torch, dist, local_preconditioner=args.local_precond)
     d.UpdatePositions(w["x0"][:, 0], w["x0"][:, 1], w["x0"][:, 2])
@@ -172,8 +174,16 @@ def main():
     kt = s.TimeKernels(reps=40 if E < 200000 else 10)
     roof_all = {}
     n_outer = st["spmv"][1] // max(1, deg_eff)       # stage counter tallies deg launches per outer iteration
-    st = dict(st, spmv=(st["spmv"][0], n_outer), cheb_step=(0.0, n_outer * (deg_eff - 1)))
-    for k in ("residual", "tangent_blocks", "assemble_rows", "spmv", "cheb_step"):
+    pmg = s.GetPmgInfo()                              # (coarse nodes, coarse blocks, coarse polynomial degree) | None
+    if pmg:   # V-cycle: 4 fine-level steps (2-term smoother before and after) + kc-1 coarse-level steps per CG iteration
+        ab["cheb_step_coarse"] = pmg[1] * (9 * bits_eff // 8 + 4) + pmg[0] * (24 + 48 + 72 + 48 + 24) * vec_bits // 64
+        st = dict(st, spmv=(st["spmv"][0], n_outer), cheb_step=(0.0, n_outer * 4),
+                  cheb_step_coarse=(0.0, n_outer * (pmg[2] - 1)))
+    else:
+        st = dict(st, spmv=(st["spmv"][0], n_outer), cheb_step=(0.0, n_outer * (deg_eff - 1)))
+    for k in ("residual", "tangent_blocks", "assemble_rows", "spmv", "cheb_step", "cheb_step_coarse"):
+        if k not in st:
+            continue
         ms, n = st[k]
         if n == 0:
             continue
@@ -204,7 +214,9 @@ def main():
                    "elements_per_gpu": E, "nodes_per_gpu": N, "hessian_nnz": 9 * nnz_coef,
                    "pcg_outer_iters_per_step": round(float(np.mean(pcg_its)), 1),
                    "preconditioner": ("block-Jacobi (3x3)" if deg_eff <= 1 else
-                                      f"Chebyshev degree {deg_eff} of block-Jacobi, steps stream a "
+                                      (f"two-level p-multigrid V-cycle (T10 -> vertex mesh, {pmg[0]} coarse nodes, Galerkin "
+                                       f"coarse operator, 2-term Chebyshev smoothers, degree-{pmg[2]} coarse polynomial), "
+                                       if pmg else f"Chebyshev degree {deg_eff} of block-Jacobi, ") + "steps stream a "
                                       f"{'scaled fp%d copy of H' % bits_eff if bits_eff != 64 else 'fp64 H'} "
                                       f"with fp{vec_bits} work vectors; "
                                       "outer CG, residual and convergence test in fp64 on H")},

@@ -53,6 +53,9 @@ typedef struct {
                         scaled fp32 / fp16 block copy, and on one GPU the polynomial's recurrence then runs in fp32
                         (the outer CG, its residual and its convergence test stay fp64 on H);
                         0 (default) = auto = 16 */
+  int precond;       /* 0 (default) = auto, 1 = Chebyshev polynomial of block-Jacobi, 2 = two-level p-multigrid (T10 on one
+                        GPU: quadratic tets -> their vertex mesh, Galerkin coarse operator, polynomial smoothers and
+                        coarse solve; auto picks it wherever it exists) */
 } tlfea_linsolve_opts;
 
 const char *tlfea_last_error(void);
@@ -164,6 +167,14 @@ int tlfea_newton_set_linsolve_opts(tlfea_newton_t s, const tlfea_linsolve_opts *
 /* what the auto rules resolved to for this mesh: polynomial degree (1 = block-Jacobi), matrix bits of its steps and
  * the precision of its work vectors (32 on the single-GPU low-precision path, else 64) */
 int tlfea_newton_get_linsolve_info(tlfea_newton_t s, int *cheb_degree, int *cheb_bits, int *cheb_vector_bits);
+/* preconditioner a solve would use now: 0 block-Jacobi, 1 Chebyshev polynomial, 2 p-multigrid */
+int tlfea_newton_get_precond(tlfea_newton_t s);
+/* degree of the coarse-level polynomial of the p-multigrid cycle (grows with the coarse mesh); 0 without p-multigrid */
+int tlfea_newton_pmg_coarse_degree(tlfea_newton_t s);
+/* p-multigrid test hooks: coarse sizes; parent map [N] x 2, coarse block-CSR pattern and Hc = P^T H P of the current H
+ * (9 nnz values in the DOF-level layout of H: node row -> [d][k][e]) */
+int tlfea_newton_pmg_sizes(tlfea_newton_t s, int *n_coarse, int *nnz_coarse_blocks);
+int tlfea_newton_pmg_retrieve(tlfea_newton_t s, int *par0, int *par1, int *c_off, int *c_cols, double *Hc);
 int tlfea_newton_hessian_nnz(tlfea_newton_t s, int *nnz);
 /* H in the reference's DOF-level CSR (SyncedNewton.cu:163-205): rows 3N, sorted columns */
 int tlfea_newton_retrieve_hessian_csr(tlfea_newton_t s, int *row_offsets, int *col_indices, double *values);
@@ -174,10 +185,11 @@ int tlfea_newton_eval_gradient(tlfea_newton_t s, double *norm_g);
 int tlfea_newton_assemble_hessian(tlfea_newton_t s);
 /* Solve H x = b for host vectors (b,x length 3N) with the current H; iterations returned. */
 int tlfea_newton_linear_solve(tlfea_newton_t s, const double *b, double *x, int *iters, double *rel_res);
-/* mean duration (ms) of the 4 hot kernels over `reps` back-to-back launches each (hipEvent pair per kernel on the
- * launch stream): [0] residual, [1] tangent blocks, [2] row assembly, [3] CG SpMV, [4] Chebyshev step.  State of
- * the Newton iteration is unchanged (only linear-solver work vectors are touched). */
-int tlfea_newton_time_kernels(tlfea_newton_t s, int reps, double *out_ms5);
+/* mean duration (ms) of the hot kernels over `reps` back-to-back launches each (hipEvent pair per kernel on the
+ * launch stream): [0] residual, [1] tangent blocks, [2] row assembly, [3] CG SpMV (fp64), [4] fine-level polynomial /
+ * smoother step, [5] coarse-level polynomial step of the p-multigrid cycle (0 without it).  State of the Newton
+ * iteration is unchanged (only linear-solver work vectors are touched). */
+int tlfea_newton_time_kernels(tlfea_newton_t s, int reps, double *out_ms6);
 /* y = H x with the current H, host vectors of 3N (partition-boundary rows summed over ranks). */
 int tlfea_newton_apply_hessian(tlfea_newton_t s, const double *x, double *y);
 /* One full Newton iteration without the convergence test (gradient, assembly, solve, update):

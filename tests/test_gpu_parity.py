@@ -137,6 +137,31 @@ def test_hessian(mesh, mat):
     d.Destroy()
 
 
+@pytest.mark.parametrize("tag", ["beam_3x2x1", "res2", "res4"])
+def test_linear_solve_pmg_vs_chebyshev_vs_direct(tag):
+    """The same fp64 solution with the Chebyshev polynomial and with the two-level p-multigrid preconditioner."""
+    X, conn = load_mesh(tag)
+    fixed = fixed_x0(X)
+    o, d = make_oracle(X, conn, MATERIALS["svk"], fixed), make_gpu(X, conn, MATERIALS["svk"], fixed)
+    x, _ = perturbed_state(X, sigma=1e-4)
+    set_state(o, d, x)
+    s = tl.SyncedNewtonSolver(d, d.get_n_constraint())
+    s.SetParameters(tl.SyncedNewtonParams(1e-4, 1e-4, 1e-4, 1e14, 5, 10, 1e-3))
+    s.AssembleHessian()
+    ro, ci, val = o.assemble_hessian(1e-3, 1e14)
+    b = np.random.default_rng(3).normal(size=3 * X.shape[0])
+    x_ref = orc.solve_spd_upper(ro, ci, val, b)
+    its = {}
+    for pre in (1, 2):
+        s.SetLinSolveOpts(tl.LinSolveOpts(1e-13, 20000, 10, 0, 0.0, 0, pre))
+        assert s.GetPreconditioner() == pre
+        x_gpu, its[pre], rel = s.LinearSolve(b)
+        assert rel < 1e-12 and relerr(x_gpu, x_ref) < 1e-8, (pre, rel)
+    assert its[2] < 3 * its[1], its
+    del s
+    d.Destroy()
+
+
 @pytest.mark.parametrize("deg,bits", [(1, 0), (4, 64), (12, 64), (12, 32), (12, 16), (5, 16), (2, 16)])
 def test_linear_solve_preconditioner_degrees(deg, bits):
     """Plain block-Jacobi (deg 1) and Chebyshev polynomial preconditioners -- streaming H itself (64) or its scaled
@@ -148,7 +173,7 @@ def test_linear_solve_preconditioner_degrees(deg, bits):
     set_state(o, d, x)
     s = tl.SyncedNewtonSolver(d, d.get_n_constraint())
     s.SetParameters(tl.SyncedNewtonParams(1e-4, 1e-4, 1e-4, 1e14, 5, 10, 1e-3))
-    s.SetLinSolveOpts(tl.LinSolveOpts(1e-13, 20000, 10, deg, 400.0, bits))
+    s.SetLinSolveOpts(tl.LinSolveOpts(1e-13, 20000, 10, deg, 400.0, bits, 1))
     assert s.GetLinSolveInfo()[:2] == (deg, 64 if deg == 1 else bits)
     s.AssembleHessian()
     ro, ci, val = o.assemble_hessian(1e-3, 1e14)
@@ -156,6 +181,60 @@ def test_linear_solve_preconditioner_degrees(deg, bits):
     x_ref = orc.solve_spd_upper(ro, ci, val, b)
     x_gpu, iters, rel = s.LinearSolve(b)
     assert rel < 1e-12 and relerr(x_gpu, x_ref) < 1e-8
+    del s
+    d.Destroy()
+
+
+def test_pmg_galerkin_operator_matches_PtHP():
+    """Two-level p-multigrid set-up on a real TetGen mesh: every mid-edge node has its edge's two vertices as parents,
+    the coarse pattern is the vertex adjacency, and the device's gather-built Hc equals P^T H P of the retrieved H."""
+    import scipy.sparse as sp
+    X, conn = load_mesh("res2")
+    fixed = fixed_x0(X)
+    o, d = make_oracle(X, conn, MATERIALS["svk"], fixed), make_gpu(X, conn, MATERIALS["svk"], fixed)
+    x, _ = perturbed_state(X, sigma=1e-4)
+    set_state(o, d, x)
+    s = tl.SyncedNewtonSolver(d, d.get_n_constraint())
+    s.SetParameters(tl.SyncedNewtonParams(1e-4, 1e-4, 1e-4, 1e14, 5, 10, 1e-3))
+    s.AssembleHessian()
+    assert s.GetPreconditioner() == 2
+    par0, par1, c_off, c_cols, Hc = s.RetrievePmgLevel()
+    N = X.shape[0]
+    verts = np.unique(conn[:, :4])
+    assert np.array_equal(np.where(par0 == par1)[0], verts)
+    edges = [(0, 1), (1, 2), (0, 2), (0, 3), (1, 3), (2, 3)]
+    cid = -np.ones(N, dtype=np.int64)
+    cid[verts] = np.arange(len(verts))
+    for m, (a, b) in enumerate(edges):
+        mid = conn[:, 4 + m]
+        pa, pb = np.minimum(cid[conn[:, a]], cid[conn[:, b]]), np.maximum(cid[conn[:, a]], cid[conn[:, b]])
+        assert np.array_equal(par0[mid], pa) and np.array_equal(par1[mid], pb)
+    # P in DOF space and the reference triple product
+    rows = np.concatenate([np.arange(N), np.arange(N)])
+    cols = np.concatenate([par0, par1])
+    vals = np.where(np.concatenate([par0 == par1, par0 == par1]), 0.5, 0.5)   # a vertex gets 0.5 + 0.5 on the same entry
+    Pn = sp.csr_matrix((vals, (rows, cols)), shape=(N, len(verts)))
+    P = sp.kron(Pn, sp.identity(3), format="csr")
+    ro, ci, val = s.RetrieveHessianCSRToCPU()
+    H = sp.csr_matrix((val, ci, ro), shape=(3 * N, 3 * N))
+    ref = (P.T @ H @ P).tocsr()
+    ref.sort_indices()
+    # device Hc -> scipy: node row I, component d, column slot k, component e at 9 c_off[I] + d*3deg + 3k + e
+    nc = len(verts)
+    ro_c = np.zeros(3 * nc + 1, dtype=np.int64)
+    ci_c, va_c = [], []
+    for I in range(nc):
+        deg = c_off[I + 1] - c_off[I]
+        blk = Hc[9 * c_off[I]:9 * c_off[I + 1]].reshape(3, deg, 3)
+        cc = (3 * c_cols[c_off[I]:c_off[I + 1]][:, None] + np.arange(3)[None, :]).reshape(-1)
+        for dd in range(3):
+            ci_c.append(cc)
+            va_c.append(blk[dd].reshape(-1))
+            ro_c[3 * I + dd + 1] = ro_c[3 * I + dd] + 3 * deg
+    dev = sp.csr_matrix((np.concatenate(va_c), np.concatenate(ci_c), ro_c), shape=(3 * nc, 3 * nc))
+    assert np.all(np.diff(c_cols[c_off[0]:c_off[1]]) > 0)
+    assert abs(dev - ref).max() <= 1e-12 * abs(ref).max()
+    assert (abs(ref) > 0).nnz <= dev.nnz                      # the P1 pattern holds every Galerkin entry
     del s
     d.Destroy()
 

@@ -31,7 +31,7 @@ class AdamWParamsC(C.Structure):  # tlfea_adamw_params == SyncedAdamWParams (Syn
 
 class LinSolveOptsC(C.Structure):
     _fields_ = [("rel_tol", C.c_double), ("max_iter", C.c_int), ("check_every", C.c_int), ("cheb_degree", C.c_int),
-                ("cheb_kappa", C.c_double), ("cheb_bits", C.c_int)]
+                ("cheb_kappa", C.c_double), ("cheb_bits", C.c_int), ("precond", C.c_int)]
 
 
 def exported_symbols():

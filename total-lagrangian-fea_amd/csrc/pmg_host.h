@@ -1,0 +1,170 @@
+// Host-side set-up of the two-level p-multigrid preconditioner for T10 meshes (quadratic tets -> their linear
+// vertex mesh).  No reference counterpart: the reference hands the Newton system to cuDSS (SyncedNewton.cu:995-1114);
+// this is part of the device solve that replaces it ("Linear solve").
+//
+//   P  (fine N nodes <- coarse Nc vertex nodes):  vertex node <- itself;  mid-edge node <- 1/2 (a + b), its edge's ends
+//   Hc = P^T H P  (Galerkin: SPD whenever H is; pattern = vertices sharing an element, the P1 adjacency)
+//
+// Everything is integer bookkeeping built once per mesh in a fixed order (bitwise-reproducible products): per fine
+// node its (up to two) coarse parents, per coarse node its children (restriction), and per coarse 3x3 block the list
+// of fine blocks that contribute to it with weights 1, 1/2, 1/4 (triple product by gather, no atomics).
+#ifndef TLFEA_PMG_HOST_H_
+#define TLFEA_PMG_HOST_H_
+#include <algorithm>
+#include <cstdint>
+#include <vector>
+
+namespace tlfea {
+
+struct PmgHost {
+  int N = 0, Nc = 0, nnz_c = 0;
+  std::vector<int> par0, par1;               // [N] coarse ids of the parents (par1 == par0 for a vertex node)
+  std::vector<int> c_off, c_cols, c_diagpos; // coarse node adjacency (CSR, sorted columns) + diagonal positions
+  std::vector<int> cblk_row;                 // [nnz_c] coarse row of each coarse block
+  std::vector<int> child_off, child;         // [Nc+1], fine ids: the vertex itself first, then its mid-edge nodes
+  std::vector<float> child_w;                // 1 or 1/2
+  std::vector<int> con_off;                  // [nnz_c+1] contributions of fine blocks to each coarse block
+  std::vector<int> con_blk;                  // fine block index (off[i] + k), ascending within a coarse block
+  std::vector<float> con_w;                  // w_i * w_j
+  std::vector<int> blk_row;                  // [nnz_f] fine row of each fine block
+};
+
+// T10 local edges of the mid-edge nodes 4..9 (FEAT10Data.cu:143, cpu_utils.cc:609-619)
+static const int kT10Edge[6][2] = {{0, 1}, {1, 2}, {0, 2}, {0, 3}, {1, 3}, {2, 3}};
+
+// conn: column-major [10][E]; off/cols: fine node adjacency (sorted).  Returns false when the mesh is not a conforming
+// T10 mesh in the sense needed here (a node that is a vertex in one element and a mid-edge node in another, a mid-edge
+// node with two different parent pairs, or a fine block whose parents are not coarse neighbours).
+inline bool pmg_build(int N, int E, const int* conn, const int* off, const int* cols, PmgHost& o) {
+  o = PmgHost();
+  o.N = N;
+  std::vector<char> is_vertex(N, 0), is_mid(N, 0);
+  for (int e = 0; e < E; e++) {
+    for (int a = 0; a < 4; a++) is_vertex[conn[(size_t)a * E + e]] = 1;
+    for (int a = 4; a < 10; a++) is_mid[conn[(size_t)a * E + e]] = 1;
+  }
+  for (int n = 0; n < N; n++) {
+    if (is_vertex[n] && is_mid[n]) return false;
+    if (!is_vertex[n] && !is_mid[n]) is_vertex[n] = 1;  // a node no element uses: its own coarse node
+  }
+  std::vector<int> cid(N, -1);
+  int Nc = 0;
+  for (int n = 0; n < N; n++)
+    if (is_vertex[n]) cid[n] = Nc++;
+  o.Nc = Nc;
+  o.par0.assign(N, -1);
+  o.par1.assign(N, -1);
+  for (int n = 0; n < N; n++)
+    if (is_vertex[n]) o.par0[n] = o.par1[n] = cid[n];
+  for (int e = 0; e < E; e++)
+    for (int m = 0; m < 6; m++) {
+      const int n = conn[(size_t)(4 + m) * E + e];
+      int a = cid[conn[(size_t)kT10Edge[m][0] * E + e]], b = cid[conn[(size_t)kT10Edge[m][1] * E + e]];
+      if (a > b) std::swap(a, b);
+      if (a < 0 || a == b) return false;
+      if (o.par0[n] < 0) {
+        o.par0[n] = a;
+        o.par1[n] = b;
+      } else if (o.par0[n] != a || o.par1[n] != b) {
+        return false;
+      }
+    }
+  // coarse adjacency: vertices sharing an element
+  {
+    std::vector<std::vector<int>> rows((size_t)Nc);
+    for (int e = 0; e < E; e++) {
+      int v[4];
+      for (int a = 0; a < 4; a++) v[a] = cid[conn[(size_t)a * E + e]];
+      for (int a = 0; a < 4; a++)
+        for (int b = 0; b < 4; b++) rows[v[a]].push_back(v[b]);
+    }
+    o.c_off.assign((size_t)Nc + 1, 0);
+    for (int i = 0; i < Nc; i++) {
+      auto& r = rows[i];
+      r.push_back(i);
+      std::sort(r.begin(), r.end());
+      r.erase(std::unique(r.begin(), r.end()), r.end());
+      o.c_off[i + 1] = o.c_off[i] + (int)r.size();
+    }
+    o.nnz_c = o.c_off[Nc];
+    o.c_cols.resize((size_t)o.nnz_c);
+    o.c_diagpos.resize((size_t)Nc);
+    o.cblk_row.resize((size_t)o.nnz_c);
+    for (int i = 0; i < Nc; i++) {
+      std::copy(rows[i].begin(), rows[i].end(), o.c_cols.begin() + o.c_off[i]);
+      o.c_diagpos[i] = (int)(std::lower_bound(rows[i].begin(), rows[i].end(), i) - rows[i].begin());
+      for (int k = o.c_off[i]; k < o.c_off[i + 1]; k++) o.cblk_row[k] = i;
+    }
+  }
+  // children of every coarse node (restriction): itself first, then its mid-edge nodes in ascending fine id
+  {
+    o.child_off.assign((size_t)Nc + 1, 0);
+    for (int n = 0; n < N; n++) {
+      o.child_off[o.par0[n] + 1]++;
+      if (o.par1[n] != o.par0[n]) o.child_off[o.par1[n] + 1]++;
+    }
+    for (int i = 0; i < Nc; i++) o.child_off[i + 1] += o.child_off[i];
+    o.child.assign((size_t)o.child_off[Nc], 0);
+    o.child_w.assign((size_t)o.child_off[Nc], 0.f);
+    std::vector<int> cur(o.child_off.begin(), o.child_off.end() - 1);
+    for (int n = 0; n < N; n++)  // vertices first so that slot 0 of every row is the vertex itself
+      if (o.par1[n] == o.par0[n]) {
+        o.child[cur[o.par0[n]]] = n;
+        o.child_w[cur[o.par0[n]]++] = 1.f;
+      }
+    for (int n = 0; n < N; n++)
+      if (o.par1[n] != o.par0[n])
+        for (int p : {o.par0[n], o.par1[n]}) {
+          o.child[cur[p]] = n;
+          o.child_w[cur[p]++] = 0.5f;
+        }
+  }
+  // contributions of fine blocks (i, j) to coarse blocks (I, J), I in parents(i), J in parents(j)
+  const int nnz_f = off[N];
+  o.blk_row.resize((size_t)nnz_f);
+  std::vector<int> tgt((size_t)4 * nnz_f, -1);
+  int bad = 0;
+#pragma omp parallel for schedule(dynamic, 2048) reduction(+ : bad)
+  for (int i = 0; i < N; i++) {
+    const int pi[2] = {o.par0[i], o.par1[i]};
+    const int npi = pi[0] == pi[1] ? 1 : 2;
+    for (int g = off[i]; g < off[i + 1]; g++) {
+      o.blk_row[g] = i;
+      const int j = cols[g];
+      const int pj[2] = {o.par0[j], o.par1[j]};
+      const int npj = pj[0] == pj[1] ? 1 : 2;
+      for (int a = 0; a < npi; a++)
+        for (int b = 0; b < npj; b++) {
+          const int* r = o.c_cols.data() + o.c_off[pi[a]];
+          const int deg = o.c_off[pi[a] + 1] - o.c_off[pi[a]];
+          const int* p = std::lower_bound(r, r + deg, pj[b]);
+          if (p == r + deg || *p != pj[b]) bad++;
+          else tgt[(size_t)4 * g + 2 * a + b] = o.c_off[pi[a]] + (int)(p - r);
+        }
+    }
+  }
+  if (bad) return false;
+  o.con_off.assign((size_t)o.nnz_c + 1, 0);
+  for (size_t t = 0; t < tgt.size(); t++)
+    if (tgt[t] >= 0) o.con_off[(size_t)tgt[t] + 1]++;
+  for (int k = 0; k < o.nnz_c; k++) o.con_off[k + 1] += o.con_off[k];
+  o.con_blk.assign((size_t)o.con_off[o.nnz_c], 0);
+  o.con_w.assign((size_t)o.con_off[o.nnz_c], 0.f);
+  {
+    std::vector<int> cur(o.con_off.begin(), o.con_off.end() - 1);
+    for (int g = 0; g < nnz_f; g++) {  // ascending fine block index: fixed summation order
+      const int i = o.blk_row[g], j = cols[g];
+      const float wi = o.par0[i] == o.par1[i] ? 1.f : 0.5f, wj = o.par0[j] == o.par1[j] ? 1.f : 0.5f;
+      for (int t = 0; t < 4; t++) {
+        const int cb = tgt[(size_t)4 * g + t];
+        if (cb < 0) continue;
+        o.con_blk[cur[cb]] = g;
+        o.con_w[cur[cb]++] = wi * wj;
+      }
+    }
+  }
+  return true;
+}
+
+}  // namespace tlfea
+#endif

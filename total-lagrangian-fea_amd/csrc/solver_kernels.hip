@@ -1036,6 +1036,106 @@ void launch_cheb32(hipStream_t s, int N, int nnz_coef, const Incidence& inc, con
 #undef TLFEA_C32
 }
 
+// ---- two-level p-multigrid for T10 (pmg_host.h): Galerkin coarse operator and grid transfers ----------------
+// Hc = P^T H P by gather: one thread owns one coarse 3x3 block and adds its contributing fine blocks in ascending
+// fine-block order with weights 1, 1/2, 1/4 (no atomics: bitwise reproducible).  H and Hc in the reference's
+// DOF-level layout (node row -> [d][k][e]).
+__global__ __launch_bounds__(256) void pmg_galerkin_kernel(int nnz_c, const int* __restrict__ c_off,
+                                                          const int* __restrict__ cblk_row,
+                                                          const int* __restrict__ con_off,
+                                                          const int* __restrict__ con_blk,
+                                                          const float* __restrict__ con_w,
+                                                          const int* __restrict__ blk_row,
+                                                          const int* __restrict__ f_off,
+                                                          const double* __restrict__ Hf, double* __restrict__ Hc) {
+  const int cb = blockIdx.x * blockDim.x + threadIdx.x;
+  if (cb >= nnz_c) return;
+  double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int t = con_off[cb]; t < con_off[cb + 1]; t++) {
+    const int g = con_blk[t], i = blk_row[g];
+    const int o = f_off[i], deg = f_off[i + 1] - o, k = g - o;
+    const double w = (double)con_w[t];
+    const double* Hi = Hf + (size_t)9 * o + 3 * k;
+#pragma unroll
+    for (int d = 0; d < 3; d++)
+#pragma unroll
+      for (int e = 0; e < 3; e++) acc[3 * d + e] += w * Hi[(size_t)d * 3 * deg + e];
+  }
+  const int I = cblk_row[cb], oc = c_off[I], degc = c_off[I + 1] - oc, pc = cb - oc;
+  double* out = Hc + (size_t)9 * oc + 3 * pc;
+#pragma unroll
+  for (int d = 0; d < 3; d++)
+#pragma unroll
+    for (int e = 0; e < 3; e++) out[(size_t)d * 3 * degc + e] = acc[3 * d + e];
+}
+void launch_pmg_galerkin(hipStream_t s, int nnz_c, const int* c_off, const int* cblk_row, const int* con_off,
+                         const int* con_blk, const float* con_w, const int* blk_row, const int* f_off, const double* Hf,
+                         double* Hc) {
+  hipLaunchKernelGGL(pmg_galerkin_kernel, dim3((nnz_c + 255) / 256), dim3(256), 0, s, nnz_c, c_off, cblk_row, con_off,
+                     con_blk, con_w, blk_row, f_off, Hf, Hc);
+}
+
+// Restriction fused with the coarse polynomial's start vectors.  The fine residual lives in the fine scaled space
+// (res^ = S_f res), the coarse system in its own:  r^_c = S_c P^T S_f^-1 res^ ;  d = (S_c D_c S_c)^-1 r^_c / theta_c
+__global__ __launch_bounds__(256) void pmg_restrict_init_kernel(
+    int Nc, const int* __restrict__ child_off, const int* __restrict__ child, const float* __restrict__ child_w,
+    const float* __restrict__ res_f, const double* __restrict__ sc_f, const double* __restrict__ sc_c,
+    const float* __restrict__ Dinv_c, const double* __restrict__ coef_c, float* __restrict__ d_c,
+    float* __restrict__ z_c, float* __restrict__ res_c) {
+  const int I = blockIdx.x * blockDim.x + threadIdx.x;
+  if (I >= Nc) return;
+  double r[3] = {0.0, 0.0, 0.0};
+  for (int t = child_off[I]; t < child_off[I + 1]; t++) {  // fixed order: the vertex, then its mid-edge nodes
+    const int n = child[t];
+    const double w = (double)child_w[t];
+#pragma unroll
+    for (int c = 0; c < 3; c++) r[c] += w * (double)res_f[3 * n + c] / sc_f[3 * n + c];
+  }
+  const float inv_theta = (float)coef_c[0];
+  float rs[3];
+#pragma unroll
+  for (int c = 0; c < 3; c++) rs[c] = (float)(r[c] * sc_c[3 * I + c]);
+  const float* D = Dinv_c + (size_t)9 * I;
+#pragma unroll
+  for (int c = 0; c < 3; c++) {
+    const float v = (D[3 * c] * rs[0] + D[3 * c + 1] * rs[1] + D[3 * c + 2] * rs[2]) * inv_theta;
+    d_c[3 * I + c] = v;
+    z_c[3 * I + c] = v;
+    res_c[3 * I + c] = rs[c];
+  }
+}
+void launch_pmg_restrict_init(hipStream_t s, int Nc, const int* child_off, const int* child, const float* child_w,
+                              const float* res_f, const double* sc_f, const double* sc_c, const float* Dinv_c,
+                              const double* coef_c, float* d_c, float* z_c, float* res_c) {
+  hipLaunchKernelGGL(pmg_restrict_init_kernel, dim3((Nc + 255) / 256), dim3(256), 0, s, Nc, child_off, child, child_w,
+                     res_f, sc_f, sc_c, Dinv_c, coef_c, d_c, z_c, res_c);
+}
+
+// Prolongation of the coarse correction:  corr^ = S_f^-1 P S_c z^_c ;  z^ += corr^ ;  d := corr^ (the next fine step
+// subtracts Hs corr^ from the residual and starts the post-smoothing polynomial)
+__global__ __launch_bounds__(256) void pmg_prolong_kernel(int N, const int* __restrict__ par0,
+                                                         const int* __restrict__ par1,
+                                                         const float* __restrict__ z_c,
+                                                         const double* __restrict__ sc_c,
+                                                         const double* __restrict__ sc_f, float* __restrict__ z_f,
+                                                         float* __restrict__ d_f) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const int a = par0[i], b = par1[i];
+#pragma unroll
+  for (int c = 0; c < 3; c++) {
+    const double ea = sc_c[3 * a + c] * (double)z_c[3 * a + c];
+    const double e = (a == b) ? ea : 0.5 * (ea + sc_c[3 * b + c] * (double)z_c[3 * b + c]);
+    const float corr = (float)(e / sc_f[3 * i + c]);
+    d_f[3 * i + c] = corr;
+    z_f[3 * i + c] += corr;
+  }
+}
+void launch_pmg_prolong(hipStream_t s, int N, const int* par0, const int* par1, const float* z_c, const double* sc_c,
+                        const double* sc_f, float* z_f, float* d_f) {
+  hipLaunchKernelGGL(pmg_prolong_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, par0, par1, z_c, sc_c, sc_f, z_f, d_f);
+}
+
 // the same step with the SpMV result q = H d_old already summed over ranks (multi-GPU path)
 template <bool LAST>
 __global__ __launch_bounds__(256) void cheb_update_kernel(int N, const double* __restrict__ Dinv,

@@ -15,6 +15,7 @@
 #include "../../include/tlfea_c.h"
 #include "ancf_host.h"
 #include "tlfea_internal.h"
+#include "pmg_host.h"
 
 using namespace tlfea;
 
@@ -833,7 +834,7 @@ struct tlfea_newton_s {
   int N = 0, n_constraints = 0;
   int n_constraints_global = 0;  // over all ranks (control flow must be identical on every rank)
   tlfea_newton_params prm{1e-4, 1e-4, 1e-4, 1e14, 5, 10, 1e-3};
-  tlfea_linsolve_opts lin{1e-12, 20000, 25, 0, 0.0, 0};
+  tlfea_linsolve_opts lin{1e-12, 20000, 25, 0, 0.0, 0, 0};
   double lam_max = 0.0;       // estimate of lambda_max(D^-1 H) (power iteration, warm-started across solves)
   double lam_safety = 1.15;   // the polynomial's interval ends at lam_safety * lam_max (power iteration converges from below)
   double* d_eigv = nullptr;   // its vector
@@ -843,6 +844,23 @@ struct tlfea_newton_s {
   int lp_bits_alloc = 0;
   double *d_sc = nullptr, *d_Dinv_s = nullptr;
   double *d_cz = nullptr, *d_cz2 = nullptr, *d_cres2 = nullptr;  // ping-pong partners of z / res in the LP steps
+  // two-level p-multigrid preconditioner (T10, single GPU): see pmg_host.h / pmg_apply()
+  struct Pmg {
+    bool tried = false, ok = false;
+    int Nc = 0, nnz_c = 0;
+    int *d_par0 = nullptr, *d_par1 = nullptr, *d_c_off = nullptr, *d_c_cols = nullptr, *d_c_diagpos = nullptr,
+        *d_cblk_row = nullptr, *d_child_off = nullptr, *d_child = nullptr, *d_con_off = nullptr, *d_con_blk = nullptr,
+        *d_blk_row = nullptr;
+    float *d_child_w = nullptr, *d_con_w = nullptr;
+    double *d_Hc = nullptr, *d_Dc = nullptr, *d_Dinv_c = nullptr, *d_sc_c = nullptr, *d_Dinv_s_c = nullptr,
+           *d_eigv_c = nullptr, *d_q_c = nullptr, *d_p_c = nullptr;
+    void *d_B8c = nullptr, *d_B1c = nullptr;
+    int bits_alloc = 0;
+    float* d_f32c = nullptr;   // coarse d, z^, res^ ping-pong pairs (6 x 3Nc) + (S D S)^-1 (9 Nc)
+    double* d_coef = nullptr;  // [0..7] fine smoother, [8..] coarse polynomial
+    double lam_c = 0.0;
+    Incidence inc() const { return Incidence{nullptr, nullptr, nullptr, d_c_off, d_c_cols, d_c_diagpos}; }
+  } pmg;
   float* d_f32 = nullptr;  // single-precision polynomial (single GPU): d, z, res ping-pong pairs (6 x 3N) + (SDS)^-1 (9N)
   bool fixed_pattern = false, sparsity_done = false;
   int verbose = 0;
@@ -903,7 +921,7 @@ extern "C" int tlfea_newton_create(tlfea_t10_t data, int n_constraints, tlfea_ne
   TRY(dmalloc(&s->d_xp, (size_t)s->N)); TRY(dmalloc(&s->d_yp, (size_t)s->N)); TRY(dmalloc(&s->d_zp, (size_t)s->N));
   TRY(dmalloc(&s->d_parts, (size_t)6 * kNPart));
   TRY(dmalloc(&s->d_scal, (size_t)4));
-  HIP_TRY(hipHostMalloc((void**)&s->h_pin, (8 + 2 * 64) * sizeof(double)));
+  HIP_TRY(hipHostMalloc((void**)&s->h_pin, (8 + 8 + 2 * 64) * sizeof(double)));
   TRY(dmalloc(&s->d_coef, (size_t)2 * 64));
   if (const char* e = std::getenv("TLFEA_GRAPH")) s->use_graphs = std::atoi(e) != 0;
   TRY(dmalloc(&s->d_Dinv, (size_t)9 * s->N));
@@ -918,6 +936,7 @@ extern "C" int tlfea_newton_create(tlfea_t10_t data, int n_constraints, tlfea_ne
   if (const char* e = std::getenv("TLFEA_CHEB_DEG")) s->lin.cheb_degree = std::min(64, std::max(0, std::atoi(e)));
   if (const char* e = std::getenv("TLFEA_SPMV_NT")) s->spmv_nt = std::atoi(e) != 0;
   if (const char* e = std::getenv("TLFEA_CHEB_BITS")) s->lin.cheb_bits = std::atoi(e);
+  if (const char* e = std::getenv("TLFEA_PRECOND")) s->lin.precond = std::atoi(e);
   *out = s;
   return tlfea_newton_setup(s);
 }
@@ -933,6 +952,14 @@ extern "C" int tlfea_newton_destroy(tlfea_newton_t s) {
     if (e) (void)hipEventDestroy(e);
   if (s->h_pin) (void)hipHostFree(s->h_pin);
   cg_graphs_destroy(s);
+  {
+    auto& m = s->pmg;
+    void* pp[] = {m.d_par0, m.d_par1, m.d_c_off, m.d_c_cols, m.d_c_diagpos, m.d_cblk_row, m.d_child_off, m.d_child,
+                  m.d_con_off, m.d_con_blk, m.d_blk_row, m.d_child_w, m.d_con_w, m.d_Hc, m.d_Dc, m.d_Dinv_c, m.d_sc_c,
+                  m.d_Dinv_s_c, m.d_eigv_c, m.d_q_c, m.d_p_c, m.d_B8c, m.d_B1c, m.d_f32c, m.d_coef};
+    for (void* q : pp)
+      if (q) (void)hipFree(q);
+  }
   if (s->d_coef) (void)hipFree(s->d_coef);
   if (s->stream_own) (void)hipStreamDestroy(s->stream_own);
   delete s;
@@ -964,6 +991,7 @@ extern "C" int tlfea_newton_set_linsolve_opts(tlfea_newton_t s, const tlfea_lins
   if (s->lin.cheb_degree > 64) s->lin.cheb_degree = 64;
   if (!(s->lin.cheb_kappa > 1.0)) s->lin.cheb_kappa = 0.0;  // auto
   if (s->lin.cheb_bits != 16 && s->lin.cheb_bits != 32 && s->lin.cheb_bits != 64) s->lin.cheb_bits = 0;
+  if (s->lin.precond < 0 || s->lin.precond > 2) s->lin.precond = 0;
   return 0;
 }
 extern "C" int tlfea_newton_set_fixed_sparsity_pattern(tlfea_newton_t s, int fixed) {
@@ -1444,6 +1472,197 @@ static int cheb_apply(tlfea_newton_t s, const double* d_r, double* d_z, double* 
   return 0;
 }
 
+// ---- two-level p-multigrid preconditioner (T10 quadratic tets -> their linear vertex mesh) ----------------------
+// z = M^-1 r, one symmetric V-cycle in the scaled single-precision space of the polynomial path:
+//   pre-smooth   2-term Chebyshev polynomial of the fine operator on [lmax/kappa_s, lmax]     (2 fine passes)
+//   restrict     r_c = P^T (r - H z)              coarse system Hc = P^T H P (Galerkin, rebuilt every Newton iteration)
+//   coarse       degree-kc Chebyshev polynomial of Hc (its own fp16 copy, 1/14 of the fine blocks)
+//   prolong      z += P e_c
+//   post-smooth  the same 2-term polynomial on the updated residual                           (2 fine passes)
+// Every piece is a fixed polynomial / linear map, so M^-1 is a fixed SPD operator and plain CG applies.  Against the
+// degree-24 polynomial it replaces: 4 fine + ~1.1 fine-equivalent coarse passes per CG iteration instead of 23, and
+// iteration counts that grow slowly with the mesh (CPU prototype: 10k elements 38 vs 33, 83k elements 47 vs 65).
+// The coarse problem is solved by a fixed polynomial, so its degree must grow with the coarse mesh: measured optimum
+// (kc, kappa_c) = (12, 200) at 2 197 coarse nodes (config B: 3.9 ms), (32, 1600) at 172 081 (config C: 98 ms; 16/400
+// gives 159 ms, 48/3200 108 ms) -- about 3.2 per doubling of the node count, with kappa_c = 1.5 kc^2.  The fine
+// smoother stays the 2-term polynomial on [lmax/8, lmax] (kappa_s 5 / 8 / 12: 103 / 98 / 158 ms at config C).
+static const int kPmgMaxCoarseDeg = 64;
+static int pmg_coarse_degree(int n_coarse) {
+  static const int forced = std::getenv("TLFEA_PMG_KC") ? std::atoi(std::getenv("TLFEA_PMG_KC")) : 0;
+  if (forced > 1) return std::min(forced, kPmgMaxCoarseDeg);
+  const double kc = 12.0 + 3.2 * (std::log2((double)std::max(2, n_coarse)) - 11.1);
+  return std::max(8, std::min(kPmgMaxCoarseDeg, (int)std::lround(kc)));
+}
+static double pmg_kappa_coarse(int kc) {
+  static const double forced = std::getenv("TLFEA_PMG_KAPPA_C") ? std::atof(std::getenv("TLFEA_PMG_KAPPA_C")) : 0.0;
+  return forced > 1.0 ? forced : 1.5 * kc * kc;
+}
+static const double kPmgKappaS = std::getenv("TLFEA_PMG_KAPPA_S") ? std::atof(std::getenv("TLFEA_PMG_KAPPA_S")) : 8.0;
+
+template <typename T>
+static int upload_vec(T** dst, const std::vector<T>& v) {
+  TRY(dmalloc(dst, std::max<size_t>(1, v.size())));
+  if (!v.empty()) HIP_TRY(hipMemcpy(*dst, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+  return 0;
+}
+
+// 1 = Chebyshev polynomial, 2 = p-multigrid.  Auto: p-multigrid wherever it exists (T10, one GPU, low-precision path,
+// no general linear constraint rows -- they couple coefficients the vertex hierarchy does not know about).
+static int precond_eff(tlfea_newton_t s) {
+  if (s->lin.precond == 1) return 1;
+  tlfea_t10_t d = s->d;
+  const bool possible = d->kind == kT10 && !s->ar && d->cons_mode != 2 && cheb_degree_eff(s) > 1 &&
+                        cheb_bits_eff(s) != 64 && !(s->pmg.tried && !s->pmg.ok);
+  return possible ? 2 : 1;
+}
+
+static int pmg_prepare(tlfea_newton_t s) {
+  auto& m = s->pmg;
+  if (m.tried) return 0;
+  m.tried = true;
+  tlfea_t10_t d = s->d;
+  PmgHost h;
+  if (!pmg_build(d->N, d->E, d->h_conn.data(), d->h_off.data(), d->h_cols.data(), h)) {
+    if (s->verbose) std::printf("p-multigrid: the mesh is not a conforming T10 mesh, using the polynomial preconditioner\n");
+    return 0;
+  }
+  m.Nc = h.Nc;
+  m.nnz_c = h.nnz_c;
+  TRY(upload_vec(&m.d_par0, h.par0)); TRY(upload_vec(&m.d_par1, h.par1));
+  TRY(upload_vec(&m.d_c_off, h.c_off)); TRY(upload_vec(&m.d_c_cols, h.c_cols)); TRY(upload_vec(&m.d_c_diagpos, h.c_diagpos));
+  TRY(upload_vec(&m.d_cblk_row, h.cblk_row));
+  TRY(upload_vec(&m.d_child_off, h.child_off)); TRY(upload_vec(&m.d_child, h.child)); TRY(upload_vec(&m.d_child_w, h.child_w));
+  TRY(upload_vec(&m.d_con_off, h.con_off)); TRY(upload_vec(&m.d_con_blk, h.con_blk)); TRY(upload_vec(&m.d_con_w, h.con_w));
+  TRY(upload_vec(&m.d_blk_row, h.blk_row));
+  const size_t nc = 3 * (size_t)m.Nc;
+  TRY(dmalloc(&m.d_Hc, (size_t)9 * m.nnz_c));
+  TRY(dmalloc(&m.d_Dc, (size_t)9 * m.Nc)); TRY(dmalloc(&m.d_Dinv_c, (size_t)9 * m.Nc));
+  TRY(dmalloc(&m.d_sc_c, nc)); TRY(dmalloc(&m.d_Dinv_s_c, (size_t)9 * m.Nc));
+  TRY(dmalloc(&m.d_eigv_c, nc)); TRY(dmalloc(&m.d_q_c, nc)); TRY(dmalloc(&m.d_p_c, nc));
+  TRY(dmalloc(&m.d_f32c, 6 * nc + (size_t)9 * m.Nc));
+  TRY(dmalloc(&m.d_coef, (size_t)8 + 2 * kPmgMaxCoarseDeg));
+  m.ok = true;
+  if (s->verbose) std::printf("p-multigrid: %d fine nodes -> %d vertex nodes, %d coarse blocks\n", d->N, m.Nc, m.nnz_c);
+  return 0;
+}
+
+// per solve, after H and the fine block diagonal are current: Hc = P^T H P, its block-Jacobi scaling and fp16 copy
+static int pmg_build_level(tlfea_newton_t s) {
+  auto& m = s->pmg;
+  tlfea_t10_t d = s->d;
+  const int bits = cheb_bits_eff(s);
+  launch_pmg_galerkin(s->stream, m.nnz_c, m.d_c_off, m.d_cblk_row, m.d_con_off, m.d_con_blk, m.d_con_w, m.d_blk_row,
+                      d->d_off, s->d_H, m.d_Hc);
+  if (m.bits_alloc != bits) {
+    if (m.d_B8c) (void)hipFree(m.d_B8c);
+    if (m.d_B1c) (void)hipFree(m.d_B1c);
+    m.d_B8c = m.d_B1c = nullptr;
+    HIP_TRY(hipMalloc(&m.d_B8c, (size_t)m.nnz_c * 8 * (bits / 8)));
+    HIP_TRY(hipMalloc(&m.d_B1c, (size_t)m.nnz_c * (bits / 8)));
+    m.bits_alloc = bits;
+  }
+  const Incidence ic = m.inc();
+  launch_extract_diag(s->stream, m.Nc, ic, m.d_Hc, m.d_Dc);
+  launch_invert_diag(s->stream, m.Nc, m.d_Dc, m.d_Dinv_c);
+  launch_lp_scale(s->stream, m.Nc, m.d_Dc, m.d_Dinv_c, m.d_sc_c, m.d_Dinv_s_c);
+  launch_lp_convert(s->stream, m.Nc, ic, m.d_Hc, m.d_sc_c, nullptr, m.d_Dc, m.d_B8c, m.d_B1c, bits);
+  launch_to_float(s->stream, (size_t)9 * m.Nc, m.d_Dinv_s_c, m.d_f32c + (size_t)18 * m.Nc);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+// lambda_max(Dc^-1 Hc) by power iteration (warm-started), then both coefficient tables to the device:
+//   d_coef[0..7]: fine smoother on [lmax/kappa_s, lmax]: (1/theta, 0), step 1 (c1, c2), residual pass (0, 0),
+//                 post-smoothing restart (0, 1/theta)
+//   d_coef[8..]:  coarse polynomial: (1/theta_c, 0), steps 1..kc-1
+static int pmg_coefficients(tlfea_newton_t s) {
+  auto& m = s->pmg;
+  const int Nc = m.Nc, nc = 3 * Nc;
+  const Incidence ic = m.inc();
+  const bool cold = !(m.lam_c > 0.0);
+  if (cold) {  // start vector: D^-1 applied to the restricted scaling vector (positive on every DOF)
+    HIP_TRY(hipMemcpyAsync(m.d_eigv_c, m.d_sc_c, (size_t)nc * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
+  }
+  launch_norm2(s->stream, m.d_eigv_c, nullptr, nc, part(s, 5), s->d_scal);
+  launch_scale_inv_sqrt(s->stream, nc, s->d_scal, m.d_eigv_c);
+  for (int k = 0; k < (cold ? 16 : 4); k++) {
+    launch_spmv_dir_dot(s->stream, Nc, ic, m.d_Hc, m.d_eigv_c, m.d_eigv_c, 1, part(s, 1), part(s, 0), m.d_p_c, m.d_q_c,
+                        part(s, 2), false, false);
+    launch_apply_dinv(s->stream, Nc, m.d_Dinv_c, m.d_q_c, m.d_eigv_c);
+    launch_norm2(s->stream, m.d_eigv_c, nullptr, nc, part(s, 5), s->d_scal);
+    launch_scale_inv_sqrt(s->stream, nc, s->d_scal, m.d_eigv_c);
+  }
+  double ss = 0.0;
+  TRY(fetch_scalar(s, s->d_scal, &ss));
+  if (!(ss > 0.0)) return fail("p-multigrid: coarse lambda_max estimate failed");
+  m.lam_c = std::sqrt(ss);
+  double* h = s->h_pin + 8;
+  {
+    const double b = s->lam_safety * s->lam_max, a = b / kPmgKappaS;
+    const double theta = 0.5 * (b + a), delta = 0.5 * (b - a), sigma = theta / delta;
+    const double rho0 = 1.0 / sigma, rho1 = 1.0 / (2.0 * sigma - rho0);
+    h[0] = 1.0 / theta; h[1] = 0.0;
+    h[2] = rho1 * rho0; h[3] = 2.0 * rho1 / delta;
+    h[4] = 0.0; h[5] = 0.0;
+    h[6] = 0.0; h[7] = 1.0 / theta;
+  }
+  const int kc = pmg_coarse_degree(m.Nc);
+  {
+    const double b = s->lam_safety * m.lam_c, a = b / pmg_kappa_coarse(kc);
+    const double theta = 0.5 * (b + a), delta = 0.5 * (b - a), sigma = theta / delta;
+    double rho = 1.0 / sigma;
+    h[8] = 1.0 / theta; h[9] = 0.0;
+    for (int k = 1; k < kc; k++) {
+      const double rho_new = 1.0 / (2.0 * sigma - rho);
+      h[8 + 2 * k] = rho_new * rho;
+      h[8 + 2 * k + 1] = 2.0 * rho_new / delta;
+      rho = rho_new;
+    }
+  }
+  HIP_TRY(hipMemcpyAsync(m.d_coef, h, (size_t)(8 + 2 * kc) * sizeof(double), hipMemcpyHostToDevice, s->stream));
+  return 0;
+}
+
+// z = V-cycle(r); the last fine step leaves the r.z slots in rz_part.  init_done: the previous iteration's update
+// kernel already wrote the fine start vectors.
+static int pmg_apply(tlfea_newton_t s, const double* d_r, double* d_z, double* rz_part, bool init_done) {
+  auto& m = s->pmg;
+  tlfea_t10_t d = s->d;
+  const int N = s->N, Nc = m.Nc, bits = cheb_bits_eff(s);
+  const size_t n = 3 * (size_t)N, nc = 3 * (size_t)Nc;
+  float *f_d = s->d_f32, *f_d2 = f_d + n, *f_z = f_d2 + n, *f_z2 = f_z + n, *f_r = f_z2 + n, *f_r2 = f_r + n;
+  const float* Dinv_f = f_r2 + n;
+  float *c_d = m.d_f32c, *c_d2 = c_d + nc, *c_z = c_d2 + nc, *c_z2 = c_z + nc, *c_r = c_z2 + nc, *c_r2 = c_r + nc;
+  const float* Dinv_fc = c_r2 + nc;
+  const double* cf = m.d_coef;
+  const Incidence inc_f = d->inc(), inc_c = m.inc();
+  // pre-smooth: d0 = (SDS)^-1 r^/theta ; one Chebyshev step ; residual of the result
+  if (!init_done) launch_cheb32_init(s->stream, N, Dinv_f, d_r, s->d_sc, cf, f_d, f_z, f_r);
+  launch_cheb32(s->stream, N, d->nnz_coef, inc_f, s->d_B8, s->d_B1, bits, Dinv_f, s->d_sc, f_d, cf + 2, f_d2, f_z, f_z2, f_r,
+                f_r2, d_r, d_z, rz_part, false);
+  launch_cheb32(s->stream, N, d->nnz_coef, inc_f, s->d_B8, s->d_B1, bits, Dinv_f, s->d_sc, f_d2, cf + 4, f_d, f_z2, f_z, f_r2,
+                f_r, d_r, d_z, rz_part, false);  // coefficients (0,0): res -= Hs d only; z^, res^ are back in f_z, f_r
+  // coarse correction
+  launch_pmg_restrict_init(s->stream, Nc, m.d_child_off, m.d_child, m.d_child_w, f_r, s->d_sc, m.d_sc_c, Dinv_fc, cf + 8,
+                           c_d, c_z, c_r);
+  const int kc = pmg_coarse_degree(Nc);
+  for (int k = 1; k < kc; k++) {
+    launch_cheb32(s->stream, Nc, m.nnz_c, inc_c, m.d_B8c, m.d_B1c, bits, Dinv_fc, m.d_sc_c, c_d, cf + 8 + 2 * k, c_d2, c_z,
+                  c_z2, c_r, c_r2, d_r, d_z, rz_part, false);
+    std::swap(c_d, c_d2);
+    std::swap(c_z, c_z2);
+    std::swap(c_r, c_r2);
+  }
+  launch_pmg_prolong(s->stream, N, m.d_par0, m.d_par1, c_z, m.d_sc_c, s->d_sc, f_z, f_d);  // z^ += corr ; d := corr
+  // post-smooth: res^ -= Hs corr ; d0' = (SDS)^-1 res^/theta ; z^ += d0'   == one step with coefficients (0, 1/theta)
+  launch_cheb32(s->stream, N, d->nnz_coef, inc_f, s->d_B8, s->d_B1, bits, Dinv_f, s->d_sc, f_d, cf + 6, f_d2, f_z, f_z2, f_r,
+                f_r2, d_r, d_z, rz_part, false);
+  // ... and the Chebyshev step that completes the 2-term polynomial; returns z = S z^ (fp64) and the r.z slots
+  launch_cheb32(s->stream, N, d->nnz_coef, inc_f, s->d_B8, s->d_B1, bits, Dinv_f, s->d_sc, f_d2, cf + 2, f_d, f_z2, f_z, f_r2,
+                f_r, d_r, d_z, rz_part, true);
+  return 0;
+}
+
 // Enqueue CG iteration `it` (parity cur = it & 1 selects the r.z slot pair and, in the fused variant, which of the
 // two direction buffers is read).  Everything an iteration needs from the previous one (alpha, beta, Chebyshev
 // coefficients) is read from device memory, so iterations >= 1 of either parity are the SAME launch sequence.
@@ -1458,7 +1677,10 @@ static int enqueue_cg_iteration(tlfea_newton_t s, double* d_x, bool first, int c
   const bool fuse_init = deg > 1 && cheb_bits_eff(s) != 64 && !s->ar;
   if (deg > 1) {
     // polynomial preconditioner: z = Cheb(r), r.z slots -> part(cur)   (deg-1 SpMV launches, no reductions)
-    TRY(cheb_apply(s, s->d_r, s->d_zv, part(s, cur), fuse_init && !first));
+    if (precond_eff(s) == 2)
+      TRY(pmg_apply(s, s->d_r, s->d_zv, part(s, cur), fuse_init && !first));
+    else
+      TRY(cheb_apply(s, s->d_r, s->d_zv, part(s, cur), fuse_init && !first));
     if (s->ar && !(s->d_own && cheb_bits_eff(s) != 64)) TRY(parts_sum(s, part(s, cur)));
   }
   if (s->profiling) (void)hipEventRecord(s->ev[4], s->stream);
@@ -1486,7 +1708,8 @@ static int enqueue_cg_iteration(tlfea_newton_t s, double* d_x, bool first, int c
       const size_t n = 3 * (size_t)N;
       float* f = s->d_f32;  // d, z^, res^ start buffers of cheb_apply and (SDS)^-1
       launch_pcg_update_init32(s->stream, N, fused ? p_new : p_old, s->d_q, part(s, cur), pq_part, d_x, s->d_r,
-                               part(s, 3), s->d_scal + 3, f + 6 * n, s->d_sc, s->d_coef, f, f + 2 * n, f + 4 * n);
+                               part(s, 3), s->d_scal + 3, f + 6 * n, s->d_sc,
+                               precond_eff(s) == 2 ? s->pmg.d_coef : s->d_coef, f, f + 2 * n, f + 4 * n);
     } else {
       launch_pcg_update_noz(s->stream, N, w, fused ? p_new : p_old, s->d_q, part(s, cur), pq_part, d_x, s->d_r,
                             part(s, 3), s->d_scal + 3);
@@ -1514,7 +1737,8 @@ static void cg_graphs_destroy(tlfea_newton_t s) {
 // is what an iteration costs otherwise.  Single-GPU path only (the multi-GPU path calls back into the host
 // between kernels).
 static int cg_graphs_prepare(tlfea_newton_t s, double* d_x, bool fused, int deg, int bits) {
-  const long key[6] = {deg, bits, fused ? 1 : 0, (long)(size_t)d_x, (long)(size_t)s->d_B8, (long)(size_t)s->d_w};
+  const long key[6] = {deg + 1000 * precond_eff(s), bits, fused ? 1 : 0, (long)(size_t)d_x, (long)(size_t)s->d_B8,
+                       (long)(size_t)s->pmg.d_B8c};
   if (s->cg_graph[0] && std::equal(key, key + 6, s->cg_graph_key)) return 0;
   cg_graphs_destroy(s);
   for (int cur = 0; cur < 2; cur++) {
@@ -1564,7 +1788,7 @@ static int pcg(tlfea_newton_t s, const double* d_b, double* d_x, int* iters_out,
     // Every convergence test drains the launch queue (tens of microseconds: as much as an iteration on a small
     // mesh).  Consecutive Newton iterations need nearly the same number of CG iterations, so after the first solve
     // the tests start one iteration before the previous solve's count and then run every iteration.
-    const int bits = cheb_bits_eff(s);
+    const int bits = cheb_bits_eff(s) + 1000 * precond_eff(s);
     int first_check = check_every;
     if (s->last_outer_iters > 1 && s->last_deg == deg && s->last_bits == bits) {
       first_check = s->last_outer_iters - 1;
@@ -1575,6 +1799,13 @@ static int pcg(tlfea_newton_t s, const double* d_b, double* d_x, int* iters_out,
     if (deg > 1) {
       TRY(estimate_lam_max(s, d_b));
       TRY(cheb_upload_coefficients(s));
+      if (precond_eff(s) == 2) {
+        TRY(pmg_prepare(s));
+        if (precond_eff(s) == 2) {  // still available after the set-up attempt
+          TRY(pmg_build_level(s));
+          TRY(pmg_coefficients(s));
+        }
+      }
     }
     const bool graphs = s->use_graphs && !s->ar && !s->profiling;
     if (graphs) TRY(cg_graphs_prepare(s, d_x, fused, deg, bits));
@@ -1602,6 +1833,7 @@ static int pcg(tlfea_newton_t s, const double* d_b, double* d_x, int* iters_out,
       s->lam_safety *= 1.5;  // kept for the following solves: the estimate is systematically low on this mesh
       if (s->verbose) std::printf("PCG breakdown: Chebyshev interval widened to %.3g x lambda_max estimate\n", s->lam_safety);
       TRY(cheb_upload_coefficients(s));
+      if (precond_eff(s) == 2) TRY(pmg_coefficients(s));
       launch_pcg_init(s->stream, N, d_b, s->d_Dinv, w, d_x, s->d_r, s->d_zv, part(s, 0), part(s, 4));
       TRY(parts_sum(s, part(s, 0), part(s, 4)));
       HIP_TRY(hipMemsetAsync(s->d_scal + 3, 0, sizeof(double), s->stream));
@@ -1623,6 +1855,37 @@ static int pcg(tlfea_newton_t s, const double* d_b, double* d_x, int* iters_out,
   return 0;
 }
 
+// Test hooks of the p-multigrid level: sizes, then the parent map and the Galerkin operator Hc = P^T H P of the CURRENT H
+// in the same DOF-level layout as H (rows 3 Nc, node row -> [d][k][e]); builds the hierarchy if needed.
+extern "C" int tlfea_newton_pmg_sizes(tlfea_newton_t s, int* n_coarse, int* nnz_coarse_blocks) {
+  TRY(tlfea_newton_analyze_hessian_sparsity(s));
+  TRY(pmg_prepare(s));
+  if (!s->pmg.ok) return fail("p-multigrid is not available for this mesh");
+  *n_coarse = s->pmg.Nc;
+  *nnz_coarse_blocks = s->pmg.nnz_c;
+  return 0;
+}
+extern "C" int tlfea_newton_pmg_retrieve(tlfea_newton_t s, int* par0, int* par1, int* c_off, int* c_cols, double* Hc) {
+  int nc = 0, nnz = 0;
+  TRY(tlfea_newton_pmg_sizes(s, &nc, &nnz));
+  auto& m = s->pmg;
+  launch_pmg_galerkin(s->stream, m.nnz_c, m.d_c_off, m.d_cblk_row, m.d_con_off, m.d_con_blk, m.d_con_w, m.d_blk_row,
+                      s->d->d_off, s->d_H, m.d_Hc);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  D2H(par0, m.d_par0, (size_t)s->N);
+  D2H(par1, m.d_par1, (size_t)s->N);
+  D2H(c_off, m.d_c_off, (size_t)nc + 1);
+  D2H(c_cols, m.d_c_cols, (size_t)nnz);
+  D2H(Hc, m.d_Hc, (size_t)9 * nnz);
+  return 0;
+}
+
+extern "C" int tlfea_newton_pmg_coarse_degree(tlfea_newton_t s) { return s && s->pmg.ok ? pmg_coarse_degree(s->pmg.Nc) : 0; }
+extern "C" int tlfea_newton_get_precond(tlfea_newton_t s) {  // 1 Chebyshev polynomial, 2 p-multigrid (what a solve would use now)
+  if (!s) return -1;
+  return cheb_degree_eff(s) > 1 ? precond_eff(s) : 0;
+}
 extern "C" int tlfea_newton_get_linsolve_info(tlfea_newton_t s, int* cheb_degree, int* cheb_bits, int* cheb_vector_bits) {
   if (!s) return fail("null argument");
   if (cheb_degree) *cheb_degree = cheb_degree_eff(s);
@@ -1653,14 +1916,16 @@ extern "C" int tlfea_newton_linear_solve(tlfea_newton_t s, const double* b, doub
 // same-stream boundary, directly comparable with rocprofv3 --kernel-trace).  The launches recompute what the
 // last Newton iteration computed (same inputs, same outputs), so the solver state is unchanged.
 // out[0] residual, [1] tangent blocks, [2] row assembly, [3] CG SpMV, [4] Chebyshev step (SpMV + vector updates).
-extern "C" int tlfea_newton_time_kernels(tlfea_newton_t s, int reps, double* out_ms4) {
+extern "C" int tlfea_newton_time_kernels(tlfea_newton_t s, int reps, double* out_ms4) {  // out: 6 entries
   TRY(tlfea_newton_analyze_hessian_sparsity(s));
   tlfea_t10_t d = s->d;
   const tlfea_newton_params& p = s->prm;
   if (reps < 1) reps = 1;
   const int N = s->N;
   const bool fused = s->pcg_fused < 0 ? (N <= 200000) : (s->pcg_fused != 0);
-  for (int k = 0; k < 5; k++) {
+  out_ms4[5] = 0.0;
+  for (int k = 0; k < 6; k++) {
+    if (k == 5 && !(s->pmg.ok && s->pmg.d_B8c)) break;
     HIP_TRY(hipEventRecord(s->ev[6], s->stream));
     for (int r = 0; r < reps; r++) {
       if (k == 0)
@@ -1675,7 +1940,15 @@ extern "C" int tlfea_newton_time_kernels(tlfea_newton_t s, int reps, double* out
         launch_spmv_dir_dot(s->stream, N, d->inc(), s->d_H, s->d_zv, (r & 1) ? s->d_p2 : s->d_p, 0, part(s, 1), part(s, 0),
                             fused ? ((r & 1) ? s->d_p : s->d_p2) : ((r & 1) ? s->d_p2 : s->d_p), s->d_q, part(s, 2), fused,
                             s->spmv_nt);
-      else if (cheb_bits_eff(s) != 64 && s->d_B8 && !s->ar) {  // one step of the polynomial, buffers ping-pong as in
+      else if (k == 5) {  // one step of the coarse-level polynomial of the p-multigrid cycle
+        auto& m = s->pmg;
+        const size_t nc = 3 * (size_t)m.Nc;
+        float* f = m.d_f32c;
+        const int a = r & 1, b = 1 - a;
+        launch_cheb32(s->stream, m.Nc, m.nnz_c, m.inc(), m.d_B8c, m.d_B1c, cheb_bits_eff(s), f + 6 * nc, m.d_sc_c,
+                      f + a * nc, m.d_coef + 10, f + b * nc, f + (2 + a) * nc, f + (2 + b) * nc, f + (4 + a) * nc,
+                      f + (4 + b) * nc, s->d_r, s->d_zv, part(s, 0), false);
+      } else if (cheb_bits_eff(s) != 64 && s->d_B8 && !s->ar) {  // one step of the polynomial, buffers ping-pong as in
         const size_t n = 3 * (size_t)N;                          // cheb_apply (each step reads what the last one wrote)
         float* f = s->d_f32;
         const int a = r & 1, b = 1 - a;

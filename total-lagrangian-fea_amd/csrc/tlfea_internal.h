@@ -120,6 +120,15 @@ void launch_cheb32(hipStream_t s, int N, int nnz_coef, const Incidence& inc, con
                    const float* Dinv_f, const double* sc, const float* d_old, const double* coef, float* d_new,
                    const float* z, float* z_new, const float* res, float* res_new, const double* r, double* z_out,
                    double* rz_part, bool last);
+// two-level p-multigrid (T10): Galerkin coarse operator and grid transfers (pmg_host.h holds the integer set-up)
+void launch_pmg_galerkin(hipStream_t s, int nnz_c, const int* c_off, const int* cblk_row, const int* con_off,
+                         const int* con_blk, const float* con_w, const int* blk_row, const int* f_off, const double* Hf,
+                         double* Hc);
+void launch_pmg_restrict_init(hipStream_t s, int Nc, const int* child_off, const int* child, const float* child_w,
+                              const float* res_f, const double* sc_f, const double* sc_c, const float* Dinv_c,
+                              const double* coef_c, float* d_c, float* z_c, float* res_c);
+void launch_pmg_prolong(hipStream_t s, int N, const int* par0, const int* par1, const float* z_c, const double* sc_c,
+                        const double* sc_f, float* z_f, float* d_f);
 // mode 0: Chebyshev step, 1: last step (z back in the unscaled space + r.z slots in out), 2: out = Hs d_old
 void launch_cheb_lp(hipStream_t s, int N, int nnz_coef, const Incidence& inc, const void* B8, const void* B1, int bits,
                     const double* Dinv_s, const double* sc, const double* d_old, const double* coef, double* d_new,

@@ -26,6 +26,7 @@ class LinSolveOpts:
     cheb_degree: int = 0      # Chebyshev polynomial preconditioner degree (1 = block-Jacobi, 0 = auto = 24)
     cheb_kappa: float = 0.0   # polynomial interval [lmax/kappa, lmax] of D^-1 H (0 = auto, by degree)
     cheb_bits: int = 0        # matrix precision of the polynomial's steps: 64 | 32 | 16 (0 = auto = 16)
+    precond: int = 0          # 0 auto | 1 Chebyshev polynomial | 2 two-level p-multigrid (T10, one GPU)
 
 
 class SyncedNewtonSolver:
@@ -55,7 +56,7 @@ class SyncedNewtonSolver:
         check(self._lib.tlfea_newton_set_parameters(self._h, C.byref(p)))
 
     def SetLinSolveOpts(self, o):
-        c = LinSolveOptsC(o.rel_tol, o.max_iter, o.check_every, o.cheb_degree, o.cheb_kappa, o.cheb_bits)
+        c = LinSolveOptsC(o.rel_tol, o.max_iter, o.check_every, o.cheb_degree, o.cheb_kappa, o.cheb_bits, o.precond)
         check(self._lib.tlfea_newton_set_linsolve_opts(self._h, C.byref(c)))
 
     def GetLinSolveInfo(self):
@@ -63,6 +64,21 @@ class SyncedNewtonSolver:
         deg, bits, vbits = C.c_int(), C.c_int(), C.c_int()
         check(self._lib.tlfea_newton_get_linsolve_info(self._h, C.byref(deg), C.byref(bits), C.byref(vbits)))
         return deg.value, bits.value, vbits.value
+
+    def GetPreconditioner(self):
+        """0 block-Jacobi, 1 Chebyshev polynomial, 2 two-level p-multigrid (what a solve would use now)"""
+        return int(self._lib.tlfea_newton_get_precond(self._h))
+
+    def RetrievePmgLevel(self):
+        """(par0, par1, c_off, c_cols, Hc_values): parent map of the fine nodes, coarse node adjacency and the Galerkin
+        operator P^T H P of the current H in the DOF-level layout of H (test hook)."""
+        nc, nnz = C.c_int(), C.c_int()
+        check(self._lib.tlfea_newton_pmg_sizes(self._h, C.byref(nc), C.byref(nnz)))
+        par0, par1 = np.zeros(self.n_coef, dtype=np.int32), np.zeros(self.n_coef, dtype=np.int32)
+        c_off, c_cols = np.zeros(nc.value + 1, dtype=np.int32), np.zeros(nnz.value, dtype=np.int32)
+        Hc = np.zeros(9 * nnz.value)
+        check(self._lib.tlfea_newton_pmg_retrieve(self._h, ip(par0), ip(par1), ip(c_off), ip(c_cols), dp(Hc)))
+        return par0, par1, c_off, c_cols, Hc
 
     def AnalyzeHessianSparsity(self):
         check(self._lib.tlfea_newton_analyze_hessian_sparsity(self._h))
@@ -165,9 +181,18 @@ class SyncedNewtonSolver:
 
     def TimeKernels(self, reps=20):
         """-> {kernel: mean ms} over `reps` back-to-back launches each (hipEvents on the launch stream)."""
-        out = np.zeros(5)
+        out = np.zeros(6)
         check(self._lib.tlfea_newton_time_kernels(self._h, int(reps), dp(out)))
-        return dict(zip(["residual", "tangent_blocks", "assemble_rows", "spmv", "cheb_step"], out.tolist()))
+        return dict(zip(["residual", "tangent_blocks", "assemble_rows", "spmv", "cheb_step", "cheb_step_coarse"],
+                        out.tolist()))
+
+    def GetPmgInfo(self):
+        """(coarse nodes, coarse 3x3 blocks, coarse polynomial degree) of the p-multigrid level, or None"""
+        if self.GetPreconditioner() != 2:
+            return None
+        nc, nnz = C.c_int(), C.c_int()
+        check(self._lib.tlfea_newton_pmg_sizes(self._h, C.byref(nc), C.byref(nnz)))
+        return nc.value, nnz.value, int(self._lib.tlfea_newton_pmg_coarse_degree(self._h))
 
     def BeginStep(self):
         check(self._lib.tlfea_newton_begin_step(self._h))
