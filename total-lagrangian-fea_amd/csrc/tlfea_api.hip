@@ -1358,7 +1358,7 @@ static int estimate_lam_max(tlfea_newton_t s, const double* d_b) {
   tlfea_t10_t d = s->d;
   const int N = s->N, n = 3 * N;
   const bool cold = !(s->lam_max > 0.0);
-  const int iters = cold ? 16 : 4;
+  const int iters = cold ? 16 : 2;  // warm: H moves little between Newton iterations, the vector is kept
   // v <- D^-1 H v / ||D^-1 H v||, the norm stays on the device between iterations: one host read at the end
   if (cold) launch_apply_dinv(s->stream, N, s->d_Dinv, d_b, s->d_eigv);
   TRY(device_sumsq_async(s, s->d_eigv, s->d_w, n));
@@ -1585,7 +1585,7 @@ static int pmg_coefficients(tlfea_newton_t s) {
   }
   launch_norm2(s->stream, m.d_eigv_c, nullptr, nc, part(s, 5), s->d_scal);
   launch_scale_inv_sqrt(s->stream, nc, s->d_scal, m.d_eigv_c);
-  for (int k = 0; k < (cold ? 16 : 4); k++) {
+  for (int k = 0; k < (cold ? 16 : 2); k++) {
     launch_spmv_dir_dot(s->stream, Nc, ic, m.d_Hc, m.d_eigv_c, m.d_eigv_c, 1, part(s, 1), part(s, 0), m.d_p_c, m.d_q_c,
                         part(s, 2), false, false);
     launch_apply_dinv(s->stream, Nc, m.d_Dinv_c, m.d_q_c, m.d_eigv_c);
