@@ -257,7 +257,10 @@ def load_pmc_traffic():
     for r in csv.DictReader(open(path)):
         for frag, key in names.items():
             if re.search(frag, r["kernel"]):
-                acc.setdefault(key, {})[r["counter"]] = float(r["mean_KB"])
+                # several rows can match (the polynomial step runs on both levels of the p-multigrid cycle, one row per
+                # grid size): the fine level is the one with the larger traffic
+                c = acc.setdefault(key, {})
+                c[r["counter"]] = max(c.get(r["counter"], 0.0), float(r["mean_KB"]))
     for key, c in acc.items():
         if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
             out[key] = int((2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024)

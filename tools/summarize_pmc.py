@@ -13,6 +13,10 @@ for f in sys.argv[1:]:
     for r in csv.DictReader(open(f)):
         name = r["Kernel_Name"].split("(")[0]
         if "tlfea" in name:
+            # the polynomial step kernel runs on two levels of the p-multigrid cycle: keep launches of different grid
+            # sizes apart (fine level = the larger grid)
+            if "cheb32_kernel" in name and r.get("Grid_Size"):
+                name += " [grid %s]" % r["Grid_Size"]
             agg[(name, r["Counter_Name"])].append(float(r["Counter_Value"]))
     for (k, c), v in sorted(agg.items()):
         out.append(dict(kernel=k, counter=c, launches=len(v), mean_KB=round(sum(v) / len(v), 2)))

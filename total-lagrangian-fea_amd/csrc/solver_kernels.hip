@@ -1048,30 +1048,24 @@ __global__ __launch_bounds__(256) void pmg_galerkin_kernel(int nnz_c, const int*
                                                           const int* __restrict__ blk_row,
                                                           const int* __restrict__ f_off,
                                                           const double* __restrict__ Hf, double* __restrict__ Hc) {
-  const int cb = blockIdx.x * blockDim.x + threadIdx.x;
+  // one thread per ENTRY of a coarse block (9 per block): small meshes have too few coarse blocks to fill the chip
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int cb = t / 9, de = t - 9 * cb;
   if (cb >= nnz_c) return;
-  double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-  for (int t = con_off[cb]; t < con_off[cb + 1]; t++) {
-    const int g = con_blk[t], i = blk_row[g];
+  const int dd = de / 3, ee = de - 3 * dd;
+  double acc = 0.0;
+  for (int u = con_off[cb]; u < con_off[cb + 1]; u++) {  // ascending fine block index: fixed summation order
+    const int g = con_blk[u], i = blk_row[g];
     const int o = f_off[i], deg = f_off[i + 1] - o, k = g - o;
-    const double w = (double)con_w[t];
-    const double* Hi = Hf + (size_t)9 * o + 3 * k;
-#pragma unroll
-    for (int d = 0; d < 3; d++)
-#pragma unroll
-      for (int e = 0; e < 3; e++) acc[3 * d + e] += w * Hi[(size_t)d * 3 * deg + e];
+    acc += (double)con_w[u] * Hf[(size_t)9 * o + (size_t)dd * 3 * deg + 3 * k + ee];
   }
   const int I = cblk_row[cb], oc = c_off[I], degc = c_off[I + 1] - oc, pc = cb - oc;
-  double* out = Hc + (size_t)9 * oc + 3 * pc;
-#pragma unroll
-  for (int d = 0; d < 3; d++)
-#pragma unroll
-    for (int e = 0; e < 3; e++) out[(size_t)d * 3 * degc + e] = acc[3 * d + e];
+  Hc[(size_t)9 * oc + (size_t)dd * 3 * degc + 3 * pc + ee] = acc;
 }
 void launch_pmg_galerkin(hipStream_t s, int nnz_c, const int* c_off, const int* cblk_row, const int* con_off,
                          const int* con_blk, const float* con_w, const int* blk_row, const int* f_off, const double* Hf,
                          double* Hc) {
-  hipLaunchKernelGGL(pmg_galerkin_kernel, dim3((nnz_c + 255) / 256), dim3(256), 0, s, nnz_c, c_off, cblk_row, con_off,
+  hipLaunchKernelGGL(pmg_galerkin_kernel, dim3((unsigned)(((size_t)9 * nnz_c + 255) / 256)), dim3(256), 0, s, nnz_c, c_off, cblk_row, con_off,
                      con_blk, con_w, blk_row, f_off, Hf, Hc);
 }
 
@@ -1082,32 +1076,37 @@ __global__ __launch_bounds__(256) void pmg_restrict_init_kernel(
     const float* __restrict__ res_f, const double* __restrict__ sc_f, const double* __restrict__ sc_c,
     const float* __restrict__ Dinv_c, const double* __restrict__ coef_c, float* __restrict__ d_c,
     float* __restrict__ z_c, float* __restrict__ res_c) {
-  const int I = blockIdx.x * blockDim.x + threadIdx.x;
+  // 16 lanes per coarse node: the ~15 children are loaded in parallel and summed by a fixed-order butterfly
+  const int lane = threadIdx.x & 15;
+  const int I = blockIdx.x * 16 + (threadIdx.x >> 4);
   if (I >= Nc) return;
   double r[3] = {0.0, 0.0, 0.0};
-  for (int t = child_off[I]; t < child_off[I + 1]; t++) {  // fixed order: the vertex, then its mid-edge nodes
+  for (int t = child_off[I] + lane; t < child_off[I + 1]; t += 16) {
     const int n = child[t];
     const double w = (double)child_w[t];
 #pragma unroll
     for (int c = 0; c < 3; c++) r[c] += w * (double)res_f[3 * n + c] / sc_f[3 * n + c];
   }
-  const float inv_theta = (float)coef_c[0];
-  float rs[3];
 #pragma unroll
-  for (int c = 0; c < 3; c++) rs[c] = (float)(r[c] * sc_c[3 * I + c]);
-  const float* D = Dinv_c + (size_t)9 * I;
-#pragma unroll
-  for (int c = 0; c < 3; c++) {
-    const float v = (D[3 * c] * rs[0] + D[3 * c + 1] * rs[1] + D[3 * c + 2] * rs[2]) * inv_theta;
-    d_c[3 * I + c] = v;
-    z_c[3 * I + c] = v;
-    res_c[3 * I + c] = rs[c];
+  for (int o = 8; o > 0; o >>= 1) {
+    r[0] += __shfl_xor(r[0], o);
+    r[1] += __shfl_xor(r[1], o);
+    r[2] += __shfl_xor(r[2], o);
   }
+  if (lane >= 3) return;
+  const int c = lane;
+  const float inv_theta = (float)coef_c[0];
+  const float rs0 = (float)(r[0] * sc_c[3 * I]), rs1 = (float)(r[1] * sc_c[3 * I + 1]), rs2 = (float)(r[2] * sc_c[3 * I + 2]);
+  const float* D = Dinv_c + (size_t)9 * I + 3 * c;
+  const float v = (D[0] * rs0 + D[1] * rs1 + D[2] * rs2) * inv_theta;
+  d_c[3 * I + c] = v;
+  z_c[3 * I + c] = v;
+  res_c[3 * I + c] = (c == 0) ? rs0 : ((c == 1) ? rs1 : rs2);
 }
 void launch_pmg_restrict_init(hipStream_t s, int Nc, const int* child_off, const int* child, const float* child_w,
                               const float* res_f, const double* sc_f, const double* sc_c, const float* Dinv_c,
                               const double* coef_c, float* d_c, float* z_c, float* res_c) {
-  hipLaunchKernelGGL(pmg_restrict_init_kernel, dim3((Nc + 255) / 256), dim3(256), 0, s, Nc, child_off, child, child_w,
+  hipLaunchKernelGGL(pmg_restrict_init_kernel, dim3((Nc + 15) / 16), dim3(256), 0, s, Nc, child_off, child, child_w,
                      res_f, sc_f, sc_c, Dinv_c, coef_c, d_c, z_c, res_c);
 }
 
