@@ -25,6 +25,7 @@ struct PmgHost {
   std::vector<float> child_w;                // 1 or 1/2
   std::vector<int> con_off;                  // [nnz_c+1] contributions of fine blocks to each coarse block
   std::vector<int> con_blk;                  // fine block index (off[i] + k), ascending within a coarse block
+  std::vector<int> con_base, con_deg;        // of that fine block: 9 off[i] + 3 k (its place in H's layout) and deg(i)
   std::vector<float> con_w;                  // w_i * w_j
   std::vector<int> blk_row;                  // [nnz_f] fine row of each fine block
 };
@@ -150,6 +151,8 @@ inline bool pmg_build(int N, int E, const int* conn, const int* off, const int* 
   for (int k = 0; k < o.nnz_c; k++) o.con_off[k + 1] += o.con_off[k];
   o.con_blk.assign((size_t)o.con_off[o.nnz_c], 0);
   o.con_w.assign((size_t)o.con_off[o.nnz_c], 0.f);
+  o.con_base.assign((size_t)o.con_off[o.nnz_c], 0);
+  o.con_deg.assign((size_t)o.con_off[o.nnz_c], 0);
   {
     std::vector<int> cur(o.con_off.begin(), o.con_off.end() - 1);
     for (int g = 0; g < nnz_f; g++) {  // ascending fine block index: fixed summation order
@@ -159,6 +162,8 @@ inline bool pmg_build(int N, int E, const int* conn, const int* off, const int* 
         const int cb = tgt[(size_t)4 * g + t];
         if (cb < 0) continue;
         o.con_blk[cur[cb]] = g;
+        o.con_base[cur[cb]] = 9 * off[i] + 3 * (g - off[i]);
+        o.con_deg[cur[cb]] = off[i + 1] - off[i];
         o.con_w[cur[cb]++] = wi * wj;
       }
     }

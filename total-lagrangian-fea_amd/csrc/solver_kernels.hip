@@ -1043,30 +1043,42 @@ void launch_cheb32(hipStream_t s, int N, int nnz_coef, const Incidence& inc, con
 __global__ __launch_bounds__(256) void pmg_galerkin_kernel(int nnz_c, const int* __restrict__ c_off,
                                                           const int* __restrict__ cblk_row,
                                                           const int* __restrict__ con_off,
-                                                          const int* __restrict__ con_blk,
+                                                          const int* __restrict__ con_base,
+                                                          const int* __restrict__ con_deg,
                                                           const float* __restrict__ con_w,
-                                                          const int* __restrict__ blk_row,
-                                                          const int* __restrict__ f_off,
                                                           const double* __restrict__ Hf, double* __restrict__ Hc) {
-  // one thread per ENTRY of a coarse block (9 per block): small meshes have too few coarse blocks to fill the chip
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  const int cb = t / 9, de = t - 9 * cb;
+  // 16 lanes per coarse block: each lane adds every 16th contribution (about 40 per block), then a fixed-order
+  // butterfly; con_base = 9 off[i] + 3 k and con_deg = deg(i) of the contributing fine block are precomputed so that
+  // a contribution is one independent round trip instead of a chain of four
+  const int lane = threadIdx.x & 15;
+  const int cb = blockIdx.x * 16 + (threadIdx.x >> 4);
   if (cb >= nnz_c) return;
-  const int dd = de / 3, ee = de - 3 * dd;
-  double acc = 0.0;
-  for (int u = con_off[cb]; u < con_off[cb + 1]; u++) {  // ascending fine block index: fixed summation order
-    const int g = con_blk[u], i = blk_row[g];
-    const int o = f_off[i], deg = f_off[i + 1] - o, k = g - o;
-    acc += (double)con_w[u] * Hf[(size_t)9 * o + (size_t)dd * 3 * deg + 3 * k + ee];
+  double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int u = con_off[cb] + lane; u < con_off[cb + 1]; u += 16) {
+    const double w = (double)con_w[u];
+    const int deg3 = 3 * con_deg[u];
+    const double* Hi = Hf + con_base[u];
+#pragma unroll
+    for (int d = 0; d < 3; d++)
+#pragma unroll
+      for (int e = 0; e < 3; e++) acc[3 * d + e] += w * Hi[(size_t)d * deg3 + e];
   }
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1)
+#pragma unroll
+    for (int k = 0; k < 9; k++) acc[k] += __shfl_xor(acc[k], o);
+  if (lane >= 9) return;
+  const int dd = lane / 3, ee = lane - 3 * dd;
+  double v = acc[0];
+#pragma unroll
+  for (int k = 1; k < 9; k++) v = (lane == k) ? acc[k] : v;
   const int I = cblk_row[cb], oc = c_off[I], degc = c_off[I + 1] - oc, pc = cb - oc;
-  Hc[(size_t)9 * oc + (size_t)dd * 3 * degc + 3 * pc + ee] = acc;
+  Hc[(size_t)9 * oc + (size_t)dd * 3 * degc + 3 * pc + ee] = v;
 }
 void launch_pmg_galerkin(hipStream_t s, int nnz_c, const int* c_off, const int* cblk_row, const int* con_off,
-                         const int* con_blk, const float* con_w, const int* blk_row, const int* f_off, const double* Hf,
-                         double* Hc) {
-  hipLaunchKernelGGL(pmg_galerkin_kernel, dim3((unsigned)(((size_t)9 * nnz_c + 255) / 256)), dim3(256), 0, s, nnz_c, c_off, cblk_row, con_off,
-                     con_blk, con_w, blk_row, f_off, Hf, Hc);
+                         const int* con_base, const int* con_deg, const float* con_w, const double* Hf, double* Hc) {
+  hipLaunchKernelGGL(pmg_galerkin_kernel, dim3((nnz_c + 15) / 16), dim3(256), 0, s, nnz_c, c_off, cblk_row, con_off,
+                     con_base, con_deg, con_w, Hf, Hc);
 }
 
 // Restriction fused with the coarse polynomial's start vectors.  The fine residual lives in the fine scaled space

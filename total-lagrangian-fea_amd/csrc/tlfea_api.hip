@@ -849,8 +849,8 @@ struct tlfea_newton_s {
     bool tried = false, ok = false;
     int Nc = 0, nnz_c = 0;
     int *d_par0 = nullptr, *d_par1 = nullptr, *d_c_off = nullptr, *d_c_cols = nullptr, *d_c_diagpos = nullptr,
-        *d_cblk_row = nullptr, *d_child_off = nullptr, *d_child = nullptr, *d_con_off = nullptr, *d_con_blk = nullptr,
-        *d_blk_row = nullptr;
+        *d_cblk_row = nullptr, *d_child_off = nullptr, *d_child = nullptr, *d_con_off = nullptr, *d_con_base = nullptr,
+        *d_con_deg = nullptr;
     float *d_child_w = nullptr, *d_con_w = nullptr;
     double *d_Hc = nullptr, *d_Dc = nullptr, *d_Dinv_c = nullptr, *d_sc_c = nullptr, *d_Dinv_s_c = nullptr,
            *d_eigv_c = nullptr, *d_q_c = nullptr, *d_p_c = nullptr;
@@ -955,7 +955,7 @@ extern "C" int tlfea_newton_destroy(tlfea_newton_t s) {
   {
     auto& m = s->pmg;
     void* pp[] = {m.d_par0, m.d_par1, m.d_c_off, m.d_c_cols, m.d_c_diagpos, m.d_cblk_row, m.d_child_off, m.d_child,
-                  m.d_con_off, m.d_con_blk, m.d_blk_row, m.d_child_w, m.d_con_w, m.d_Hc, m.d_Dc, m.d_Dinv_c, m.d_sc_c,
+                  m.d_con_off, m.d_con_base, m.d_con_deg, m.d_child_w, m.d_con_w, m.d_Hc, m.d_Dc, m.d_Dinv_c, m.d_sc_c,
                   m.d_Dinv_s_c, m.d_eigv_c, m.d_q_c, m.d_p_c, m.d_B8c, m.d_B1c, m.d_f32c, m.d_coef};
     for (void* q : pp)
       if (q) (void)hipFree(q);
@@ -1532,8 +1532,8 @@ static int pmg_prepare(tlfea_newton_t s) {
   TRY(upload_vec(&m.d_c_off, h.c_off)); TRY(upload_vec(&m.d_c_cols, h.c_cols)); TRY(upload_vec(&m.d_c_diagpos, h.c_diagpos));
   TRY(upload_vec(&m.d_cblk_row, h.cblk_row));
   TRY(upload_vec(&m.d_child_off, h.child_off)); TRY(upload_vec(&m.d_child, h.child)); TRY(upload_vec(&m.d_child_w, h.child_w));
-  TRY(upload_vec(&m.d_con_off, h.con_off)); TRY(upload_vec(&m.d_con_blk, h.con_blk)); TRY(upload_vec(&m.d_con_w, h.con_w));
-  TRY(upload_vec(&m.d_blk_row, h.blk_row));
+  TRY(upload_vec(&m.d_con_off, h.con_off)); TRY(upload_vec(&m.d_con_base, h.con_base)); TRY(upload_vec(&m.d_con_deg, h.con_deg));
+  TRY(upload_vec(&m.d_con_w, h.con_w));
   const size_t nc = 3 * (size_t)m.Nc;
   TRY(dmalloc(&m.d_Hc, (size_t)9 * m.nnz_c));
   TRY(dmalloc(&m.d_Dc, (size_t)9 * m.Nc)); TRY(dmalloc(&m.d_Dinv_c, (size_t)9 * m.Nc));
@@ -1549,10 +1549,9 @@ static int pmg_prepare(tlfea_newton_t s) {
 // per solve, after H and the fine block diagonal are current: Hc = P^T H P, its block-Jacobi scaling and fp16 copy
 static int pmg_build_level(tlfea_newton_t s) {
   auto& m = s->pmg;
-  tlfea_t10_t d = s->d;
   const int bits = cheb_bits_eff(s);
-  launch_pmg_galerkin(s->stream, m.nnz_c, m.d_c_off, m.d_cblk_row, m.d_con_off, m.d_con_blk, m.d_con_w, m.d_blk_row,
-                      d->d_off, s->d_H, m.d_Hc);
+  launch_pmg_galerkin(s->stream, m.nnz_c, m.d_c_off, m.d_cblk_row, m.d_con_off, m.d_con_base, m.d_con_deg, m.d_con_w,
+                      s->d_H, m.d_Hc);
   if (m.bits_alloc != bits) {
     if (m.d_B8c) (void)hipFree(m.d_B8c);
     if (m.d_B1c) (void)hipFree(m.d_B1c);
@@ -1869,8 +1868,8 @@ extern "C" int tlfea_newton_pmg_retrieve(tlfea_newton_t s, int* par0, int* par1,
   int nc = 0, nnz = 0;
   TRY(tlfea_newton_pmg_sizes(s, &nc, &nnz));
   auto& m = s->pmg;
-  launch_pmg_galerkin(s->stream, m.nnz_c, m.d_c_off, m.d_cblk_row, m.d_con_off, m.d_con_blk, m.d_con_w, m.d_blk_row,
-                      s->d->d_off, s->d_H, m.d_Hc);
+  launch_pmg_galerkin(s->stream, m.nnz_c, m.d_c_off, m.d_cblk_row, m.d_con_off, m.d_con_base, m.d_con_deg, m.d_con_w,
+                      s->d_H, m.d_Hc);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(s->stream));
   D2H(par0, m.d_par0, (size_t)s->N);

@@ -122,8 +122,7 @@ void launch_cheb32(hipStream_t s, int N, int nnz_coef, const Incidence& inc, con
                    double* rz_part, bool last);
 // two-level p-multigrid (T10): Galerkin coarse operator and grid transfers (pmg_host.h holds the integer set-up)
 void launch_pmg_galerkin(hipStream_t s, int nnz_c, const int* c_off, const int* cblk_row, const int* con_off,
-                         const int* con_blk, const float* con_w, const int* blk_row, const int* f_off, const double* Hf,
-                         double* Hc);
+                         const int* con_base, const int* con_deg, const float* con_w, const double* Hf, double* Hc);
 void launch_pmg_restrict_init(hipStream_t s, int Nc, const int* child_off, const int* child, const float* child_w,
                               const float* res_f, const double* sc_f, const double* sc_c, const float* Dinv_c,
                               const double* coef_c, float* d_c, float* z_c, float* res_c);
