@@ -187,9 +187,10 @@ int tlfea_newton_assemble_hessian(tlfea_newton_t s);
 int tlfea_newton_linear_solve(tlfea_newton_t s, const double *b, double *x, int *iters, double *rel_res);
 /* mean duration (ms) of the hot kernels over `reps` back-to-back launches each (hipEvent pair per kernel on the
  * launch stream): [0] residual, [1] tangent blocks, [2] row assembly, [3] CG SpMV (fp64), [4] fine-level polynomial /
- * smoother step, [5] coarse-level polynomial step of the p-multigrid cycle (0 without it).  State of the Newton
- * iteration is unchanged (only linear-solver work vectors are touched). */
-int tlfea_newton_time_kernels(tlfea_newton_t s, int reps, double *out_ms6);
+ * smoother step, [5] coarse-level polynomial step of the p-multigrid cycle, [6] the same kernel averaged over the
+ * launch pattern of one V-cycle (3 fine + kc-1 coarse launches; [5], [6] are 0 without p-multigrid).  State of the
+ * Newton iteration is unchanged (only linear-solver work vectors are touched). */
+int tlfea_newton_time_kernels(tlfea_newton_t s, int reps, double *out_ms7);
 /* y = H x with the current H, host vectors of 3N (partition-boundary rows summed over ranks). */
 int tlfea_newton_apply_hessian(tlfea_newton_t s, const double *x, double *y);
 /* One full Newton iteration without the convergence test (gradient, assembly, solve, update):

@@ -181,10 +181,10 @@ class SyncedNewtonSolver:
 
     def TimeKernels(self, reps=20):
         """-> {kernel: mean ms} over `reps` back-to-back launches each (hipEvents on the launch stream)."""
-        out = np.zeros(6)
+        out = np.zeros(7)
         check(self._lib.tlfea_newton_time_kernels(self._h, int(reps), dp(out)))
-        return dict(zip(["residual", "tangent_blocks", "assemble_rows", "spmv", "cheb_step", "cheb_step_coarse"],
-                        out.tolist()))
+        return dict(zip(["residual", "tangent_blocks", "assemble_rows", "spmv", "cheb_step", "cheb_step_coarse",
+                         "cheb_step_cycle"], out.tolist()))
 
     def GetPmgInfo(self):
         """(coarse nodes, coarse 3x3 blocks, coarse polynomial degree) of the p-multigrid level, or None"""
