@@ -261,3 +261,21 @@ def test_adamw_with_penalty_constraints():
     assert np.any(s.RetrieveLambdaToCPU() != 0.0)
     del s
     d.Destroy()
+
+
+def test_pmg_request_falls_back_where_it_does_not_exist():
+    """p-multigrid needs the nested vertex mesh of quadratic tets: an ANCF mesh asked for it keeps the Chebyshev
+    polynomial (and still solves)."""
+    o, d = make_pair(PROBLEMS["beam3243"](), SVK_D)
+    s = tl.SyncedNewtonSolver(d, d.get_n_constraint())
+    s.Setup()
+    s.SetParameters(tl.SyncedNewtonParams(1e-4, 0.0, 1e-6, 1e14, 5, 10, 1e-3))
+    s.SetLinSolveOpts(tl.LinSolveOpts(1e-13, 50000, 10, 0, 0.0, 0, 2))
+    assert s.GetPreconditioner() == 1 and s.GetPmgInfo() is None
+    s.Solve()
+    st = o.newton_step(orc.NewtonParams(1e-4, 0.0, 1e-6, 1e14, 5, 10, 1e-3))
+    assert s.GetStats()["newton"] == st[1]
+    X0 = np.stack([o.xt, o.yt, o.zt], axis=1)
+    assert disp_err_ok(np.stack(d.RetrievePositionToCPU(), axis=1), np.stack([o.x, o.y, o.z], axis=1), X0)
+    del s
+    d.Destroy()
