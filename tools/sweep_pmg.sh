@@ -1,4 +1,5 @@
 #!/bin/bash
+# parameter sweep of the p-multigrid cycle (coarse polynomial degree / interval, smoother interval) on configs B and C
 set -o pipefail
 mkdir -p gpurun_out/pmg2
 run() { # name config steps env...
