@@ -308,10 +308,13 @@ def cpu_baseline(w, args):
     h, rho = prm[6], prm[3]
     t0 = time.perf_counter()
     n_it = 0
+    t_elem = 0.0
     while True:
+        te = time.perf_counter()
         f_int = o.internal_force(o.v)
         g = o.grad_L(f_int, h, rho)
         ro, ci, val = o.assemble_hessian(h, rho, nthreads=cores)
+        t_elem += time.perf_counter() - te
         dv, its = orc.solve_pcg(ro, ci, val, -g, rel_tol=args.rel_tol, max_iter=50000, nthreads=cores)
         o.v += dv
         # x = x_prev + h v  (x_prev = x0)
@@ -323,7 +326,7 @@ def cpu_baseline(w, args):
         if el > 10.0 or n_it >= 3:
             break
     return {"value": round(conn.shape[0] * n_it / el, 1), "unit": "element-updates/s", "cores": cores,
-            "kind": "port", "sample": f"{n_it} Newton iteration(s) of the same workload ({conn.shape[0]} elements, "
+            "kind": "port", "element_stage_value": round(conn.shape[0] * n_it / t_elem, 1), "sample": f"{n_it} Newton iteration(s) of the same workload ({conn.shape[0]} elements, "
                                       f"PCG rel_tol {args.rel_tol:g}, {its} iterations last solve) in {el:.1f} s"}
 
 
