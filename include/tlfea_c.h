@@ -258,6 +258,27 @@ int tlfea_adamw_retrieve_lambda(tlfea_adamw_t a, double *lam);
 int tlfea_adamw_get_stats(tlfea_adamw_t a, double *out6);
 int tlfea_adamw_set_verbose(tlfea_adamw_t a, int v);
 
+/* ---- SyncedNesterovSolver (SyncedNesterov.cuh:26-260, SyncedNesterov.cu:95-372) ---------------------------------
+ * Accelerated-gradient ALM solver on the velocities (the reference's cooperative kernel as ordinary launches of the
+ * same residual path).  Fixed-coefficient constraints, single GPU. */
+typedef struct tlfea_nesterov_s *tlfea_nesterov_t;
+typedef struct { /* SyncedNesterovParams (SyncedNesterov.cuh:26-30) */
+  double alpha, rho, inner_tol, outer_tol;
+  int max_outer, max_inner;
+  double time_step;
+} tlfea_nesterov_params;
+int tlfea_nesterov_create(tlfea_t10_t data, int n_constraints, tlfea_nesterov_t *out);
+int tlfea_nesterov_destroy(tlfea_nesterov_t a);
+int tlfea_nesterov_setup(tlfea_nesterov_t a);                                          /* Setup :140-156 */
+int tlfea_nesterov_set_parameters(tlfea_nesterov_t a, const tlfea_nesterov_params *p); /* SetParameters :118-138 */
+int tlfea_nesterov_solve(tlfea_nesterov_t a);                                          /* Solve()/OneStepNesterov */
+double *tlfea_nesterov_velocity_guess_device_ptr(tlfea_nesterov_t a);
+int tlfea_nesterov_retrieve_velocity(tlfea_nesterov_t a, double *v);
+int tlfea_nesterov_retrieve_lambda(tlfea_nesterov_t a, double *lam);
+/* out6: outer iterations run, inner iterations (total), last ||g||, last ||c||, inner-converged flag, device ms */
+int tlfea_nesterov_get_stats(tlfea_nesterov_t a, double *out6);
+int tlfea_nesterov_set_verbose(tlfea_nesterov_t a, int v);
+
 #ifdef __cplusplus
 }
 #endif

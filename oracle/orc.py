@@ -257,6 +257,11 @@ class AdamWParams(C.Structure):  # SyncedAdamWParams (SyncedAdamW.cuh:27-34)
                 ("time_step", C.c_double), ("convergence_check_interval", C.c_int), ("inner_rtol", C.c_double)]
 
 
+class NesterovParams(C.Structure):  # SyncedNesterovParams (SyncedNesterov.cuh:26-30)
+    _fields_ = [("alpha", C.c_double), ("rho", C.c_double), ("inner_tol", C.c_double), ("outer_tol", C.c_double),
+                ("max_outer", C.c_int), ("max_inner", C.c_int), ("time_step", C.c_double)]
+
+
 class ElemOracle:
     """Element-type-generic oracle object (S shape functions, Q points); the ANCF subclasses fill gradN/detJ."""
 
@@ -402,6 +407,16 @@ class ElemOracle:
             dp(self.v_prev), dp(self.lam), dp(stats))
         if rc != 0:
             raise RuntimeError("oracle: Cholesky failed (matrix not SPD)")
+        return stats
+
+    def nesterov_step(self, prm):
+        """SyncedNesterovSolver::OneStepNesterov (fixed-coefficient constraints)."""
+        stats = np.zeros(5)
+        self.L.orc_gen_nesterov_step(
+            self.S, self.Q, self.E, self.N, ip(self.conn_cm), dp(self.x), dp(self.y), dp(self.z), dp(self.xt),
+            dp(self.yt), dp(self.zt), dp(self.gradN), dp(self.detJ), dp(self.qw), C.byref(self.mat), ip(self.m_off),
+            ip(self.m_col), dp(self.m_val), ip(self.fixed), len(self.fixed), dp(self.f_ext), C.byref(prm),
+            dp(self.v), dp(self.v_prev), dp(self.lam), dp(stats))
         return stats
 
     def adamw_step(self, prm):

@@ -674,3 +674,70 @@ int orc_gen_adamw_step(int S, int Q, int E, int N, const int *conn, double *x, d
   free(xp); free(P); free(f_int); free(g); free(m); free(va); free(c);
   return 0;
 }
+
+
+/* ---- SyncedNesterovSolver: one_step_nesterov_kernel (SyncedNesterov.cu:95-372) for any element type -----------
+ * Restated phase by phase: x_prev saved and both flags cleared ONCE per call (:99-113); per outer iteration (only
+ * while the outer flag is clear) v_k = v_km1 = v_guess, t = 1 (:118-139); per inner iteration (only while the inner
+ * flag is clear -- it is never cleared again inside the call) look-ahead y (:151-158), x = x_prev + dt y, compute_p,
+ * f_int, constraints, g (:162-228), flag on | ||g|| - ||g_prev|| | < inner_tol for inner > 0 (:230-247), v_next = y -
+ * alpha g (:252-258), flag on | ||v_next|| - ||v_k|| | < inner_tol (:262-283), rotate (:287-293); then v_prev = v
+ * (:305), x update, constraints, lambda += rho dt c (:333-338), outer flag on ||c|| < outer_tol (:341-354). */
+typedef struct {
+  double alpha, rho, inner_tol, outer_tol;
+  int max_outer, max_inner;
+  double time_step;
+} orc_nesterov_params;
+
+int orc_gen_nesterov_step(int S, int Q, int E, int N, const int *conn, double *x, double *y, double *z,
+                          const double *xt, const double *yt, const double *zt, const double *gradN,
+                          const double *detJ, const double *qw, const orc_material *mat, const int *mo,
+                          const int *mc, const double *mv, const int *fixed, int n_fixed, const double *f_ext,
+                          const orc_nesterov_params *prm, double *v, double *v_prev, double *lam, double *stats) {
+  const int n = 3 * N, nc = 3 * n_fixed;
+  const double dt = prm->time_step, rho = prm->rho;
+  double *xp = (double *)malloc(sizeof(double) * n), *P = (double *)malloc(sizeof(double) * 9 * (size_t)E * Q);
+  double *f_int = (double *)malloc(sizeof(double) * n), *g = (double *)malloc(sizeof(double) * n);
+  double *vk = (double *)malloc(sizeof(double) * n), *vkm1 = (double *)malloc(sizeof(double) * n);
+  double *vnext = (double *)malloc(sizeof(double) * n);
+  double *c = (double *)calloc(nc > 0 ? nc : 1, sizeof(double));
+  memcpy(xp, x, sizeof(double) * N); memcpy(xp + N, y, sizeof(double) * N); memcpy(xp + 2 * N, z, sizeof(double) * N);
+  int inner_flag = 0, outer_flag = 0, n_outer = 0, n_inner = 0;
+  double ng = 0.0, ncn = 0.0;
+  for (int outer = 0; outer < prm->max_outer; outer++) {
+    if (outer_flag) continue;
+    n_outer++;
+    memcpy(vk, v, sizeof(double) * n); memcpy(vkm1, v, sizeof(double) * n);
+    double t = 1.0, prev_ng = 0.0;
+    for (int inner = 0; inner < prm->max_inner; inner++) {
+      if (inner_flag) continue;
+      n_inner++;
+      const double t_next = 0.5 * (1.0 + sqrt(1.0 + 4.0 * t * t)), beta = (t - 1.0) / t_next;
+      for (int i = 0; i < n; i++) v[i] = vk[i] + beta * (vk[i] - vkm1[i]);
+      for (int i = 0; i < N; i++) { x[i] = xp[i] + dt * v[3 * i]; y[i] = xp[N + i] + dt * v[3 * i + 1]; z[i] = xp[2 * N + i] + dt * v[3 * i + 2]; }
+      orc_gen_compute_p(S, Q, E, conn, x, y, z, v, gradN, mat, NULL, P);
+      orc_gen_internal_force(S, Q, E, N, conn, P, gradN, detJ, qw, f_int);
+      for (int k = 0; k < n_fixed; k++) { c[3 * k] = x[fixed[k]] - xt[fixed[k]]; c[3 * k + 1] = y[fixed[k]] - yt[fixed[k]]; c[3 * k + 2] = z[fixed[k]] - zt[fixed[k]]; }
+      orc_grad_L(N, mo, mc, mv, v, v_prev, f_int, f_ext, fixed, n_fixed, c, lam, dt, rho, g);
+      ng = 0.0; for (int i = 0; i < n; i++) ng += g[i] * g[i]; ng = sqrt(ng);
+      if (inner > 0 && fabs(ng - prev_ng) < prm->inner_tol) inner_flag = 1;
+      double nvn = 0.0, nvk = 0.0;
+      for (int i = 0; i < n; i++) { vnext[i] = v[i] - prm->alpha * g[i]; nvn += vnext[i] * vnext[i]; nvk += vk[i] * vk[i]; }
+      nvn = sqrt(nvn); nvk = sqrt(nvk);
+      if (inner > 0 && fabs(nvn - nvk) < prm->inner_tol) inner_flag = 1;
+      memcpy(vkm1, vk, sizeof(double) * n); memcpy(vk, vnext, sizeof(double) * n); memcpy(v, vnext, sizeof(double) * n);
+      t = t_next;
+      prev_ng = ng;
+    }
+    memcpy(v_prev, v, sizeof(double) * n);
+    for (int i = 0; i < N; i++) { x[i] = xp[i] + dt * v[3 * i]; y[i] = xp[N + i] + dt * v[3 * i + 1]; z[i] = xp[2 * N + i] + dt * v[3 * i + 2]; }
+    for (int k = 0; k < n_fixed; k++) { c[3 * k] = x[fixed[k]] - xt[fixed[k]]; c[3 * k + 1] = y[fixed[k]] - yt[fixed[k]]; c[3 * k + 2] = z[fixed[k]] - zt[fixed[k]]; }
+    for (int k = 0; k < nc; k++) lam[k] += rho * dt * c[k];
+    ncn = 0.0; for (int k = 0; k < nc; k++) ncn += c[k] * c[k]; ncn = sqrt(ncn);
+    if (fabs(ncn) < prm->outer_tol) outer_flag = 1;
+  }
+  for (int i = 0; i < N; i++) { x[i] = xp[i] + dt * v[3 * i]; y[i] = xp[N + i] + dt * v[3 * i + 1]; z[i] = xp[2 * N + i] + dt * v[3 * i + 2]; }
+  if (stats) { stats[0] = n_outer; stats[1] = n_inner; stats[2] = ng; stats[3] = ncn; stats[4] = inner_flag; }
+  free(xp); free(P); free(f_int); free(g); free(vk); free(vkm1); free(vnext); free(c);
+  return 0;
+}

@@ -279,3 +279,31 @@ def test_pmg_request_falls_back_where_it_does_not_exist():
     assert disp_err_ok(np.stack(d.RetrievePositionToCPU(), axis=1), np.stack([o.x, o.y, o.z], axis=1), X0)
     del s
     d.Destroy()
+
+
+# ---- SyncedNesterovSolver ---------------------------------------------------------------------------
+@pytest.mark.parametrize("pname", ["beam3243", "shell3443"])
+def test_nesterov_matches_oracle(pname):
+    """SyncedNesterov with the beam_sag driver parameters (test_ancf3243.cc:351-352: alpha 1e-8, rho 1e14, tolerances
+    1e-6, 5 x 200 iterations): gradient steps are linear in g, so the device and the oracle agree to round-off including
+    the pinned coefficients, the iteration at which |d||g||| or |d||v||| drops below inner_tol, and the multipliers."""
+    o, d = make_pair(PROBLEMS[pname](), SVK_D)
+    perturb(o, d, sigma=1e-5)
+    kw = dict(alpha=1e-8, rho=1e14, inner_tol=1e-6, outer_tol=1e-6, max_outer=3, max_inner=60, time_step=1e-3)
+    s = tl.SyncedNesterovSolver(d, d.get_n_constraint())
+    s.Setup()
+    s.SetParameters(tl.SyncedNesterovParams(**kw))
+    oprm = orc.NesterovParams(*[kw[k] for k, _ in orc.NesterovParams._fields_])
+    X0 = np.stack([o.xt, o.yt, o.zt], axis=1)
+    for _ in range(2):
+        s.Solve()
+        st_o = o.nesterov_step(oprm)
+        st_g = s.GetStats()
+        assert (st_g["outer"], st_g["inner"], st_g["inner_flag"]) == (int(st_o[0]), int(st_o[1]), int(st_o[4])), (st_g, st_o)
+        xg = np.stack(d.RetrievePositionToCPU(), axis=1)
+        xo = np.stack([o.x, o.y, o.z], axis=1)
+        assert disp_err_ok(xg, xo, X0), st_g
+        assert relerr(s.RetrieveVelocityToCPU(), o.v) < 1e-9
+        assert relerr(s.RetrieveLambdaToCPU(), o.lam) < 1e-6
+    del s
+    d.Destroy()

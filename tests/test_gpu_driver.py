@@ -115,5 +115,9 @@ def test_cpp_ancf3243_driver_adamw(tmp_path):
     assert open(csv).readline().strip() == "step,tip_z"
     rows = np.loadtxt(csv, delimiter=",", skiprows=1)
     assert rows.shape == (2, 2) and rows[1, 1] > rows[0, 1] > 0.0      # tip force is +z (3100 N)
+    out = subprocess.run([drv, "--solver=nesterov", "--steps=1", "--n_elements=6", f"--csv_path={csv}"],
+                         capture_output=True, text=True, timeout=300)       # test_ancf3243.cc:350-366
+    assert out.returncode == 0, out.stderr
+    assert np.isfinite(np.loadtxt(csv, delimiter=",", skiprows=1)).all()
     bad = subprocess.run([drv, "--solver=vbd"], capture_output=True, text=True)
     assert bad.returncode == 1 and "Invalid --solver" in bad.stderr

@@ -1373,6 +1373,26 @@ void launch_adamw_update_velocity(hipStream_t s, int n, const double* g, double 
   hipLaunchKernelGGL(adamw_update_velocity_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, g, beta1, beta2, eps,
                      weight_decay, lr, inv_1mb1t, inv_1mb2t, m, va, v);
 }
+// ---- SyncedNesterov (SyncedNesterov.cu:95-372) --------------------------------------------------------------
+// look-ahead  y = v_k + beta (v_k - v_km1)  -> v_guess
+__global__ void nesterov_lookahead_kernel(int n, double beta, const double* __restrict__ vk,
+                                          const double* __restrict__ vkm1, double* __restrict__ v) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) v[i] = vk[i] + beta * (vk[i] - vkm1[i]);
+}
+void launch_nesterov_lookahead(hipStream_t s, int n, double beta, const double* vk, const double* vkm1, double* v) {
+  hipLaunchKernelGGL(nesterov_lookahead_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, beta, vk, vkm1, v);
+}
+// v_next = y - alpha g  (y is in v_guess)
+__global__ void nesterov_step_kernel(int n, double alpha, const double* __restrict__ y, const double* __restrict__ g,
+                                     double* __restrict__ vnext) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) vnext[i] = y[i] - alpha * g[i];
+}
+void launch_nesterov_step(hipStream_t s, int n, double alpha, const double* y, const double* g, double* vnext) {
+  hipLaunchKernelGGL(nesterov_step_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, alpha, y, g, vnext);
+}
+
 // x = x_prev + dt v   (adamw_update_positions_from_prev_kernel)
 __global__ void positions_from_prev_kernel(int N, const double* __restrict__ v, const double* __restrict__ xp,
                                            const double* __restrict__ yp, const double* __restrict__ zp, double dt,

@@ -2271,3 +2271,126 @@ extern "C" int tlfea_adamw_solve(tlfea_adamw_t a) {
   a->stats[4] = inner_flag; a->stats[5] = ms;
   return 0;
 }
+
+
+// =================================================================================================
+// SyncedNesterovSolver (SyncedNesterov.cuh:26-260, SyncedNesterov.cu:95-372): accelerated gradient ALM solver on the
+// velocities.  The reference runs it as one cooperative kernel with grid.sync() between phases and serial thread-0
+// norms; here the same phases are ordinary launches of the engine's residual / gradient path.  Reproduced as
+// written: the inner-converged flag is cleared once per Solve(), not per outer iteration (:110-113), so after the
+// inner loop has converged once the later outer iterations only update the multipliers.
+struct tlfea_nesterov_s {
+  tlfea_newton_t core = nullptr;
+  tlfea_nesterov_params prm{1e-8, 1e14, 1e-6, 1e-6, 5, 200, 1e-3};
+  double *d_vk = nullptr, *d_vkm1 = nullptr, *d_vnext = nullptr;
+  double stats[6] = {0, 0, 0, 0, 0, 0};
+  int verbose = 0;
+};
+extern "C" int tlfea_nesterov_create(tlfea_t10_t data, int n_constraints, tlfea_nesterov_t* out) {
+  if (!data || !out) return fail("tlfea_nesterov_create: null argument");
+  auto* a = new tlfea_nesterov_s();
+  TRY(tlfea_newton_create(data, n_constraints, &a->core));
+  const size_t n = 3 * (size_t)a->core->N;
+  TRY(dmalloc(&a->d_vk, n)); TRY(dmalloc(&a->d_vkm1, n)); TRY(dmalloc(&a->d_vnext, n));
+  *out = a;
+  return 0;
+}
+extern "C" int tlfea_nesterov_destroy(tlfea_nesterov_t a) {
+  if (!a) return 0;
+  for (double* p : {a->d_vk, a->d_vkm1, a->d_vnext})
+    if (p) (void)hipFree(p);
+  (void)tlfea_newton_destroy(a->core);
+  delete a;
+  return 0;
+}
+extern "C" int tlfea_nesterov_setup(tlfea_nesterov_t a) { return tlfea_newton_setup(a->core); }  // :140-156
+extern "C" int tlfea_nesterov_set_parameters(tlfea_nesterov_t a, const tlfea_nesterov_params* p) {
+  if (!a || !p) return fail("null argument");
+  a->prm = *p;
+  tlfea_newton_t s = a->core;  // SetParameters clears v_guess, v_prev, lambda (SyncedNesterov.cuh:135-137)
+  const size_t n = 3 * (size_t)s->N;
+  HIP_TRY(hipMemset(s->d_v, 0, n * sizeof(double)));
+  HIP_TRY(hipMemset(s->d_vprev, 0, n * sizeof(double)));
+  HIP_TRY(hipMemset(s->d_lam, 0, (size_t)std::max(1, s->n_constraints) * sizeof(double)));
+  return 0;
+}
+extern "C" int tlfea_nesterov_set_verbose(tlfea_nesterov_t a, int v) {
+  a->verbose = v;
+  return 0;
+}
+extern "C" double* tlfea_nesterov_velocity_guess_device_ptr(tlfea_nesterov_t a) { return a->core->d_v; }
+extern "C" int tlfea_nesterov_retrieve_velocity(tlfea_nesterov_t a, double* v) { return tlfea_newton_retrieve_velocity(a->core, v); }
+extern "C" int tlfea_nesterov_retrieve_lambda(tlfea_nesterov_t a, double* lam) { return tlfea_newton_retrieve_lambda(a->core, lam); }
+extern "C" int tlfea_nesterov_get_stats(tlfea_nesterov_t a, double* out6) {
+  std::copy(a->stats, a->stats + 6, out6);
+  return 0;
+}
+
+// OneStepNesterov (SyncedNesterov.cu:95-372)
+extern "C" int tlfea_nesterov_solve(tlfea_nesterov_t a) {
+  tlfea_newton_t s = a->core;
+  tlfea_t10_t d = s->d;
+  const tlfea_nesterov_params& p = a->prm;
+  if (!d->is_csr_setup) return fail("SyncedNesterov: CalcMassMatrix() must precede Solve() (the gradient uses the mass CSR)");
+  if (s->ar) return fail("SyncedNesterov: single-GPU path only");
+  if (d->cons_mode == 2) return fail("SyncedNesterov: fixed-coefficient constraints only (as the reference, :197-200)");
+  const int N = s->N, n = 3 * N;
+  const double dt = p.time_step;
+  const size_t nb = (size_t)n * sizeof(double);
+  s->prm.time_step = dt;
+  s->prm.rho = p.rho;
+  hipEvent_t e0 = s->ev[2], e1 = s->ev[3];
+  HIP_TRY(hipEventRecord(e0, s->stream));
+  TRY(begin_step(s));  // x_prev = x
+  int inner_flag = 0, outer_flag = 0, n_outer = 0, n_inner_total = 0;
+  double norm_g = 0.0, norm_c = 0.0;
+  for (int outer = 0; outer < p.max_outer; outer++) {
+    if (outer_flag) continue;
+    n_outer++;
+    HIP_TRY(hipMemcpyAsync(a->d_vk, s->d_v, nb, hipMemcpyDeviceToDevice, s->stream));
+    HIP_TRY(hipMemcpyAsync(a->d_vkm1, s->d_v, nb, hipMemcpyDeviceToDevice, s->stream));
+    double t = 1.0, prev_norm_g = 0.0;
+    for (int inner = 0; inner < p.max_inner; inner++) {
+      if (inner_flag) continue;
+      n_inner_total++;
+      const double t_next = 0.5 * (1.0 + std::sqrt(1.0 + 4.0 * t * t)), beta = (t - 1.0) / t_next;
+      launch_nesterov_lookahead(s->stream, n, beta, a->d_vk, a->d_vkm1, s->d_v);  // y -> v_guess
+      launch_positions_from_prev(s->stream, N, s->d_v, s->d_xp, s->d_yp, s->d_zp, dt, d->d_x, d->d_y, d->d_z);
+      TRY(eval_gradient(s, &norm_g));
+      if (inner > 0 && std::fabs(norm_g - prev_norm_g) < p.inner_tol) inner_flag = 1;
+      launch_nesterov_step(s->stream, n, p.alpha, s->d_v, s->d_g, a->d_vnext);
+      double norm_vn = 0.0, norm_vk = 0.0;
+      TRY(device_norm(s, a->d_vnext, nullptr, n, &norm_vn));
+      TRY(device_norm(s, a->d_vk, nullptr, n, &norm_vk));
+      if (inner > 0 && std::fabs(norm_vn - norm_vk) < p.inner_tol) inner_flag = 1;
+      if (a->verbose)
+        std::printf("outer iter: %d, inner iter: %d norm_g: %.17g norm_v_next: %.17g norm_v_k: %.17g\n", outer, inner,
+                    norm_g, norm_vn, norm_vk);
+      std::swap(a->d_vkm1, a->d_vk);   // v_km1 = v_k
+      std::swap(a->d_vk, a->d_vnext);  // v_k = v_next (the old v_km1 buffer becomes scratch)
+      HIP_TRY(hipMemcpyAsync(s->d_v, a->d_vk, nb, hipMemcpyDeviceToDevice, s->stream));  // v_guess = v_next
+      t = t_next;
+      prev_norm_g = norm_g;
+    }
+    HIP_TRY(hipMemcpyAsync(s->d_vprev, s->d_v, nb, hipMemcpyDeviceToDevice, s->stream));
+    launch_positions_from_prev(s->stream, N, s->d_v, s->d_xp, s->d_yp, s->d_zp, dt, d->d_x, d->d_y, d->d_z);
+    if (s->n_constraints > 0) {
+      launch_constraint(s->stream, d->n_fixed, d->d_fixed, d->d_x, d->d_y, d->d_z, d->d_xt, d->d_yt, d->d_zt, d->d_cons);
+      launch_dual_update(s->stream, s->n_constraints, d->d_cons, p.rho * dt, s->d_lam);  // lambda += rho dt c
+      TRY(device_norm(s, d->d_cons, nullptr, s->n_constraints, &norm_c));
+    } else {
+      norm_c = 0.0;
+    }
+    if (a->verbose) std::printf("norm_constraint: %.17g\n", norm_c);
+    if (std::fabs(norm_c) < p.outer_tol) outer_flag = 1;
+  }
+  launch_positions_from_prev(s->stream, N, s->d_v, s->d_xp, s->d_yp, s->d_zp, dt, d->d_x, d->d_y, d->d_z);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(e1, s->stream));
+  HIP_TRY(hipEventSynchronize(e1));
+  float ms = 0.f;
+  HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+  a->stats[0] = n_outer; a->stats[1] = n_inner_total; a->stats[2] = norm_g; a->stats[3] = norm_c;
+  a->stats[4] = inner_flag; a->stats[5] = ms;
+  return 0;
+}

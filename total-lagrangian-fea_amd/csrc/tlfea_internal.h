@@ -149,6 +149,8 @@ void launch_axpy_neg(hipStream_t s, int n, const double* g, double* r);
 void launch_adamw_update_velocity(hipStream_t s, int n, const double* g, double beta1, double beta2, double eps,
                                   double weight_decay, double lr, double inv_1mb1t, double inv_1mb2t, double* m,
                                   double* va, double* v);
+void launch_nesterov_lookahead(hipStream_t s, int n, double beta, const double* vk, const double* vkm1, double* v);
+void launch_nesterov_step(hipStream_t s, int n, double alpha, const double* y, const double* g, double* vnext);
 void launch_positions_from_prev(hipStream_t s, int N, const double* v, const double* xp, const double* yp,
                                 const double* zp, double dt, double* x, double* y, double* z);
 void launch_dual_update(hipStream_t s, int nc, const double* cons, double rho, double* lam);

@@ -28,8 +28,8 @@ int main(int argc, char** argv) {
     else if (a == "--csv") csv_path = "tip_z_history_ancf3243_newton.csv";
     else if (StartsWith(a, "--solver=")) {
       solver_kind = a.substr(9);
-      if (solver_kind != "newton" && solver_kind != "adamw") {
-        std::cerr << "Invalid --solver (built: newton | adamw): " << solver_kind << std::endl;
+      if (solver_kind != "newton" && solver_kind != "adamw" && solver_kind != "nesterov") {
+        std::cerr << "Invalid --solver (built: newton | adamw | nesterov): " << solver_kind << std::endl;
         return 1;
       }
     }
@@ -78,10 +78,16 @@ int main(int argc, char** argv) {
     sv->Setup();
     sv->SetParameters(&params);
     solver_ptr.reset(sv);
-  } else {
+  } else if (solver_kind == "adamw") {
     auto* sv = new SyncedAdamWNocoopSolver(&data, data.get_n_constraint());
     sv->Setup();
     sv->SetParameters(&aparams);
+    solver_ptr.reset(sv);
+  } else {
+    SyncedNesterovParams nparams = {1.0e-8, 1e14, 1.0e-6, 1.0e-6, 5, 200, dt};  // test_ancf3243.cc:351-352
+    auto* sv = new SyncedNesterovSolver(&data, data.get_n_constraint());
+    sv->Setup();
+    sv->SetParameters(&nparams);
     solver_ptr.reset(sv);
   }
   SolverBase& solver = *solver_ptr;

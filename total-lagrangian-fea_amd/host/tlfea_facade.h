@@ -843,6 +843,33 @@ class SyncedNewtonSolver : public SolverBase {
   tlfea_newton_t s_ = nullptr;
 };
 
+// SyncedNesterovSolver (SyncedNesterov.cuh:26-260)
+struct SyncedNesterovParams {
+  double alpha, rho, inner_tol, outer_tol;
+  int max_outer, max_inner;
+  double time_step;
+};
+class SyncedNesterovSolver : public SolverBase {
+ public:
+  SyncedNesterovSolver(ElementBase* data, int n_constraints) {
+    TLFEA_HANDLE_ERROR(tlfea_nesterov_create(static_cast<GPU_FEAT10_Data*>(data)->h, n_constraints, &a_));
+  }
+  ~SyncedNesterovSolver() override { tlfea_nesterov_destroy(a_); }
+  void Setup() { TLFEA_HANDLE_ERROR(tlfea_nesterov_setup(a_)); }
+  void SetParameters(void* params) override {
+    const SyncedNesterovParams* p = static_cast<SyncedNesterovParams*>(params);
+    tlfea_nesterov_params c{p->alpha, p->rho, p->inner_tol, p->outer_tol, p->max_outer, p->max_inner, p->time_step};
+    TLFEA_HANDLE_ERROR(tlfea_nesterov_set_parameters(a_, &c));
+  }
+  void OneStepNesterov() { TLFEA_HANDLE_ERROR(tlfea_nesterov_solve(a_)); }
+  void Solve() override { OneStepNesterov(); }
+  double* GetVelocityGuessDevicePtr() const { return tlfea_nesterov_velocity_guess_device_ptr(a_); }
+  void SetVerbose(int v) { tlfea_nesterov_set_verbose(a_, v); }
+
+ private:
+  tlfea_nesterov_t a_ = nullptr;
+};
+
 // SyncedAdamWNocoopSolver (SyncedAdamWNocoop.cuh:20-198); SyncedAdamWParams field order of SyncedAdamW.cuh:27-34
 struct SyncedAdamWParams {
   double lr, beta1, beta2, eps, weight_decay, lr_decay;

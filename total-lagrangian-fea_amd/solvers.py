@@ -4,7 +4,8 @@ from dataclasses import dataclass
 
 import numpy as np
 
-from .binding import ALLREDUCE_FN, AdamWParamsC, LinSolveOptsC, NewtonParams, check, dp, ip, load_library
+from .binding import (ALLREDUCE_FN, AdamWParamsC, LinSolveOptsC, NesterovParamsC, NewtonParams, check, dp, ip,
+                      load_library)
 
 
 @dataclass
@@ -302,4 +303,69 @@ class SyncedAdamWNocoopSolver:
     def GetStats(self):
         st = np.zeros(6)
         check(self._lib.tlfea_adamw_get_stats(self._h, dp(st)))
+        return dict(outer=int(st[0]), inner=int(st[1]), norm_g=st[2], norm_c=st[3], inner_flag=int(st[4]), ms=st[5])
+
+
+@dataclass
+class SyncedNesterovParams:
+    """SyncedNesterovParams (SyncedNesterov.cuh:26-30; driver values test_ancf3243.cc:351-352)."""
+    alpha: float = 1e-8
+    rho: float = 1e14
+    inner_tol: float = 1e-6
+    outer_tol: float = 1e-6
+    max_outer: int = 5
+    max_inner: int = 200
+    time_step: float = 1e-3
+
+
+class SyncedNesterovSolver:
+    """SyncedNesterovSolver (SyncedNesterov.cuh:32-260): accelerated-gradient ALM solver on the element kernels."""
+
+    def __init__(self, data, n_constraints):
+        self._lib = load_library()
+        self._data = data
+        self.n_coef = data.get_n_coef()
+        self.n_constraints = int(n_constraints)
+        self._h = C.c_void_p()
+        check(self._lib.tlfea_nesterov_create(data._h, self.n_constraints, C.byref(self._h)))
+
+    def __del__(self):
+        try:
+            if self._h:
+                self._lib.tlfea_nesterov_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def Setup(self):
+        check(self._lib.tlfea_nesterov_setup(self._h))
+
+    def SetParameters(self, p):
+        c = NesterovParamsC(p.alpha, p.rho, p.inner_tol, p.outer_tol, p.max_outer, p.max_inner, p.time_step)
+        check(self._lib.tlfea_nesterov_set_parameters(self._h, C.byref(c)))
+
+    def Solve(self):
+        check(self._lib.tlfea_nesterov_solve(self._h))
+
+    OneStepNesterov = Solve
+
+    def SetVerbose(self, v):
+        check(self._lib.tlfea_nesterov_set_verbose(self._h, int(v)))
+
+    def GetVelocityGuessDevicePtr(self):
+        return self._lib.tlfea_nesterov_velocity_guess_device_ptr(self._h)
+
+    def RetrieveVelocityToCPU(self):
+        v = np.zeros(3 * self.n_coef)
+        check(self._lib.tlfea_nesterov_retrieve_velocity(self._h, dp(v)))
+        return v
+
+    def RetrieveLambdaToCPU(self):
+        lam = np.zeros(self.n_constraints)
+        check(self._lib.tlfea_nesterov_retrieve_lambda(self._h, dp(lam)))
+        return lam
+
+    def GetStats(self):
+        st = np.zeros(6)
+        check(self._lib.tlfea_nesterov_get_stats(self._h, dp(st)))
         return dict(outer=int(st[0]), inner=int(st[1]), norm_g=st[2], norm_c=st[3], inner_flag=int(st[4]), ms=st[5])
