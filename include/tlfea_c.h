@@ -138,6 +138,10 @@ int tlfea_ancf_setup(tlfea_t10_t h, const double *L, const double *W, const doub
                      const double *x12, const double *y12, const double *z12, const int *conn_nodes,
                      int conn_is_colmajor);
 int tlfea_ancf_calc_dsdu_pre(tlfea_t10_t h);
+/* ANCF3243_B12_matrix / ANCF3443_B12_matrix (cpu_utils.cc:125-188, 211-420): the (B^T)^-1 matrix of one element,
+ * column-major S x S (S = 8 | 16) -- the block layout of ANCF3243_B12_matrix_flat_per_element (cpu_utils.cc:190-209).
+ * Host-only (no GPU touched); tlfea_ancf_setup computes the same blocks itself from L, W, H. */
+int tlfea_ancf_b12_matrix(int kind /*3243|3443*/, double L, double W, double H, double *out_colmajor);
 /* SetLinearConstraintsCSR (ANCF3243Data.cuh:810-940, ANCF3443Data.cuh same member): general linear constraints
  * c = J x - rhs, J in CSR over constraint rows, columns in the flattened DOF space (3*coef + component).  Accepted
  * on every element kind.  Must be called before BuildMassCSRPattern / CalcMassMatrix: the Hessian pattern includes

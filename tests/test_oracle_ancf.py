@@ -96,6 +96,30 @@ def test_generator_known_answers():
         tl.mesh_utils.GridMeshGenerator(1.0, 0.0, 0.3)
 
 
+def test_product_B12_matrix_matches_prototype(proto):
+    """ANCF3243_B12_matrix / ANCF3443_B12_matrix of the product library (host arithmetic behind the C-ABI, no GPU call)
+    against the B_inv of the reference's NumPy prototypes, and the flat per-element packing (cpu_utils.cc:190-209)."""
+    kind, g = proto
+    L, W, H = float(g["L"]), float(g["W"]), float(g["H"])
+    f = tl.mesh_utils.ANCF3243_B12_matrix if kind == 3243 else tl.mesh_utils.ANCF3443_B12_matrix
+    B = f(L, W, H)
+    S = B.shape[0]
+    assert relerr(B, g["B_inv"]) < 1e-12
+    flat = (tl.mesh_utils.ANCF3243_B12_matrix_flat_per_element if kind == 3243
+            else tl.mesh_utils.ANCF3443_B12_matrix_flat_per_element)([L, 2 * L], [W, W], [H, H])
+    assert flat.shape == (2 * S * S,) and np.array_equal(flat[:S * S].reshape(S, S).T, B)
+    assert relerr(flat[S * S:].reshape(S, S).T, f(2 * L, W, H)) == 0.0
+    with pytest.raises(tl.binding.TlfeaError):
+        tl.mesh_utils._b12(1234, L, W, H)
+
+
+def test_3243_beam_chain_generator():
+    """ANCF3243_generate_beam_coordinates (cpu_utils.cc:443-474): node n at x = -1 + 2 n, y = 1, gradients = identity."""
+    x, y, z = tl.mesh_utils.ANCF3243_generate_beam_coordinates(3)
+    assert x.tolist() == [-1, 1, 0, 0, 1, 1, 0, 0, 3, 1, 0, 0, 5, 1, 0, 0]
+    assert y.tolist() == [1, 0, 1, 0] * 4 and z.tolist() == [0, 0, 0, 1] * 4
+
+
 @pytest.mark.parametrize("kind", [3243, 3443])
 @pytest.mark.parametrize("matname", ["svk", "mr"])
 def test_tangent_is_derivative_of_force(kind, matname, golden_dir):

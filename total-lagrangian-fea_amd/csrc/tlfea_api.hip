@@ -701,6 +701,14 @@ extern "C" int tlfea_t10_calc_internal_force(tlfea_t10_t h) {
 }
 
 extern "C" int tlfea_t10_get_n_elem(tlfea_t10_t h) { return h ? h->E : -1; }
+extern "C" int tlfea_ancf_b12_matrix(int kind, double L, double W, double H, double* out_colmajor) {
+  (void)H;  // the node reference points lie at w = 0: H does not enter B (cpu_utils.cc:125-188, 211-420)
+  if (kind != 3243 && kind != 3443) return fail("tlfea_ancf_b12_matrix: kind must be 3243 or 3443");
+  if (!out_colmajor) return fail("tlfea_ancf_b12_matrix: null output");
+  if (!ancf::B_inv(kind == 3243 ? 8 : 16, L, W, out_colmajor)) return fail("tlfea_ancf_b12_matrix: singular B matrix");
+  return 0;
+}
+
 extern "C" int tlfea_elem_dims(tlfea_t10_t h, int* S, int* Q) {
   if (!h) return fail("null handle");
   *S = h->S;

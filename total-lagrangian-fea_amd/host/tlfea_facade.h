@@ -226,6 +226,56 @@ class GridMeshGenerator {
   std::vector<std::pair<int, int>> elems_;
 };
 
+// ANCF3243_B12_matrix / ANCF3443_B12_matrix and their per-element packers (cpu_utils.cc:125-209, 211-441): (B^T)^-1
+inline void ANCF_B12_matrix_impl(int kind, double L, double W, double H, tlfea::MatrixXd& B_inv_out, int n_shape) {
+  if (n_shape != (kind == 3243 ? 8 : 16)) throw std::invalid_argument("ANCF B12 matrix: n_shape does not fit the element");
+  B_inv_out.resize(n_shape, n_shape);
+  TLFEA_HANDLE_ERROR(tlfea_ancf_b12_matrix(kind, L, W, H, B_inv_out.data()));
+}
+inline void ANCF3243_B12_matrix(double L, double W, double H, tlfea::MatrixXd& B_inv_out, int n_shape) {
+  ANCF_B12_matrix_impl(3243, L, W, H, B_inv_out, n_shape);
+}
+inline void ANCF3443_B12_matrix(double L, double W, double H, tlfea::MatrixXd& B_inv_out, int n_shape) {
+  ANCF_B12_matrix_impl(3443, L, W, H, B_inv_out, n_shape);
+}
+inline void ANCF_B12_flat_impl(int kind, const tlfea::VectorXd& L, const tlfea::VectorXd& W, const tlfea::VectorXd& H,
+                               tlfea::VectorXd& B_inv_flat_out, int n_shape) {
+  if (W.size() != L.size() || H.size() != L.size()) throw std::invalid_argument("ANCF B12 flat: L, W, H sizes differ");
+  if (n_shape != (kind == 3243 ? 8 : 16)) throw std::invalid_argument("ANCF B12 flat: n_shape does not fit the element");
+  B_inv_flat_out.resize(L.size() * n_shape * n_shape);
+  for (int e = 0; e < L.size(); e++)
+    TLFEA_HANDLE_ERROR(tlfea_ancf_b12_matrix(kind, L(e), W(e), H(e), B_inv_flat_out.data() + (size_t)e * n_shape * n_shape));
+}
+inline void ANCF3243_B12_matrix_flat_per_element(const tlfea::VectorXd& L, const tlfea::VectorXd& W,
+                                                 const tlfea::VectorXd& H, tlfea::VectorXd& out, int n_shape) {
+  ANCF_B12_flat_impl(3243, L, W, H, out, n_shape);
+}
+inline void ANCF3443_B12_matrix_flat_per_element(const tlfea::VectorXd& L, const tlfea::VectorXd& W,
+                                                 const tlfea::VectorXd& H, tlfea::VectorXd& out, int n_shape) {
+  ANCF_B12_flat_impl(3443, L, W, H, out, n_shape);
+}
+
+// ANCF3243_generate_beam_coordinates (cpu_utils.cc:443-474): chain of n_beam beams of length 2 along x; x12/y12/z12
+// must already hold 4 * (n_beam + 1) entries, as in the reference
+inline void ANCF3243_generate_beam_coordinates(int n_beam, tlfea::VectorXd& x12, tlfea::VectorXd& y12,
+                                               tlfea::VectorXd& z12) {
+  for (int n = 0; n <= n_beam; n++) {
+    const int b = 4 * n;
+    x12(b) = -1.0 + 2.0 * n; x12(b + 1) = 1.0; x12(b + 2) = 0.0; x12(b + 3) = 0.0;
+    y12(b) = 1.0; y12(b + 1) = 0.0; y12(b + 2) = 1.0; y12(b + 3) = 0.0;
+    z12(b) = 0.0; z12(b + 1) = 0.0; z12(b + 2) = 0.0; z12(b + 3) = 1.0;
+  }
+}
+// ANCF3243_calculate_offsets (cpu_utils.cc:597-605; pinned by lib_utest/utest_utils.cc:32-108)
+inline void ANCF3243_calculate_offsets(int n_beam, tlfea::VectorXi& offset_start, tlfea::VectorXi& offset_end) {
+  offset_start.resize(n_beam);
+  offset_end.resize(n_beam);
+  for (int i = 0; i < n_beam; i++) {
+    offset_start(i) = 4 * i;
+    offset_end(i) = 4 * i + 7;
+  }
+}
+
 // ANCF3443_generate_beam_coordinates (cpu_utils.cc:476-595)
 inline void ANCF3443_generate_beam_coordinates(int n_beam, tlfea::VectorXd& x12, tlfea::VectorXd& y12,
                                                tlfea::VectorXd& z12, tlfea::MatrixXi& conn) {

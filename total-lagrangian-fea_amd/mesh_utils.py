@@ -155,6 +155,49 @@ def ANCF3443_generate_beam_coordinates(n_beam):
     return x, y, z, conn
 
 
+def _b12(kind, L, W, H):
+    import ctypes as C
+
+    from . import binding
+    S = 8 if kind == 3243 else 16
+    out = np.zeros(S * S)
+    binding.check(binding.load_library().tlfea_ancf_b12_matrix(kind, C.c_double(L), C.c_double(W), C.c_double(H),
+                                                               binding.dp(out)))
+    return out
+
+
+def ANCF3243_B12_matrix(L, W, H):
+    """(B^T)^-1 of one beam as an 8 x 8 matrix (cpu_utils.cc:125-188); host arithmetic of the C-ABI, no GPU"""
+    return _b12(3243, L, W, H).reshape(8, 8).T.copy()
+
+
+def ANCF3443_B12_matrix(L, W, H):
+    """(B^T)^-1 of one shell as a 16 x 16 matrix (cpu_utils.cc:211-420)"""
+    return _b12(3443, L, W, H).reshape(16, 16).T.copy()
+
+
+def ANCF3243_B12_matrix_flat_per_element(L, W, H):
+    """column-major 8 x 8 blocks, one per element (cpu_utils.cc:190-209)"""
+    return np.concatenate([_b12(3243, l, w, h) for l, w, h in zip(L, W, H)])
+
+
+def ANCF3443_B12_matrix_flat_per_element(L, W, H):
+    """column-major 16 x 16 blocks, one per element (cpu_utils.cc:422-441)"""
+    return np.concatenate([_b12(3443, l, w, h) for l, w, h in zip(L, W, H)])
+
+
+def ANCF3243_generate_beam_coordinates(n_beam):
+    """Chain of n_beam beams of length 2 along x (cpu_utils.cc:443-474) -> (x12, y12, z12), 4 (n_beam + 1) each"""
+    n = n_beam + 1
+    x, y, z = np.zeros(4 * n), np.zeros(4 * n), np.zeros(4 * n)
+    x[0::4] = -1.0 + 2.0 * np.arange(n)
+    x[1::4] = 1.0
+    y[0::4] = 1.0
+    y[2::4] = 1.0
+    z[3::4] = 1.0
+    return x, y, z
+
+
 def ANCF3243_calculate_offsets(n_beam):
     """cpu_utils.cc:597-605"""
     start = np.arange(n_beam, dtype=np.int32) * 4
