@@ -121,3 +121,27 @@ def test_cpp_ancf3243_driver_adamw(tmp_path):
     assert np.isfinite(np.loadtxt(csv, delimiter=",", skiprows=1)).all()
     bad = subprocess.run([drv, "--solver=vbd"], capture_output=True, text=True)
     assert bad.returncode == 1 and "Invalid --solver" in bad.stderr
+
+
+UTEST = os.path.join(ROOT, "total-lagrangian-fea_amd", "host", "utest_facade")
+
+
+def test_cpp_facade_host_utilities_known_answers():
+    """Host-only part of host/utest_facade.cc (lib_utest/utest_utils.cc KATs + B12 matrices through the facade): runs
+    without a GPU, after which the program stops with its "No HIP device" status when none is visible."""
+    subprocess.check_call(["make", "-C", os.path.dirname(DRIVER)])
+    out = subprocess.run([UTEST, f"--data_dir={MESHES}"], capture_output=True, text=True, timeout=300)
+    assert out.stdout.count("[ OK ]") >= 15 and "[FAIL]" not in out.stdout, out.stdout + out.stderr
+    assert out.returncode in (0, 101)
+
+
+@pytest.mark.gpu
+def test_cpp_facade_reference_unit_tests():
+    """lib_utest/utest_3243.cc mass-matrix known answers (2 and 3 beams vs the reference's CSV fixtures, 1e-4), the
+    3443 strip flow of utest_sparse_mass.cc and the per-kind sizes of the Retrieve* members, all through the facade."""
+    if not os.path.exists(UTEST):
+        subprocess.check_call(["make", "-C", os.path.dirname(DRIVER)])
+    out = subprocess.run([UTEST, f"--data_dir={MESHES}", "--print_dsdu"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "[FAIL]" not in out.stdout and out.stdout.count("[ OK ]") >= 36
+    assert "=== Elem 0 Quadrature Point 11 detJ_ref=0.25 ===" in out.stdout and "Shape 7: " in out.stdout

@@ -591,6 +591,8 @@ inline bool ReadANCF3443MeshFromFile(const std::string& path, ANCF3443Mesh& out,
 }
 }  // namespace ANCFCPUUtils
 
+#include "tlfea_mesh_manager.h"
+
 enum ElementType { TYPE_3243, TYPE_3443, TYPE_T10 };  // ElementBase.h:20
 
 class ElementBase {  // ElementBase.h:22-50 (host-side virtuals only)
@@ -683,21 +685,26 @@ struct GPU_FEAT10_Data : public ElementBase {
   }
   void RetrievePFromFToCPU(std::vector<std::vector<tlfea::MatrixXd>>& P) { retrieve33(P, true); }
   void RetrieveDeformationGradientToCPU(std::vector<std::vector<tlfea::MatrixXd>>& F) { retrieve33(F, false); }
+  // sizes follow the element kind behind the handle (tlfea_elem_dims): T10 S = 10, Q = 5; 3243 8, 12; 3443 16, 48
   void RetrieveDnDuPreToCPU(std::vector<std::vector<tlfea::MatrixXd>>& g) {
-    std::vector<double> flat(static_cast<size_t>(n_elem) * 150);
+    int S = 0, Q = 0;
+    TLFEA_HANDLE_ERROR(tlfea_elem_dims(h, &S, &Q));
+    std::vector<double> flat(static_cast<size_t>(n_elem) * Q * 3 * S);
     TLFEA_HANDLE_ERROR(tlfea_t10_retrieve_dndu_pre(h, flat.data()));
-    g.assign(n_elem, std::vector<tlfea::MatrixXd>(5));
+    g.assign(n_elem, std::vector<tlfea::MatrixXd>(Q));
     for (int e = 0; e < n_elem; e++)
-      for (int q = 0; q < 5; q++) {
-        g[e][q].resize(10, 3);
-        std::copy_n(flat.data() + (static_cast<size_t>(e) * 5 + q) * 30, 30, g[e][q].data());
+      for (int q = 0; q < Q; q++) {
+        g[e][q].resize(S, 3);
+        std::copy_n(flat.data() + (static_cast<size_t>(e) * Q + q) * 3 * S, 3 * S, g[e][q].data());
       }
   }
   void RetrieveDetJToCPU(std::vector<std::vector<double>>& detJ) {
-    std::vector<double> flat(static_cast<size_t>(n_elem) * 5);
+    int S = 0, Q = 0;
+    TLFEA_HANDLE_ERROR(tlfea_elem_dims(h, &S, &Q));
+    std::vector<double> flat(static_cast<size_t>(n_elem) * Q);
     TLFEA_HANDLE_ERROR(tlfea_t10_retrieve_detj(h, flat.data()));
-    detJ.assign(n_elem, std::vector<double>(5));
-    for (int e = 0; e < n_elem; e++) std::copy_n(flat.data() + 5 * e, 5, detJ[e].data());
+    detJ.assign(n_elem, std::vector<double>(Q));
+    for (int e = 0; e < n_elem; e++) std::copy_n(flat.data() + static_cast<size_t>(Q) * e, Q, detJ[e].data());
   }
   void RetrieveConnectivityToCPU(tlfea::MatrixXi& connectivity) {
     connectivity.resize(n_elem, 10);
@@ -723,14 +730,16 @@ struct GPU_FEAT10_Data : public ElementBase {
 
  private:
   void retrieve33(std::vector<std::vector<tlfea::MatrixXd>>& out, bool P) {
-    std::vector<double> flat(static_cast<size_t>(n_elem) * 45);
+    int S = 0, Q = 0;
+    TLFEA_HANDLE_ERROR(tlfea_elem_dims(h, &S, &Q));
+    std::vector<double> flat(static_cast<size_t>(n_elem) * Q * 9);
     TLFEA_HANDLE_ERROR(P ? tlfea_t10_retrieve_p_from_f(h, flat.data())
                          : tlfea_t10_retrieve_deformation_gradient(h, flat.data()));
-    out.assign(n_elem, std::vector<tlfea::MatrixXd>(5));
+    out.assign(n_elem, std::vector<tlfea::MatrixXd>(Q));
     for (int e = 0; e < n_elem; e++)
-      for (int q = 0; q < 5; q++) {
+      for (int q = 0; q < Q; q++) {
         out[e][q].resize(3, 3);
-        std::copy_n(flat.data() + (static_cast<size_t>(e) * 5 + q) * 9, 9, out[e][q].data());
+        std::copy_n(flat.data() + (static_cast<size_t>(e) * Q + q) * 9, 9, out[e][q].data());
       }
   }
 };
@@ -771,6 +780,38 @@ struct GPU_ANCF_DataBase : public GPU_FEAT10_Data {
     n_constraint = tlfea_t10_get_n_constraint(h);
   }
   int GetConstraintMode() const { return tlfea_t10_get_constraint_mode(h); }
+  // element connectivity in NODE ids, n_beam x (2 | 4) (ANCF3243Data.cu:630-642, ANCF3443Data.cu:597-603); the handle
+  // keeps coefficient ids [S][E] (slot 0 of node n of the element = 4 * node)
+  void RetrieveConnectivityToCPU(tlfea::MatrixXi& connectivity) {
+    int S = 0, Q = 0;
+    TLFEA_HANDLE_ERROR(tlfea_elem_dims(h, &S, &Q));
+    std::vector<int> coef(static_cast<size_t>(S) * n_elem);
+    TLFEA_HANDLE_ERROR(tlfea_t10_retrieve_connectivity(h, coef.data()));
+    connectivity.resize(n_elem, S / 4);
+    for (int e = 0; e < n_elem; e++)
+      for (int n = 0; n < S / 4; n++) connectivity(e, n) = coef[static_cast<size_t>(4 * n) * n_elem + e] / 4;
+  }
+  // PrintDsDuPre (ANCF3243Data.cu:326-360, ANCF3443Data.cu same member): same text layout
+  void PrintDsDuPre() {
+    std::vector<std::vector<tlfea::MatrixXd>> g;
+    std::vector<std::vector<double>> dj;
+    RetrieveDnDuPreToCPU(g);
+    RetrieveDetJToCPU(dj);
+    char buf[64];
+    for (int e = 0; e < n_elem; e++)
+      for (size_t q = 0; q < g[e].size(); q++) {
+        std::cout << "\n=== Elem " << e << " Quadrature Point " << q << " detJ_ref=" << dj[e][q] << " ===" << std::endl;
+        std::cout << "        dN/dx       dN/dy       dN/dz" << std::endl;
+        for (int i = 0; i < g[e][q].rows(); i++) {
+          std::cout << "Shape " << i << ": ";
+          for (int j = 0; j < 3; j++) {
+            std::snprintf(buf, sizeof buf, "%10.6f ", g[e][q](i, j));
+            std::cout << buf;
+          }
+          std::cout << std::endl;
+        }
+      }
+  }
   void RetrieveConstraintJacobianCSRToCPU(std::vector<int>& offsets, std::vector<int>& columns,
                                           std::vector<double>& values) {
     const int nnz = tlfea_t10_constraint_jac_nnz(h);
@@ -828,6 +869,8 @@ struct GPU_ANCF3243_Data : public GPU_ANCF_DataBase {
 
 struct GPU_ANCF3443_Data : public GPU_ANCF_DataBase {
   GPU_ANCF3443_Data(int n_nodes, int n_elements) : GPU_ANCF_DataBase(3443, TYPE_3443, n_nodes, n_elements) {}
+  // strip constructor: every new element of the chain brings 2 new nodes (ANCF3443Data.cuh:445-449)
+  explicit GPU_ANCF3443_Data(int num_beams) : GPU_ANCF_DataBase(3443, TYPE_3443, 4 + 2 * (num_beams - 1), num_beams) {}
   // ANCF3443Data.cuh:532-542
   void Setup(const tlfea::VectorXd& length, const tlfea::VectorXd& width, const tlfea::VectorXd& height,
              const tlfea::VectorXd& gauss_xi_m, const tlfea::VectorXd& gauss_eta_m, const tlfea::VectorXd& gauss_zeta_m,
