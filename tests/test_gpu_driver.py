@@ -54,9 +54,13 @@ def test_cpp_ancf3243_cantilever_config_a(tmp_path):
     if not os.path.exists(drv):
         subprocess.check_call(["make", "-C", os.path.dirname(DRIVER)])
     csv = tmp_path / "tip.csv"
-    out = subprocess.run([drv, "--steps=4", "--dt=1e-3", f"--csv_path={csv}"], capture_output=True, text=True, timeout=300)
+    out = subprocess.run([drv, "--steps=4", "--dt=1e-3", f"--csv_path={csv}", f"--vtu={tmp_path}/vtu"], capture_output=True,
+                         text=True, timeout=300)
     assert out.returncode == 0, out.stderr
     assert open(csv).readline().strip() == "step,tip_z"
+    # --vtu: every 20th step -> only step 0 here, one hexahedron per beam (test_ancf3243.cc:46-47,302-318)
+    assert os.listdir(tmp_path / "vtu") == ["ancf3243_newton_000000.vtu"]
+    assert 'NumberOfPoints="240" NumberOfCells="30"' in open(tmp_path / "vtu" / "ancf3243_newton_000000.vtu").read()
     rows = np.loadtxt(csv, delimiter=",", skiprows=1)
     kind, x, y, z, conn, (L, W, H), fixed, f_ext = beam_problem(30)
     o = orc.AncfOracle(kind, x, y, z, conn, L, W, H, orc.svk(7e8, 0.33, rho0=2700.0, eta=1e5, lamd=1e5), fixed, f_ext)
@@ -126,22 +130,22 @@ def test_cpp_ancf3243_driver_adamw(tmp_path):
 UTEST = os.path.join(ROOT, "total-lagrangian-fea_amd", "host", "utest_facade")
 
 
-def test_cpp_facade_host_utilities_known_answers():
-    """Host-only part of host/utest_facade.cc (lib_utest/utest_utils.cc KATs + B12 matrices through the facade): runs
+def test_cpp_facade_host_utilities_known_answers(tmp_path):
+    """Host-only part of host/utest_facade.cc (lib_utest/utest_utils.cc KATs, B12 matrices, MeshManager, VTU exporters through the facade): runs
     without a GPU, after which the program stops with its "No HIP device" status when none is visible."""
     subprocess.check_call(["make", "-C", os.path.dirname(DRIVER)])
-    out = subprocess.run([UTEST, f"--data_dir={MESHES}"], capture_output=True, text=True, timeout=300)
-    assert out.stdout.count("[ OK ]") >= 15 and "[FAIL]" not in out.stdout, out.stdout + out.stderr
+    out = subprocess.run([UTEST, f"--data_dir={MESHES}", f"--tmp_dir={tmp_path}"], capture_output=True, text=True, timeout=300)
+    assert out.stdout.count("[ OK ]") >= 18 and "[FAIL]" not in out.stdout, out.stdout + out.stderr
     assert out.returncode in (0, 101)
 
 
 @pytest.mark.gpu
-def test_cpp_facade_reference_unit_tests():
+def test_cpp_facade_reference_unit_tests(tmp_path):
     """lib_utest/utest_3243.cc mass-matrix known answers (2 and 3 beams vs the reference's CSV fixtures, 1e-4), the
     3443 strip flow of utest_sparse_mass.cc and the per-kind sizes of the Retrieve* members, all through the facade."""
     if not os.path.exists(UTEST):
         subprocess.check_call(["make", "-C", os.path.dirname(DRIVER)])
-    out = subprocess.run([UTEST, f"--data_dir={MESHES}", "--print_dsdu"], capture_output=True, text=True, timeout=300)
+    out = subprocess.run([UTEST, f"--data_dir={MESHES}", f"--tmp_dir={tmp_path}", "--print_dsdu"], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
-    assert "[FAIL]" not in out.stdout and out.stdout.count("[ OK ]") >= 36
+    assert "[FAIL]" not in out.stdout and out.stdout.count("[ OK ]") >= 39
     assert "=== Elem 0 Quadrature Point 11 detJ_ref=0.25 ===" in out.stdout and "Shape 7: " in out.stdout

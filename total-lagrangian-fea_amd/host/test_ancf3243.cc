@@ -1,7 +1,9 @@
 // test_ancf3243 -- the reference's ANCF-3243 cantilever driver (lib_bin/beam_sag/test_ancf3243.cc:222-437, Newton
 // branch; BASELINE config A) on the MI355X engine: 30 beam elements L=0.5 W=H=0.1, coefficients 0-3 pinned, tip
 // force Fz=3100 N, Kelvin-Voigt damping 1e5/1e5, params {1e-4,0,1e-6,1e14,5,10,dt}; CSV schema `step,tip_z`.
-//   ./test_ancf3243 --steps=50 --dt=1e-3 [--n_elements=30] [--tip_force_z=3100] [--csv_path=out.csv]
+//   ./test_ancf3243 --steps=50 --dt=1e-3 [--n_elements=30] [--tip_force_z=3100] [--csv_path=out.csv] [--vtu[=DIR]]
+// --vtu writes one hexahedron per beam every 20 steps to output/ancf3243/ancf3243_<solver>_<step>.vtu (:46-47,237-239,302-318)
+#include <filesystem>
 #include <iomanip>
 #include <limits>
 #include <memory>
@@ -17,7 +19,7 @@ bool StartsWith(const std::string& s, const std::string& p) { return s.rfind(p, 
 int main(int argc, char** argv) {
   int steps = 50, n_elements = 30;
   double dt = 1e-3, tip_fz = kTipFz;
-  std::string csv_path, solver_kind = "newton";
+  std::string csv_path, solver_kind = "newton", vtu_dir;
   for (int i = 1; i < argc; i++) {
     const std::string a = argv[i];
     if (StartsWith(a, "--steps=")) steps = std::atoi(a.c_str() + 8);
@@ -26,6 +28,8 @@ int main(int argc, char** argv) {
     else if (StartsWith(a, "--tip_force_z=")) tip_fz = std::atof(a.c_str() + 14);
     else if (StartsWith(a, "--csv_path=")) csv_path = a.substr(11);
     else if (a == "--csv") csv_path = "tip_z_history_ancf3243_newton.csv";
+    else if (a == "--vtu") vtu_dir = "output/ancf3243";
+    else if (StartsWith(a, "--vtu=")) vtu_dir = a.substr(6);
     else if (StartsWith(a, "--solver=")) {
       solver_kind = a.substr(9);
       if (solver_kind != "newton" && solver_kind != "adamw" && solver_kind != "nesterov") {
@@ -92,10 +96,22 @@ int main(int argc, char** argv) {
   }
   SolverBase& solver = *solver_ptr;
   std::vector<double> tip_z;
+  constexpr int kVtuEvery = 20;
+  auto write_vtu = [&](int step, const tlfea::VectorXd& x, const tlfea::VectorXd& y, const tlfea::VectorXd& z) {
+    if (vtu_dir.empty() || step % kVtuEvery != 0) return;
+    std::ostringstream name;
+    name << vtu_dir << "/ancf3243_" << solver_kind << "_" << std::setw(6) << std::setfill('0') << step << ".vtu";
+    ANCFCPUUtils::VisualizationUtils::ExportANCF3243ToVTU(x, y, z, conn, kW, kH, name.str());
+  };
+  if (!vtu_dir.empty()) {
+    std::filesystem::create_directories(vtu_dir);
+    write_vtu(0, h_x12, h_y12, h_z12);
+  }
   for (int step = 0; step < steps; ++step) {
     solver.Solve();
     tlfea::VectorXd x, y, z;
     data.RetrievePositionToCPU(x, y, z);
+    write_vtu(step + 1, x, y, z);
     tip_z.push_back(z(tip_coef));
     std::cout << "Step " << step + 1 << ": tip z = " << std::setprecision(17) << z(tip_coef) << std::endl;
   }

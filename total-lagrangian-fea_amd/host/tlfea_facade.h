@@ -592,6 +592,7 @@ inline bool ReadANCF3443MeshFromFile(const std::string& path, ANCF3443Mesh& out,
 }  // namespace ANCFCPUUtils
 
 #include "tlfea_mesh_manager.h"
+#include "tlfea_visualization.h"
 
 enum ElementType { TYPE_3243, TYPE_3443, TYPE_T10 };  // ElementBase.h:20
 

@@ -209,6 +209,76 @@ void strip_3443() {
   check(c.size() == 24 && cmax == 0.0, "3443 strip: 24 satisfied constraints (8 fixed coefficients)");
   data.Destroy();
 }
+// visualization_utils.h:491-1097: the VTU files the drivers write (host only): point / cell counts and corner geometry
+std::vector<double> vtu_points(const std::string& path, int* n_points, int* n_cells) {
+  std::ifstream f(path);
+  std::string line;
+  std::vector<double> pts;
+  bool in_points = false;
+  *n_points = *n_cells = -1;
+  while (std::getline(f, line)) {
+    const size_t a = line.find("NumberOfPoints=\"");
+    if (a != std::string::npos) {
+      *n_points = std::atoi(line.c_str() + a + 16);
+      *n_cells = std::atoi(line.c_str() + line.find("NumberOfCells=\"") + 15);
+    }
+    if (line.find("<Points>") != std::string::npos) in_points = true;
+    else if (line.find("</Points>") != std::string::npos) in_points = false;
+    else if (in_points && line.find('<') == std::string::npos) {
+      std::stringstream ss(line);
+      double v;
+      while (ss >> v) pts.push_back(v);
+    }
+  }
+  return pts;
+}
+
+void vtu_known_answers(const std::string& tmp) {
+  // one straight beam from (0,0,0) to (2,0,0), width 0.2 (along t x z = -y), height 0.1 (along t x n = -z... sign below)
+  tlfea::VectorXd x(8), y(8), z(8);
+  x(4) = 2.0;
+  tlfea::MatrixXi conn(1, 2);
+  conn(0, 1) = 1;
+  const std::string fb = tmp + "/utest_beam.vtu";
+  int np = 0, nc = 0;
+  bool ok = ANCFCPUUtils::VisualizationUtils::ExportANCF3243ToVTU(x, y, z, conn, 0.2, 0.1, fb);
+  std::vector<double> p = vtu_points(fb, &np, &nc);
+  ok = ok && np == 8 && nc == 1 && p.size() == 24;
+  // t = x, n = t x z = -y, b = t x n = -z: corner 0 = p0 - W/2 n - H/2 b = (0, +0.1, +0.05)
+  ok = ok && std::fabs(p[0]) < 1e-15 && std::fabs(p[1] - 0.1) < 1e-15 && std::fabs(p[2] - 0.05) < 1e-15 &&
+       std::fabs(p[12] - 2.0) < 1e-15 && std::fabs(p[3 * 6 + 1] + 0.1) < 1e-15 && std::fabs(p[3 * 6 + 2] + 0.05) < 1e-15;
+  check(ok, "ExportANCF3243ToVTU: 8 points / 1 hexahedron, cross-section frame of a beam along x");
+  // one flat shell in the z = 0 plane, thickness 0.1: bottom face at z = -0.05 first, then top
+  tlfea::VectorXd sx, sy, sz;
+  tlfea::MatrixXi sc;
+  ANCFCPUUtils::ANCF3443_generate_beam_coordinates(2, sx, sy, sz, sc);
+  const std::string fs = tmp + "/utest_shell.vtu";
+  ok = ANCFCPUUtils::VisualizationUtils::ExportANCF3443ToVTU(sx, sy, sz, sc, 0.1, fs);
+  p = vtu_points(fs, &np, &nc);
+  ok = ok && np == 16 && nc == 2 && p.size() == 48;
+  for (int k = 0; ok && k < 4; k++) ok = std::fabs(p[3 * k + 2] + 0.05) < 1e-15 && std::fabs(p[3 * (4 + k) + 2] - 0.05) < 1e-15;
+  ok = ok && p[3 * 1] == 2.0 && p[3 * 2 + 1] == 1.0 && p[3 * 9] == 4.0;  // element 1 = nodes (1,4,5,2): second corner x = 4
+  check(ok, "ExportANCF3443ToVTU: 16 points / 2 hexahedra, bottom face then top face along the element normal");
+  tlfea::MatrixXd nodes(5, 3);
+  nodes(1, 0) = nodes(2, 1) = nodes(3, 2) = 1.0;
+  nodes(4, 0) = 0.5;
+  tlfea::MatrixXi tet(1, 10);
+  for (int k = 0; k < 4; k++) tet(0, k) = k;
+  tlfea::VectorXd disp(15), field(5);
+  disp(3) = 3.0; disp(4) = 4.0;
+  const std::string fd = tmp + "/utest_disp.vtu", fm = tmp + "/utest_mesh.vtu";
+  ok = ANCFCPUUtils::VisualizationUtils::ExportMeshWithDisplacement(nodes, tet, disp, fd) &&
+       ANCFCPUUtils::VisualizationUtils::ExportMeshToVTU(nodes, tet, field, fm);
+  std::ifstream f(fd);
+  std::stringstream all;
+  all << f.rdbuf();
+  const std::string txt = all.str();
+  ok = ok && txt.find("Scalars=\"displacement_magnitude\" Vectors=\"displacement\"") != std::string::npos &&
+       txt.find("5.000000000000000e+00") != std::string::npos && txt.find("          10\n") != std::string::npos;
+  vtu_points(fm, &np, &nc);
+  check(ok && np == 5 && nc == 1, "ExportMeshWithDisplacement / ExportMeshToVTU: corner tets, |(3,4,0)| = 5 at node 1");
+}
+
 // mesh_manager.cc:180-220, 443-570 semantics (host only)
 void mesh_manager_known_answers(const std::string& d) {
   ANCFCPUUtils::MeshManager mm;
@@ -312,11 +382,12 @@ void two_bodies_one_system(const std::string& d) {
 }  // namespace
 
 int main(int argc, char** argv) {
-  std::string data_dir = ".";
+  std::string data_dir = ".", tmp_dir = "/tmp";
   bool print = false;
   for (int i = 1; i < argc; i++) {
     const std::string a = argv[i];
     if (a.rfind("--data_dir=", 0) == 0) data_dir = a.substr(11);
+    else if (a.rfind("--tmp_dir=", 0) == 0) tmp_dir = a.substr(10);
     else if (a == "--print_dsdu") print = true;
     else {
       std::cerr << "Unknown argument: " << a << std::endl;
@@ -325,6 +396,7 @@ int main(int argc, char** argv) {
   }
   utils_known_answers();  // host-only
   mesh_manager_known_answers(data_dir);
+  vtu_known_answers(tmp_dir);
   if (tlfea_device_count() <= 0) {
     std::cerr << "No HIP device visible" << std::endl;
     return 101;
