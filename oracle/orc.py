@@ -119,7 +119,56 @@ def keast5():
     return qx, qy, qz, qw
 
 
-class T10Oracle:
+class VbdParams(C.Structure):  # SyncedVBDParams (SyncedVBD.cuh:13-21)
+    _fields_ = [("inner_tol", C.c_double), ("inner_rtol", C.c_double), ("outer_tol", C.c_double), ("rho", C.c_double),
+                ("max_outer", C.c_int), ("max_inner", C.c_int), ("time_step", C.c_double), ("omega", C.c_double),
+                ("hess_eps", C.c_double), ("convergence_check_interval", C.c_int), ("color_group_size", C.c_int)]
+
+
+class VbdMixin:
+    """SyncedVBDSolver on either oracle object (T10Oracle: S = 10, Q = 5)."""
+
+    def _sq(self):
+        return getattr(self, "S", 10), getattr(self, "Q", 5)
+
+    def vbd_coloring(self, group_size=1):
+        """InitializeColoring (SyncedVBD.cu:764-1028): colors, color_offsets, color_nodes, group_offsets, group_colors"""
+        S, _ = self._sq()
+        colors = np.zeros(self.N, dtype=np.int32)
+        nc = self.L.orc_vbd_coloring(S, self.E, self.N, ip(self.conn_cm), ip(colors))
+        assert self.L.orc_vbd_validate_coloring(S, self.E, ip(self.conn_cm), ip(colors)) == 1
+        order = np.argsort(colors, kind="stable").astype(np.int32)  # BuildColorToNodes: ascending node id per color
+        offsets = np.concatenate([[0], np.cumsum(np.bincount(colors, minlength=nc))]).astype(np.int32)
+        g_off, g_col = np.zeros(nc + 1, dtype=np.int32), np.zeros(nc, dtype=np.int32)
+        ng = self.L.orc_vbd_color_groups(S, self.E, ip(self.conn_cm), ip(colors), nc, max(1, group_size), ip(g_off), ip(g_col))
+        self.vbd = dict(colors=colors, n_colors=nc, color_offsets=offsets, color_nodes=order, n_groups=ng,
+                        group_offsets=g_off[:ng + 1].copy(), group_colors=g_col)
+        return self.vbd
+
+    def vbd_node_terms(self, h, v=None):
+        """per node: sum of cached P h_a dV (3) and h * sum K_aa (3 x 3) over the incident elements"""
+        S, Q = self._sq()
+        r, K = np.zeros(3 * self.N), np.zeros(9 * self.N)
+        self.L.orc_gen_vbd_node_terms(S, Q, self.E, self.N, ip(self.conn_cm), dp(self.x), dp(self.y), dp(self.z),
+                                      dp(v) if v is not None else None, dp(self.gradN), dp(self.detJ), dp(self.qw),
+                                      C.byref(self.mat), C.c_double(h), dp(r), dp(K))
+        return r.reshape(-1, 3), K.reshape(-1, 3, 3)
+
+    def vbd_step(self, prm):
+        """SyncedVBDSolver::OneStepVBD; needs vbd_coloring(prm.color_group_size) first"""
+        S, Q = self._sq()
+        c = self.vbd
+        stats = np.zeros(4)
+        self.L.orc_gen_vbd_step(
+            S, Q, self.E, self.N, ip(self.conn_cm), dp(self.x), dp(self.y), dp(self.z), dp(self.xt), dp(self.yt),
+            dp(self.zt), dp(self.gradN), dp(self.detJ), dp(self.qw), C.byref(self.mat), ip(self.m_off), ip(self.m_col),
+            dp(self.m_val), ip(self.fixed), len(self.fixed), dp(self.f_ext), C.byref(prm), c["n_colors"],
+            ip(c["color_offsets"]), ip(c["color_nodes"]), c["n_groups"], ip(c["group_offsets"]), ip(c["group_colors"]),
+            dp(self.v), dp(self.v_prev), dp(self.lam), dp(stats))
+        return stats
+
+
+class T10Oracle(VbdMixin):
     """Host-side mirror of the GPU_FEAT10_Data call sequence on the oracle (one object = one mesh)."""
 
     def __init__(self, X, conn, mat, fixed=None, f_ext=None):
@@ -262,7 +311,7 @@ class NesterovParams(C.Structure):  # SyncedNesterovParams (SyncedNesterov.cuh:2
                 ("max_outer", C.c_int), ("max_inner", C.c_int), ("time_step", C.c_double)]
 
 
-class ElemOracle:
+class ElemOracle(VbdMixin):
     """Element-type-generic oracle object (S shape functions, Q points); the ANCF subclasses fill gradN/detJ."""
 
     def __init__(self, S, Q, x, y, z, conn_coef, qw, mat, fixed=None, f_ext=None):

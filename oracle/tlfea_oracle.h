@@ -143,6 +143,28 @@ int orc_gen_newton_step_lin(int S, int Q, int E, int N, const int *conn, double 
                             const double *jval, const double *rhs, const double *f_ext,
                             const orc_newton_params *prm, double *v, double *v_prev, double *lam, double *stats);
 
+/* ---- SyncedVBDSolver (SyncedVBD.cuh:13-21 parameter order) ---- */
+typedef struct {
+  double inner_tol, inner_rtol, outer_tol, rho;
+  int max_outer, max_inner;
+  double time_step, omega, hess_eps;
+  int convergence_check_interval, color_group_size;
+} orc_vbd_params;
+void orc_gen_vbd_node_terms(int S, int Q, int E, int N, const int *conn, const double *x, const double *y, const double *z,
+                            const double *v, const double *gradN, const double *detJ, const double *qw,
+                            const orc_material *mat, double h, double *r_out, double *K_out);
+int orc_gen_vbd_step(int S, int Q, int E, int N, const int *conn, double *x, double *y, double *z, const double *xt,
+                     const double *yt, const double *zt, const double *gradN, const double *detJ, const double *qw,
+                     const orc_material *mat, const int *mo, const int *mc, const double *mv, const int *fixed,
+                     int n_fixed, const double *f_ext, const orc_vbd_params *prm, int n_colors, const int *color_offsets,
+                     const int *color_nodes, int n_groups, const int *group_offsets, const int *group_colors, double *v,
+                     double *v_prev, double *lam, double *stats);
+/* tlfea_oracle_coloring.cc (C++: the reference orders nodes with std::sort, whose tie order is the library's) */
+int orc_vbd_coloring(int S, int E, int N, const int *conn, int *colors);
+int orc_vbd_validate_coloring(int S, int E, const int *conn, const int *colors);
+int orc_vbd_color_groups(int S, int E, const int *conn, const int *colors, int n_colors, int group_size,
+                         int *group_offsets, int *group_colors);
+
 #ifdef __cplusplus
 }
 #endif

@@ -291,6 +291,21 @@ void orc_gen_internal_force(int S, int Q, int E, int N, const int *conn, const d
     }
 }
 
+/* A = dP/dF of compressible Mooney-Rivlin (MooneyRivlin.cuh:113-225) */
+static void mr_tangent_tensor(const double F[3][3], const orc_material *mat, double A[3][3][3][3]) {
+  mrs s; mr_pro(F, mat, &s);
+  double T1[3][3], T2[3][3];
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { T1[i][j] = F[i][j] - (s.I1 / 3.0) * s.G[i][j]; T2[i][j] = s.I1 * F[i][j] - s.FC[i][j] - (2.0 * s.I2 / 3.0) * s.G[i][j]; }
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) for (int k = 0; k < 3; k++) for (int l = 0; l < 3; l++) {
+    double dik = i == k, djl = j == l, dG = -s.G[i][l] * s.G[k][j];
+    double dt1 = (-2.0 / 3.0) * s.t1 * s.G[k][l], dt2 = (-4.0 / 3.0) * s.t2 * s.G[k][l], dt3 = mat->kappa * (2.0 * s.J - 1.0) * s.J * s.G[k][l];
+    double dT1 = dik * djl - (2.0 / 3.0) * F[k][l] * s.G[i][j] + (s.I1 / 3.0) * s.G[i][l] * s.G[k][j];
+    double dT2 = 2.0 * F[k][l] * F[i][j] + s.I1 * dik * djl - (dik * s.C[l][j] + F[i][l] * F[k][j] + djl * s.FFT[i][k]) -
+                 (4.0 / 3.0) * (s.I1 * F[k][l] - s.FC[k][l]) * s.G[i][j] + (2.0 * s.I2 / 3.0) * s.G[i][l] * s.G[k][j];
+    A[i][j][k][l] = dt1 * T1[i][j] + s.t1 * dT1 + dt2 * T2[i][j] + s.t2 * dT2 + dt3 * s.G[i][j] + s.t3 * dG;
+  }
+}
+
 /* K_e and C_e (row-major 3S x 3S) summed over the Q points: SVK.cuh:35-55 / MooneyRivlin.cuh:113-225 and the
  * Kelvin-Voigt block of ANCF3243DataFunc.cuh:842-915 (same expression as FEAT10DataFunc.cuh:695-762). */
 static void qp_tangent(int S, const double *xn /*[S][3]*/, const double *g, double dV, const orc_material *mat,
@@ -304,19 +319,7 @@ static void qp_tangent(int S, const double *xn /*[S][3]*/, const double *g, doub
   for (int a = 0; a < S; a++) for (int r = 0; r < 3; r++) { Fh[a][r] = 0; for (int c = 0; c < 3; c++) Fh[a][r] += F[r][c] * g[a + S * c]; }
   double A[3][3][3][3];
   const int use_mr = mat->model == ORC_MAT_MOONEY_RIVLIN;
-  if (use_mr) {
-    mrs s; mr_pro(F, mat, &s);
-    double T1[3][3], T2[3][3];
-    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { T1[i][j] = F[i][j] - (s.I1 / 3.0) * s.G[i][j]; T2[i][j] = s.I1 * F[i][j] - s.FC[i][j] - (2.0 * s.I2 / 3.0) * s.G[i][j]; }
-    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) for (int k = 0; k < 3; k++) for (int l = 0; l < 3; l++) {
-      double dik = i == k, djl = j == l, dG = -s.G[i][l] * s.G[k][j];
-      double dt1 = (-2.0 / 3.0) * s.t1 * s.G[k][l], dt2 = (-4.0 / 3.0) * s.t2 * s.G[k][l], dt3 = mat->kappa * (2.0 * s.J - 1.0) * s.J * s.G[k][l];
-      double dT1 = dik * djl - (2.0 / 3.0) * F[k][l] * s.G[i][j] + (s.I1 / 3.0) * s.G[i][l] * s.G[k][j];
-      double dT2 = 2.0 * F[k][l] * F[i][j] + s.I1 * dik * djl - (dik * s.C[l][j] + F[i][l] * F[k][j] + djl * s.FFT[i][k]) -
-                   (4.0 / 3.0) * (s.I1 * F[k][l] - s.FC[k][l]) * s.G[i][j] + (2.0 * s.I2 / 3.0) * s.G[i][l] * s.G[k][j];
-      A[i][j][k][l] = dt1 * T1[i][j] + s.t1 * dT1 + dt2 * T2[i][j] + s.t2 * dT2 + dt3 * s.G[i][j] + s.t3 * dG;
-    }
-  }
+  if (use_mr) mr_tangent_tensor(F, mat, A);
   for (int i = 0; i < S; i++)
     for (int j = 0; j < S; j++) {
       double hij = 0, ff = 0;
@@ -739,5 +742,178 @@ int orc_gen_nesterov_step(int S, int Q, int E, int N, const int *conn, double *x
   for (int i = 0; i < N; i++) { x[i] = xp[i] + dt * v[3 * i]; y[i] = xp[N + i] + dt * v[3 * i + 1]; z[i] = xp[2 * N + i] + dt * v[3 * i + 2]; }
   if (stats) { stats[0] = n_outer; stats[1] = n_inner; stats[2] = ng; stats[3] = ncn; stats[4] = inner_flag; }
   free(xp); free(P); free(f_int); free(g); free(vk); free(vkm1); free(vnext); free(c);
+  return 0;
+}
+
+/* =====================================================================================================
+ * SyncedVBDSolver (SyncedVBD.cu:47-82 solve, :163-377 node update, :1233-1412 sweep/post graphs, :1475-1641 step):
+ * ALM outer loop, inner loop of coloured Gauss-Seidel sweeps of per-node 3x3 Newton updates on the velocities.
+ * Restated as written: F/P cached per (element, point) and refreshed for ALL elements after every colour group;
+ * residual of node i = full mass row . (v - v_prev)/h + sum cached P h_a dV - f_ext (+ pin terms), Hessian = diagonal
+ * mass block / h + h * sum K_aa (elastic part only) (+ h^2 rho I on pinned nodes), symmetrised, + eps max(1, tr) I. */
+static void vbd_diag_block(const double F[3][3], const double ha[3], const orc_material *mat, double w, double K[3][3]) {
+  if (mat->model == ORC_MAT_MOONEY_RIVLIN) { /* FEAT10DataFunc.cuh:353-372 */
+    double A[3][3][3][3];
+    mr_tangent_tensor(F, mat, A);
+    for (int d = 0; d < 3; d++) for (int e = 0; e < 3; e++) {
+      double sum = 0.0;
+      for (int J = 0; J < 3; J++) for (int L = 0; L < 3; L++) sum += A[d][J][e][L] * ha[J] * ha[L];
+      K[d][e] = sum * w;
+    }
+    return;
+  }
+  double FFT[3][3] = {{0}}, Fh[3] = {0, 0, 0}, trC = 0.0; /* SVK.cuh:35-55 with i == j */
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { trC += F[i][j] * F[i][j]; Fh[i] += F[i][j] * ha[j]; for (int k = 0; k < 3; k++) FFT[i][j] += F[i][k] * F[j][k]; }
+  const double trE = 0.5 * (trC - 3.0), hij = ha[0] * ha[0] + ha[1] * ha[1] + ha[2] * ha[2], ff = Fh[0] * Fh[0] + Fh[1] * Fh[1] + Fh[2] * Fh[2];
+  for (int d = 0; d < 3; d++) for (int e = 0; e < 3; e++) {
+    const double dl = d == e;
+    K[d][e] = (mat->lambda * Fh[d] * Fh[e] + mat->lambda * trE * hij * dl + mat->mu * ff * dl + mat->mu * Fh[d] * Fh[e] +
+               mat->mu * hij * FFT[d][e] - mat->mu * hij * dl) * w;
+  }
+}
+
+/* element contributions of one node from the cached F/P (vbd_accumulate_residual_and_hessian_diag,
+ * FEAT10DataFunc.cuh:295-395 and the ANCF twins): r[3] += sum P h_a dV, Kd[3][3] += h * sum K_aa */
+static void vbd_node_elements(int S, int Q, int E, int node, const int *inc_off, const int *inc, const double *Fc,
+                              const double *Pc, const double *gradN, const double *detJ, const double *qw,
+                              const orc_material *mat, double h, double r[3], double Kd[3][3]) {
+  (void)E;
+  for (int k = inc_off[node]; k < inc_off[node + 1]; k++) {
+    const int e = inc[k] / S, a = inc[k] % S;
+    for (int q = 0; q < Q; q++) {
+      const double *g = gradN + ((size_t)e * Q + q) * 3 * S, *Pq = Pc + ((size_t)e * Q + q) * 9, *Fq = Fc + ((size_t)e * Q + q) * 9;
+      const double ha[3] = {g[a], g[a + S], g[a + 2 * S]}, dV = detJ[(size_t)e * Q + q] * qw[q];
+      double F[3][3], K[3][3];
+      for (int i = 0; i < 3; i++) { r[i] += (Pq[i] * ha[0] + Pq[i + 3] * ha[1] + Pq[i + 6] * ha[2]) * dV; for (int j = 0; j < 3; j++) F[i][j] = Fq[i + 3 * j]; }
+      vbd_diag_block(F, ha, mat, h * dV, K);
+      for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) Kd[i][j] += K[i][j];
+    }
+  }
+}
+
+/* node -> (element, local index) incidence, ascending element (cpu_utils.cc BuildNodeIncidence); entries e*S + a */
+static void vbd_incidence(int S, int E, int N, const int *conn, int *off, int *inc) {
+  memset(off, 0, sizeof(int) * ((size_t)N + 1));
+  for (int e = 0; e < E; e++) for (int a = 0; a < S; a++) off[conn[(size_t)a * E + e] + 1]++;
+  for (int i = 0; i < N; i++) off[i + 1] += off[i];
+  int *cur = (int *)malloc(sizeof(int) * (size_t)N);
+  memcpy(cur, off, sizeof(int) * (size_t)N);
+  for (int e = 0; e < E; e++) for (int a = 0; a < S; a++) inc[cur[conn[(size_t)a * E + e]]++] = e * S + a;
+  free(cur);
+}
+
+/* per-node element terms at the current state (for pinning against the reference's NumPy prototype
+ * test-scripts/vbd_proto/alm_vbd_t10_svk.py:175-222: f_int_i and sum K_ii, there without the factor h) */
+void orc_gen_vbd_node_terms(int S, int Q, int E, int N, const int *conn, const double *x, const double *y, const double *z,
+                            const double *v, const double *gradN, const double *detJ, const double *qw,
+                            const orc_material *mat, double h, double *r_out /*3N*/, double *K_out /*9N row-major*/) {
+  double *Fc = (double *)malloc(sizeof(double) * 9 * (size_t)E * Q), *Pc = (double *)malloc(sizeof(double) * 9 * (size_t)E * Q);
+  int *off = (int *)malloc(sizeof(int) * ((size_t)N + 1)), *inc = (int *)malloc(sizeof(int) * (size_t)S * E);
+  vbd_incidence(S, E, N, conn, off, inc);
+  orc_gen_compute_p(S, Q, E, conn, x, y, z, v, gradN, mat, Fc, Pc);
+  for (int i = 0; i < N; i++) {
+    double r[3] = {0, 0, 0}, K[3][3] = {{0}};
+    vbd_node_elements(S, Q, E, i, off, inc, Fc, Pc, gradN, detJ, qw, mat, h, r, K);
+    for (int d = 0; d < 3; d++) { r_out[3 * i + d] = r[d]; for (int e = 0; e < 3; e++) K_out[9 * (size_t)i + 3 * d + e] = K[d][e]; }
+  }
+  free(Fc); free(Pc); free(off); free(inc);
+}
+
+int orc_gen_vbd_step(int S, int Q, int E, int N, const int *conn, double *x, double *y, double *z, const double *xt,
+                     const double *yt, const double *zt, const double *gradN, const double *detJ, const double *qw,
+                     const orc_material *mat, const int *mo, const int *mc, const double *mv, const int *fixed,
+                     int n_fixed, const double *f_ext, const orc_vbd_params *prm, int n_colors, const int *color_offsets,
+                     const int *color_nodes, int n_groups, const int *group_offsets, const int *group_colors, double *v,
+                     double *v_prev, double *lam, double *stats) {
+  (void)n_colors;
+  const int n = 3 * N, nc = 3 * n_fixed;
+  const double h = prm->time_step, inv_h = 1.0 / h, rho = prm->rho;
+  double *xp = (double *)malloc(sizeof(double) * n), *Fc = (double *)malloc(sizeof(double) * 9 * (size_t)E * Q);
+  double *Pc = (double *)malloc(sizeof(double) * 9 * (size_t)E * Q), *f_int = (double *)malloc(sizeof(double) * n);
+  double *g = (double *)malloc(sizeof(double) * n), *c = (double *)calloc(nc > 0 ? nc : 1, sizeof(double));
+  double *mdiag = (double *)calloc((size_t)N, sizeof(double));
+  int *off = (int *)malloc(sizeof(int) * ((size_t)N + 1)), *inc = (int *)malloc(sizeof(int) * (size_t)S * E);
+  int *fmap = (int *)malloc(sizeof(int) * (size_t)N);
+  vbd_incidence(S, E, N, conn, off, inc);
+  for (int i = 0; i < N; i++) { fmap[i] = -1; for (int k = mo[i]; k < mo[i + 1]; k++) if (mc[k] == i) { mdiag[i] = mv[k]; break; } } /* :1030-1085 */
+  for (int k = 0; k < n_fixed; k++) fmap[fixed[k]] = k;                                                                            /* :146-160 */
+  memcpy(xp, x, sizeof(double) * N); memcpy(xp + N, y, sizeof(double) * N); memcpy(xp + 2 * N, z, sizeof(double) * N);
+  int n_outer = 0, n_sweeps = 0;
+  double ng = 0.0, ncn = 0.0;
+#define VBD_POS() for (int i = 0; i < N; i++) { x[i] = xp[i] + h * v[3 * i]; y[i] = xp[N + i] + h * v[3 * i + 1]; z[i] = xp[2 * N + i] + h * v[3 * i + 2]; }
+#define VBD_CONS() for (int k = 0; k < n_fixed; k++) { c[3 * k] = x[fixed[k]] - xt[fixed[k]]; c[3 * k + 1] = y[fixed[k]] - yt[fixed[k]]; c[3 * k + 2] = z[fixed[k]] - zt[fixed[k]]; }
+#define VBD_GNORM(out) do { orc_gen_internal_force(S, Q, E, N, conn, Pc, gradN, detJ, qw, f_int); VBD_CONS(); \
+    orc_grad_L(N, mo, mc, mv, v, v_prev, f_int, f_ext, fixed, n_fixed, c, lam, h, rho, g); \
+    double s_ = 0.0; for (int i = 0; i < n; i++) s_ += g[i] * g[i]; (out) = sqrt(s_); } while (0)
+  for (int outer = 0; outer < prm->max_outer; outer++) {
+    n_outer++;
+    VBD_POS();
+    orc_gen_compute_p(S, Q, E, conn, x, y, z, v, gradN, mat, Fc, Pc);
+    double R0 = -1.0;
+    if (prm->convergence_check_interval > 0) VBD_GNORM(R0);
+    for (int inner = 0; inner < prm->max_inner; inner++) {
+      n_sweeps++;
+      for (int gi = 0; gi < n_groups; gi++) {
+        for (int t = group_offsets[gi]; t < group_offsets[gi + 1]; t++) {
+          const int col = group_colors[t];
+          for (int s = color_offsets[col]; s < color_offsets[col + 1]; s++) { /* vbd_update_color_block_kernel */
+            const int i = color_nodes[s];
+            double r[3] = {0, 0, 0}, K[3][3] = {{0}};
+            for (int k = mo[i]; k < mo[i + 1]; k++) for (int d = 0; d < 3; d++) r[d] += mv[k] * (v[3 * mc[k] + d] - v_prev[3 * mc[k] + d]) * inv_h;
+            vbd_node_elements(S, Q, E, i, off, inc, Fc, Pc, gradN, detJ, qw, mat, h, r, K);
+            double R[3], H[3][3];
+            for (int d = 0; d < 3; d++) { R[d] = r[d] - f_ext[3 * i + d]; for (int e = 0; e < 3; e++) H[d][e] = (d == e ? mdiag[i] * inv_h : 0.0) + K[d][e]; }
+            if (nc > 0 && fmap[i] >= 0) {
+              const int k = fmap[i];
+              const double xi[3] = {xp[i] + h * v[3 * i], xp[N + i] + h * v[3 * i + 1], xp[2 * N + i] + h * v[3 * i + 2]};
+              const double Xi[3] = {xt[i], yt[i], zt[i]};
+              for (int d = 0; d < 3; d++) { R[d] += h * (lam[3 * k + d] + rho * (xi[d] - Xi[d])); H[d][d] += h * h * rho; }
+            }
+            const double a01 = 0.5 * (H[0][1] + H[1][0]), a02 = 0.5 * (H[0][2] + H[2][0]), a12 = 0.5 * (H[1][2] + H[2][1]);
+            H[0][1] = H[1][0] = a01; H[0][2] = H[2][0] = a02; H[1][2] = H[2][1] = a12;
+            const double tr = H[0][0] + H[1][1] + H[2][2], eps = prm->hess_eps * (tr > 1.0 ? tr : 1.0);
+            H[0][0] += eps; H[1][1] += eps; H[2][2] += eps;
+            const double det = H[0][0] * (H[1][1] * H[2][2] - H[1][2] * H[2][1]) - H[0][1] * (H[1][0] * H[2][2] - H[1][2] * H[2][0]) +
+                               H[0][2] * (H[1][0] * H[2][1] - H[1][1] * H[2][0]);
+            double dv[3] = {0, 0, 0};
+            if (fabs(det) >= 1e-30) { /* solve_3x3_vbd: cofactor inverse, dv = -H^-1 R */
+              const double id = 1.0 / det;
+              double Hi[3][3];
+              Hi[0][0] = (H[1][1] * H[2][2] - H[1][2] * H[2][1]) * id; Hi[0][1] = (H[0][2] * H[2][1] - H[0][1] * H[2][2]) * id;
+              Hi[0][2] = (H[0][1] * H[1][2] - H[0][2] * H[1][1]) * id; Hi[1][0] = (H[1][2] * H[2][0] - H[1][0] * H[2][2]) * id;
+              Hi[1][1] = (H[0][0] * H[2][2] - H[0][2] * H[2][0]) * id; Hi[1][2] = (H[0][2] * H[1][0] - H[0][0] * H[1][2]) * id;
+              Hi[2][0] = (H[1][0] * H[2][1] - H[1][1] * H[2][0]) * id; Hi[2][1] = (H[0][1] * H[2][0] - H[0][0] * H[2][1]) * id;
+              Hi[2][2] = (H[0][0] * H[1][1] - H[0][1] * H[1][0]) * id;
+              for (int d = 0; d < 3; d++) dv[d] = -(Hi[d][0] * R[0] + Hi[d][1] * R[1] + Hi[d][2] * R[2]);
+            }
+            for (int d = 0; d < 3; d++) v[3 * i + d] += prm->omega * dv[d];
+          }
+          for (int s = color_offsets[col]; s < color_offsets[col + 1]; s++) { /* vbd_update_pos_from_vel_color */
+            const int i = color_nodes[s];
+            x[i] = xp[i] + h * v[3 * i]; y[i] = xp[N + i] + h * v[3 * i + 1]; z[i] = xp[2 * N + i] + h * v[3 * i + 2];
+          }
+        }
+        orc_gen_compute_p(S, Q, E, conn, x, y, z, v, gradN, mat, Fc, Pc); /* refresh after the group */
+      }
+      if (prm->convergence_check_interval > 0 && (inner % prm->convergence_check_interval == 0 || inner == prm->max_inner - 1)) {
+        VBD_GNORM(ng);
+        const double a = prm->inner_tol, b = prm->inner_rtol * (R0 >= 0.0 ? R0 : ng);
+        if (ng <= (a > b ? a : b)) break;
+      }
+    }
+    VBD_POS(); /* post-outer graph: positions, constraints */
+    if (nc > 0) {
+      VBD_CONS();
+      ncn = 0.0; for (int k = 0; k < nc; k++) ncn += c[k] * c[k]; ncn = sqrt(ncn);
+      if (ncn < prm->outer_tol) break;
+      for (int k = 0; k < nc; k++) lam[k] += rho * c[k]; /* vbd_update_dual */
+    }
+  }
+  memcpy(v_prev, v, sizeof(double) * n);
+  if (stats) { stats[0] = n_outer; stats[1] = n_sweeps; stats[2] = ng; stats[3] = ncn; }
+#undef VBD_POS
+#undef VBD_CONS
+#undef VBD_GNORM
+  free(xp); free(Fc); free(Pc); free(f_int); free(g); free(c); free(mdiag); free(off); free(inc); free(fmap);
   return 0;
 }
