@@ -283,6 +283,39 @@ int tlfea_nesterov_retrieve_lambda(tlfea_nesterov_t a, double *lam);
 int tlfea_nesterov_get_stats(tlfea_nesterov_t a, double *out6);
 int tlfea_nesterov_set_verbose(tlfea_nesterov_t a, int v);
 
+
+/* ---- SyncedVBDSolver (lib_src/solvers/SyncedVBD.cuh:13-21 params, :23-330 class; SyncedVBD.cu:163-400 node update,
+ * :764-1135 Initialize*, :1475-1641 OneStepVBD) -- vertex block descent: ALM outer loop, inner loop of coloured
+ * Gauss-Seidel sweeps of per-node 3x3 Newton updates on the velocities.  Pinned-node constraints only (the reference's
+ * fixed map).  Call order of the reference drivers: create, Setup, SetParameters, InitializeColoring,
+ * InitializeMassDiagBlocks, InitializeFixedMap, Solve per step (Solve runs the Initialize* it still needs). */
+typedef struct tlfea_vbd_s *tlfea_vbd_t;
+typedef struct { /* == SyncedVBDParams, same field order */
+  double inner_tol, inner_rtol, outer_tol, rho;
+  int max_outer, max_inner;
+  double time_step, omega, hess_eps;
+  int convergence_check_interval, color_group_size;
+} tlfea_vbd_params;
+int tlfea_vbd_create(tlfea_t10_t data, int n_constraints, tlfea_vbd_t *out);
+int tlfea_vbd_destroy(tlfea_vbd_t a);
+int tlfea_vbd_setup(tlfea_vbd_t a);                                         /* Setup  SyncedVBD.cuh:263-274 */
+int tlfea_vbd_set_parameters(tlfea_vbd_t a, const tlfea_vbd_params *p);     /* SetParameters :228-261 */
+int tlfea_vbd_initialize_coloring(tlfea_vbd_t a);                           /* SyncedVBD.cu:764-1028 */
+int tlfea_vbd_initialize_mass_diag_blocks(tlfea_vbd_t a);                   /* :1030-1085 (runs CalcMassMatrix) */
+int tlfea_vbd_initialize_fixed_map(tlfea_vbd_t a);                          /* :1087-1135 */
+int tlfea_vbd_solve(tlfea_vbd_t a);                                         /* Solve()/OneStepVBD :1475-1641 */
+/* colouring: sizes {n_colors, n_groups}; arrays colors[N], color_offsets[n_colors+1], color_nodes[N],
+ * group_offsets[n_groups+1], group_colors[n_colors] (any pointer may be null) */
+int tlfea_vbd_coloring_sizes(tlfea_vbd_t a, int *n_colors, int *n_groups);
+int tlfea_vbd_retrieve_coloring(tlfea_vbd_t a, int *colors, int *color_offsets, int *color_nodes, int *group_offsets,
+                                int *group_colors);
+double *tlfea_vbd_velocity_guess_device_ptr(tlfea_vbd_t a);
+int tlfea_vbd_retrieve_velocity(tlfea_vbd_t a, double *v);
+int tlfea_vbd_retrieve_lambda(tlfea_vbd_t a, double *lam);
+/* out6: outer iterations run, sweeps (total), last checked ||g||, last ||c||, 0, device ms */
+int tlfea_vbd_get_stats(tlfea_vbd_t a, double *out6);
+int tlfea_vbd_set_verbose(tlfea_vbd_t a, int v);
+
 #ifdef __cplusplus
 }
 #endif

@@ -34,6 +34,12 @@ class NesterovParamsC(C.Structure):  # tlfea_nesterov_params == SyncedNesterovPa
                 ("max_outer", C.c_int), ("max_inner", C.c_int), ("time_step", C.c_double)]
 
 
+class VbdParamsC(C.Structure):  # tlfea_vbd_params == SyncedVBDParams (SyncedVBD.cuh:13-21)
+    _fields_ = [("inner_tol", C.c_double), ("inner_rtol", C.c_double), ("outer_tol", C.c_double), ("rho", C.c_double),
+                ("max_outer", C.c_int), ("max_inner", C.c_int), ("time_step", C.c_double), ("omega", C.c_double),
+                ("hess_eps", C.c_double), ("convergence_check_interval", C.c_int), ("color_group_size", C.c_int)]
+
+
 class LinSolveOptsC(C.Structure):
     _fields_ = [("rel_tol", C.c_double), ("max_iter", C.c_int), ("check_every", C.c_int), ("cheb_degree", C.c_int),
                 ("cheb_kappa", C.c_double), ("cheb_bits", C.c_int), ("precond", C.c_int)]
@@ -58,7 +64,8 @@ def load_library():
     lib.tlfea_last_error.restype = C.c_char_p
     for name in ("tlfea_t10_x12_device_ptr", "tlfea_t10_y12_device_ptr", "tlfea_t10_z12_device_ptr",
                  "tlfea_t10_external_force_device_ptr", "tlfea_t10_constraint_device_ptr",
-                 "tlfea_newton_velocity_guess_device_ptr", "tlfea_adamw_velocity_guess_device_ptr", "tlfea_nesterov_velocity_guess_device_ptr"):
+                 "tlfea_newton_velocity_guess_device_ptr", "tlfea_adamw_velocity_guess_device_ptr", "tlfea_nesterov_velocity_guess_device_ptr",
+                 "tlfea_vbd_velocity_guess_device_ptr"):
         getattr(lib, name).restype = C.c_void_p
         getattr(lib, name).argtypes = [C.c_void_p]
     _LIB = lib

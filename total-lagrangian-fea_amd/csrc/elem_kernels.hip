@@ -957,4 +957,234 @@ void launch_mass_values(hipStream_t s, const ElemView& m, const Incidence& inc, 
   hipLaunchKernelGGL(mass_values_kernel, dim3((m.N + 127) / 128), dim3(128), 0, s, m, inc, qx, qy, qz, rho0, mval);
 }
 
+// ------------------------------------------------------------------------------------------------
+// SyncedVBDSolver: one coloured Gauss-Seidel update (vbd_update_color_block_kernel + vbd_update_pos_from_vel_color +
+// the compute_p refresh, SyncedVBD.cu:163-400, 708-722, 1310-1330).  One 64-lane wave per node of the colour; the
+// lanes split the node's (incident element, quadrature point) items.  The reference keeps F and P of every
+// (element, point) in memory and recomputes ALL of them after every colour group; here each item rebuilds F (and Fdot)
+// from the current coordinates in registers.  That is the same arithmetic at the same state: two nodes of one colour
+// (or of one colour group) never share an element, so between the reference's refresh and its use no coordinate or
+// velocity of that element changes -- and nothing has to be refreshed, stored or re-read.
+//   residual  R = M_row (v - v_prev)/h + sum_q P h_a dV - f_ext  (+ h (lam + rho c) on a pinned node)
+//   Hessian   H = m_ii/h I + h sum_q K_aa(elastic)               (+ h^2 rho I), symmetrised, + eps max(1, tr H) I
+//   v_i += omega * (-H^-1 R) (cofactor inverse, zero update when |det| < 1e-30);  x_i = x_prev_i + h v_i
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void vbd_diag_block(const double F[3][3], const double ha[3], const Material& mat, double w,
+                                               double K[3][3]) {
+  if (mat.model == kMooneyRivlin) {
+    // K[i][k] = sum_jl A[i][j][k][l] h_j h_l with A = dP/dF of MooneyRivlin.cuh:113-225 (FEAT10DataFunc.cuh:353-372),
+    // contracted analytically: every term of A is a product of two 3x3 factors, so with a = h_a, Fa = F a, Ga = G a
+    // (G = F^-T), FCa = (F C) a, s = |a|^2, q = a.C a:
+    //   K = t1 [ s I - 2/3 (T1a (x) Ga + Ga (x) Fa) + I1/3 Ga (x) Ga ]
+    //     + t2 [ Fa (x) Fa + (I1 s - q) I - s F F^T - 4/3 (T2a (x) Ga + Ga (x) (I1 Fa - FCa)) + 2 I2/3 Ga (x) Ga ]
+    //     + (kappa (2J - 1) J - t3) Ga (x) Ga,        T1a = Fa - I1/3 Ga,  T2a = I1 Fa - FCa - 2 I2/3 Ga
+    MRState s;
+    mr_state(F, mat.mu10, mat.mu01, mat.kappa, s);
+    const double k3 = mat.kappa * (2.0 * s.J - 1.0) * s.J;
+    double Fa[3], Ga[3], FCa[3], Ca[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      Fa[i] = F[i][0] * ha[0] + F[i][1] * ha[1] + F[i][2] * ha[2];
+      Ga[i] = s.G[i][0] * ha[0] + s.G[i][1] * ha[1] + s.G[i][2] * ha[2];
+      FCa[i] = s.FC[i][0] * ha[0] + s.FC[i][1] * ha[1] + s.FC[i][2] * ha[2];
+      Ca[i] = s.C[i][0] * ha[0] + s.C[i][1] * ha[1] + s.C[i][2] * ha[2];
+    }
+    const double ss = ha[0] * ha[0] + ha[1] * ha[1] + ha[2] * ha[2], qq = ha[0] * Ca[0] + ha[1] * Ca[1] + ha[2] * Ca[2];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      const double T1a = Fa[i] - (s.I1 / 3.0) * Ga[i], T2a = s.I1 * Fa[i] - FCa[i] - (2.0 * s.I2 / 3.0) * Ga[i];
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        const double dik = (i == k) ? 1.0 : 0.0;
+        const double GG = Ga[i] * Ga[k];
+        const double e1 = ss * dik - (2.0 / 3.0) * (T1a * Ga[k] + Ga[i] * Fa[k]) + (s.I1 / 3.0) * GG;
+        const double e2 = Fa[i] * Fa[k] + (s.I1 * ss - qq) * dik - ss * s.FFT[i][k] -
+                          (4.0 / 3.0) * (T2a * Ga[k] + Ga[i] * (s.I1 * Fa[k] - FCa[k])) + (2.0 * s.I2 / 3.0) * GG;
+        K[i][k] = (s.t1 * e1 + s.t2 * e2 + (k3 - s.t3) * GG) * w;
+      }
+    }
+    return;
+  }
+  double FFT[3][3], Fh[3], trC = 0.0;  // SVK.cuh:35-55 with i == j
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    Fh[i] = F[i][0] * ha[0] + F[i][1] * ha[1] + F[i][2] * ha[2];
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      trC += F[i][j] * F[i][j];
+      FFT[i][j] = F[i][0] * F[j][0] + F[i][1] * F[j][1] + F[i][2] * F[j][2];
+    }
+  }
+  const double trE = 0.5 * (trC - 3.0), hij = ha[0] * ha[0] + ha[1] * ha[1] + ha[2] * ha[2];
+  const double ff = Fh[0] * Fh[0] + Fh[1] * Fh[1] + Fh[2] * Fh[2];
+#pragma unroll
+  for (int d = 0; d < 3; d++)
+#pragma unroll
+    for (int e = 0; e < 3; e++) {
+      const double dl = (d == e) ? 1.0 : 0.0;
+      K[d][e] = (mat.lambda * Fh[d] * Fh[e] + mat.lambda * trE * hij * dl + mat.mu * ff * dl + mat.mu * Fh[d] * Fh[e] +
+                 mat.mu * hij * FFT[d][e] - mat.mu * hij * dl) * w;
+    }
+}
+
+template <int S, int Q>
+__global__ __launch_bounds__(256) void vbd_color_kernel(ElemView m, Material mat, Incidence inc,
+                                                        const int* __restrict__ nodes, int count,
+                                                        const double* __restrict__ mval, const double* __restrict__ f_ext,
+                                                        const int* __restrict__ fixed_slot, const double* __restrict__ xt,
+                                                        const double* __restrict__ yt, const double* __restrict__ zt,
+                                                        const double* __restrict__ lam, double h, double rho, double omega,
+                                                        double hess_eps, const double* __restrict__ v_prev,
+                                                        const double* __restrict__ xp, const double* __restrict__ yp,
+                                                        const double* __restrict__ zp, double* v, double* x, double* y,
+                                                        double* z) {
+  const int lane = threadIdx.x & 63;
+  const int slot = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (slot >= count) return;  // whole wave
+  const int i = nodes[slot];
+  const double inv_h = 1.0 / h;
+  const bool damp = (mat.eta != 0.0 || mat.lamd != 0.0);
+  double acc[12];
+#pragma unroll
+  for (int k = 0; k < 12; k++) acc[k] = 0.0;
+  // mass row (consistent mass, all neighbours)
+  for (int k = inc.off[i] + lane; k < inc.off[i + 1]; k += 64) {
+    const int j = inc.cols[k];
+    const double mij = mval[k];
+#pragma unroll
+    for (int d = 0; d < 3; d++) acc[d] += mij * (v[3 * j + d] - v_prev[3 * j + d]) * inv_h;
+  }
+  // element items
+  const int i0 = inc.n2e_off[i], n_items = (inc.n2e_off[i + 1] - i0) * Q;
+  for (int w = lane; w < n_items; w += 64) {
+    const int k = w / Q, q = w - k * Q;
+    const int code = inc.n2e[i0 + k];
+    const int e = code / S, a = code - e * S;
+    const double* g = m.gradN + ((size_t)e * Q + q) * 3 * S;
+    double F[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, Fd[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+#pragma unroll 2
+    for (int b = 0; b < S; b++) {
+      const int c = m.conn[(size_t)b * m.E + e];
+      const double X[3] = {x[c], y[c], z[c]};
+      const double hb[3] = {g[b], g[S + b], g[2 * S + b]};
+#pragma unroll
+      for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int cc = 0; cc < 3; cc++) F[r][cc] += X[r] * hb[cc];
+      if (damp) {
+        const double V[3] = {v[3 * c], v[3 * c + 1], v[3 * c + 2]};
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+#pragma unroll
+          for (int cc = 0; cc < 3; cc++) Fd[r][cc] += V[r] * hb[cc];
+      }
+    }
+    double P[3][3];
+    elastic_P(F, mat, P);
+    if (damp) {  // Kelvin-Voigt part of compute_p (FEAT10DataFunc.cuh:137-232)
+      double Ed[3][3];
+#pragma unroll
+      for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int cc = 0; cc < 3; cc++) {
+          double a1 = 0.0, a2 = 0.0;
+#pragma unroll
+          for (int t = 0; t < 3; t++) {
+            a1 += Fd[t][r] * F[t][cc];
+            a2 += F[t][r] * Fd[t][cc];
+          }
+          Ed[r][cc] = 0.5 * (a1 + a2);
+        }
+      const double trEd = Ed[0][0] + Ed[1][1] + Ed[2][2];
+#pragma unroll
+      for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int cc = 0; cc < 3; cc++) {
+          double sv = 0.0;
+#pragma unroll
+          for (int t = 0; t < 3; t++) sv += F[r][t] * (2.0 * mat.eta * Ed[t][cc] + (t == cc ? mat.lamd * trEd : 0.0));
+          P[r][cc] += sv;
+        }
+    }
+    const double ha[3] = {g[a], g[S + a], g[2 * S + a]};
+    const double dV = m.detJ[(size_t)e * Q + q] * m.qw[q];
+#pragma unroll
+    for (int r = 0; r < 3; r++) acc[r] += (P[r][0] * ha[0] + P[r][1] * ha[1] + P[r][2] * ha[2]) * dV;
+    double K[3][3];
+    vbd_diag_block(F, ha, mat, h * dV, K);
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+      for (int cc = 0; cc < 3; cc++) acc[3 + 3 * r + cc] += K[r][cc];
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+    for (int k = 0; k < 12; k++) acc[k] += __shfl_xor(acc[k], o);
+  if (lane != 0) return;
+  double R[3], H[3][3];
+  const double mii = mval[inc.off[i] + inc.diagpos[i]];  // InitializeMassDiagBlocks: m_ii I (SyncedVBD.cu:1030-1085)
+#pragma unroll
+  for (int d = 0; d < 3; d++) {
+    R[d] = acc[d] - f_ext[3 * i + d];
+#pragma unroll
+    for (int e = 0; e < 3; e++) H[d][e] = (d == e ? mii * inv_h : 0.0) + acc[3 + 3 * d + e];
+  }
+  const double vi[3] = {v[3 * i], v[3 * i + 1], v[3 * i + 2]};
+  const double xpi[3] = {xp[i], yp[i], zp[i]};
+  const int k = fixed_slot ? fixed_slot[i] : -1;
+  if (k >= 0) {
+    const double Xi[3] = {xt[i], yt[i], zt[i]};
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+      const double c = (xpi[d] + h * vi[d]) - Xi[d];
+      R[d] += h * (lam[3 * k + d] + rho * c);
+      H[d][d] += h * h * rho;
+    }
+  }
+  const double a01 = 0.5 * (H[0][1] + H[1][0]), a02 = 0.5 * (H[0][2] + H[2][0]), a12 = 0.5 * (H[1][2] + H[2][1]);
+  H[0][1] = H[1][0] = a01;
+  H[0][2] = H[2][0] = a02;
+  H[1][2] = H[2][1] = a12;
+  const double eps = hess_eps * fmax(1.0, H[0][0] + H[1][1] + H[2][2]);
+  H[0][0] += eps;
+  H[1][1] += eps;
+  H[2][2] += eps;
+  const double det = H[0][0] * (H[1][1] * H[2][2] - H[1][2] * H[2][1]) - H[0][1] * (H[1][0] * H[2][2] - H[1][2] * H[2][0]) +
+                     H[0][2] * (H[1][0] * H[2][1] - H[1][1] * H[2][0]);
+  double dv[3] = {0.0, 0.0, 0.0};
+  if (fabs(det) >= 1e-30) {  // solve_3x3_vbd (SyncedVBD.cu:47-82)
+    const double id = 1.0 / det;
+    const double i00 = (H[1][1] * H[2][2] - H[1][2] * H[2][1]) * id, i01 = (H[0][2] * H[2][1] - H[0][1] * H[2][2]) * id,
+                 i02 = (H[0][1] * H[1][2] - H[0][2] * H[1][1]) * id, i10 = (H[1][2] * H[2][0] - H[1][0] * H[2][2]) * id,
+                 i11 = (H[0][0] * H[2][2] - H[0][2] * H[2][0]) * id, i12 = (H[0][2] * H[1][0] - H[0][0] * H[1][2]) * id,
+                 i20 = (H[1][0] * H[2][1] - H[1][1] * H[2][0]) * id, i21 = (H[0][1] * H[2][0] - H[0][0] * H[2][1]) * id,
+                 i22 = (H[0][0] * H[1][1] - H[0][1] * H[1][0]) * id;
+    dv[0] = -(i00 * R[0] + i01 * R[1] + i02 * R[2]);
+    dv[1] = -(i10 * R[0] + i11 * R[1] + i12 * R[2]);
+    dv[2] = -(i20 * R[0] + i21 * R[1] + i22 * R[2]);
+  }
+  const double vn[3] = {vi[0] + omega * dv[0], vi[1] + omega * dv[1], vi[2] + omega * dv[2]};
+  v[3 * i] = vn[0];
+  v[3 * i + 1] = vn[1];
+  v[3 * i + 2] = vn[2];
+  x[i] = xpi[0] + vn[0] * h;  // vbd_update_pos_from_vel_color
+  y[i] = xpi[1] + vn[1] * h;
+  z[i] = xpi[2] + vn[2] * h;
+}
+
+void launch_vbd_color(hipStream_t s, const ElemView& m, const Material& mat, const Incidence& inc, const int* nodes,
+                      int count, const double* mval, const double* f_ext, const int* fixed_slot, const double* xt,
+                      const double* yt, const double* zt, const double* lam, double h, double rho, double omega,
+                      double hess_eps, const double* v_prev, const double* xp, const double* yp, const double* zp,
+                      double* v, double* x, double* y, double* z) {
+  if (count <= 0) return;
+  const dim3 grid((count + 3) / 4), block(256);
+#define TLFEA_VBD_ARGS m, mat, inc, nodes, count, mval, f_ext, fixed_slot, xt, yt, zt, lam, h, rho, omega, hess_eps, v_prev, xp, yp, zp, v, x, y, z
+  if (m.S == 10) hipLaunchKernelGGL((vbd_color_kernel<10, 5>), grid, block, 0, s, TLFEA_VBD_ARGS);
+  else if (m.S == 8) hipLaunchKernelGGL((vbd_color_kernel<8, 12>), grid, block, 0, s, TLFEA_VBD_ARGS);
+  else hipLaunchKernelGGL((vbd_color_kernel<16, 48>), grid, block, 0, s, TLFEA_VBD_ARGS);
+#undef TLFEA_VBD_ARGS
+}
+
 }  // namespace tlfea

@@ -16,6 +16,7 @@
 #include "ancf_host.h"
 #include "tlfea_internal.h"
 #include "pmg_host.h"
+#include "vbd_host.h"
 
 using namespace tlfea;
 
@@ -2400,5 +2401,216 @@ extern "C" int tlfea_nesterov_solve(tlfea_nesterov_t a) {
   HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
   a->stats[0] = n_outer; a->stats[1] = n_inner_total; a->stats[2] = norm_g; a->stats[3] = norm_c;
   a->stats[4] = inner_flag; a->stats[5] = ms;
+  return 0;
+}
+
+// =================================================================================================
+// SyncedVBDSolver (SyncedVBD.cuh:13-330, SyncedVBD.cu:163-400, 764-1135, 1475-1641): vertex block descent on the same
+// velocity unknowns.  One launch per colour (csrc/elem_kernels.hip vbd_color_kernel: update, position and -- implicitly,
+// because it rebuilds F from the coordinates -- the reference's compute_p refresh); the convergence checks reuse the
+// Newton core's gradient evaluation, the dual update its kernel.  The sweep of all colours is captured in a hipGraph,
+// as the reference captures its sweep in a CUDA graph (:1233-1330).
+struct tlfea_vbd_s {
+  tlfea_newton_t core = nullptr;
+  tlfea_vbd_params prm{1e-4, 1e-4, 1e-4, 1e14, 5, 500, 1e-3, 1.0, 1e-12, 25, 1};
+  VbdColoring col;
+  int* d_color_nodes = nullptr;
+  bool coloring_ready = false, mass_ready = false, fixed_ready = false;
+  int colored_group_size = 0;
+  hipGraphExec_t sweep_graph = nullptr;
+  double graph_key[5] = {0, 0, 0, 0, 0};  // h, rho, omega, hess_eps, pinned?: the values baked into the captured launches
+  double stats[6] = {0, 0, 0, 0, 0, 0};
+  int verbose = 0;
+};
+
+static void vbd_drop_graph(tlfea_vbd_t a) {
+  if (a->sweep_graph) (void)hipGraphExecDestroy(a->sweep_graph);
+  a->sweep_graph = nullptr;
+}
+
+extern "C" int tlfea_vbd_create(tlfea_t10_t data, int n_constraints, tlfea_vbd_t* out) {
+  if (!data || !out) return fail("tlfea_vbd_create: null argument");
+  auto* a = new tlfea_vbd_s();
+  TRY(tlfea_newton_create(data, n_constraints, &a->core));
+  *out = a;
+  return 0;
+}
+extern "C" int tlfea_vbd_destroy(tlfea_vbd_t a) {
+  if (!a) return 0;
+  vbd_drop_graph(a);
+  if (a->d_color_nodes) (void)hipFree(a->d_color_nodes);
+  (void)tlfea_newton_destroy(a->core);
+  delete a;
+  return 0;
+}
+extern "C" int tlfea_vbd_setup(tlfea_vbd_t a) { return tlfea_newton_setup(a->core); }
+extern "C" int tlfea_vbd_set_parameters(tlfea_vbd_t a, const tlfea_vbd_params* p) {
+  if (!a || !p) return fail("null argument");
+  a->prm = *p;
+  if (a->prm.color_group_size <= 0) a->prm.color_group_size = 1;
+  tlfea_newton_t s = a->core;  // SetParameters clears v_guess, v_prev and lambda (SyncedVBD.cuh:258-260)
+  const size_t n = 3 * (size_t)s->N;
+  HIP_TRY(hipMemset(s->d_v, 0, n * sizeof(double)));
+  HIP_TRY(hipMemset(s->d_vprev, 0, n * sizeof(double)));
+  HIP_TRY(hipMemset(s->d_lam, 0, (size_t)std::max(1, s->n_constraints) * sizeof(double)));
+  return 0;
+}
+extern "C" int tlfea_vbd_initialize_mass_diag_blocks(tlfea_vbd_t a) {
+  TRY(tlfea_t10_calc_mass_matrix(a->core->d));  // the reference recomputes the mass matrix here (:1041-1052)
+  a->mass_ready = true;
+  return 0;
+}
+extern "C" int tlfea_vbd_initialize_coloring(tlfea_vbd_t a) {
+  tlfea_t10_t d = a->core->d;
+  if (a->coloring_ready && a->colored_group_size == a->prm.color_group_size) return 0;
+  if (!d->is_csr_setup) TRY(tlfea_vbd_initialize_mass_diag_blocks(a));  // the adjacency is the mass pattern
+  if (a->verbose) std::printf("Initializing VBD coloring...\n");
+  vbd_build_coloring(d->S, d->E, d->N, d->h_conn.data(), d->h_off.data(), d->h_cols.data(), a->prm.color_group_size, a->col);
+  if (!a->col.valid) std::fprintf(stderr, "Warning: Invalid coloring detected!\n");
+  if (a->verbose) std::printf("VBD coloring: %d colors for %d nodes\n", a->col.n_colors, d->N);
+  if (a->d_color_nodes) (void)hipFree(a->d_color_nodes);
+  a->d_color_nodes = nullptr;
+  TRY(dmalloc(&a->d_color_nodes, (size_t)d->N));
+  HIP_TRY(hipMemcpy(a->d_color_nodes, a->col.color_nodes.data(), (size_t)d->N * sizeof(int), hipMemcpyHostToDevice));
+  a->coloring_ready = true;
+  a->colored_group_size = a->prm.color_group_size;
+  vbd_drop_graph(a);
+  return 0;
+}
+extern "C" int tlfea_vbd_initialize_fixed_map(tlfea_vbd_t a) {
+  tlfea_t10_t d = a->core->d;
+  if (a->core->n_constraints > 0 && (!d->is_constraints_setup || d->cons_mode != 1))
+    return fail("SyncedVBDSolver: pinned-node constraints (SetNodalFixed) only; the reference's fixed map has no general rows");
+  a->fixed_ready = true;  // node -> slot map: built by SetNodalFixed (d_fixed_slot)
+  return 0;
+}
+extern "C" int tlfea_vbd_coloring_sizes(tlfea_vbd_t a, int* n_colors, int* n_groups) {
+  if (!a->coloring_ready) return fail("SyncedVBDSolver: InitializeColoring() has not run");
+  if (n_colors) *n_colors = a->col.n_colors;
+  if (n_groups) *n_groups = a->col.n_groups;
+  return 0;
+}
+extern "C" int tlfea_vbd_retrieve_coloring(tlfea_vbd_t a, int* colors, int* color_offsets, int* color_nodes,
+                                           int* group_offsets, int* group_colors) {
+  if (!a->coloring_ready) return fail("SyncedVBDSolver: InitializeColoring() has not run");
+  const VbdColoring& c = a->col;
+  if (colors) std::copy(c.colors.begin(), c.colors.end(), colors);
+  if (color_offsets) std::copy(c.color_offsets.begin(), c.color_offsets.end(), color_offsets);
+  if (color_nodes) std::copy(c.color_nodes.begin(), c.color_nodes.end(), color_nodes);
+  if (group_offsets) std::copy(c.group_offsets.begin(), c.group_offsets.end(), group_offsets);
+  if (group_colors) std::copy(c.group_colors.begin(), c.group_colors.end(), group_colors);
+  return 0;
+}
+extern "C" double* tlfea_vbd_velocity_guess_device_ptr(tlfea_vbd_t a) { return a->core->d_v; }
+extern "C" int tlfea_vbd_retrieve_velocity(tlfea_vbd_t a, double* v) { return tlfea_newton_retrieve_velocity(a->core, v); }
+extern "C" int tlfea_vbd_retrieve_lambda(tlfea_vbd_t a, double* lam) { return tlfea_newton_retrieve_lambda(a->core, lam); }
+extern "C" int tlfea_vbd_get_stats(tlfea_vbd_t a, double* out6) {
+  std::copy(a->stats, a->stats + 6, out6);
+  return 0;
+}
+extern "C" int tlfea_vbd_set_verbose(tlfea_vbd_t a, int v) {
+  a->verbose = v;
+  return 0;
+}
+
+// one sweep = every colour once, in group order; colours of a group share no element, so they are launched as they
+// come (the reference's refresh after the group changes nothing a colour of the same group reads)
+static void vbd_enqueue_sweep(tlfea_vbd_t a, hipStream_t st) {
+  tlfea_newton_t s = a->core;
+  tlfea_t10_t d = s->d;
+  const tlfea_vbd_params& p = a->prm;
+  const VbdColoring& c = a->col;
+  const bool pinned = s->n_constraints > 0;
+  for (int g = 0; g < c.n_groups; g++)
+    for (int t = c.group_offsets[g]; t < c.group_offsets[g + 1]; t++) {
+      const int k = c.group_colors[t];
+      launch_vbd_color(st, d->view(), d->mat, d->inc(), a->d_color_nodes + c.color_offsets[k],
+                       c.color_offsets[k + 1] - c.color_offsets[k], d->d_mval, d->d_fext, pinned ? d->d_fixed_slot : nullptr,
+                       d->d_xt, d->d_yt, d->d_zt, s->d_lam, p.time_step, p.rho, p.omega, p.hess_eps, s->d_vprev, s->d_xp,
+                       s->d_yp, s->d_zp, s->d_v, d->d_x, d->d_y, d->d_z);
+    }
+}
+
+static int vbd_sweep(tlfea_vbd_t a) {
+  tlfea_newton_t s = a->core;
+  const tlfea_vbd_params& p = a->prm;
+  const double key[5] = {p.time_step, p.rho, p.omega, p.hess_eps, s->n_constraints > 0 ? 1.0 : 0.0};
+  const bool graphs = s->use_graphs && s->stream != nullptr;
+  if (!graphs) {
+    vbd_enqueue_sweep(a, s->stream);
+    return 0;
+  }
+  if (a->sweep_graph && !std::equal(key, key + 5, a->graph_key)) vbd_drop_graph(a);
+  if (!a->sweep_graph) {
+    hipGraph_t graph = nullptr;
+    HIP_TRY(hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
+    vbd_enqueue_sweep(a, s->stream);
+    HIP_TRY(hipStreamEndCapture(s->stream, &graph));
+    HIP_TRY(hipGraphInstantiate(&a->sweep_graph, graph, nullptr, nullptr, 0));
+    HIP_TRY(hipGraphDestroy(graph));
+    std::copy(key, key + 5, a->graph_key);
+  }
+  HIP_TRY(hipGraphLaunch(a->sweep_graph, s->stream));
+  return 0;
+}
+
+// OneStepVBD (SyncedVBD.cu:1475-1641)
+extern "C" int tlfea_vbd_solve(tlfea_vbd_t a) {
+  tlfea_newton_t s = a->core;
+  tlfea_t10_t d = s->d;
+  const tlfea_vbd_params& p = a->prm;
+  if (s->ar) return fail("SyncedVBDSolver: single-GPU path only");
+  if (!a->mass_ready && !d->is_csr_setup) TRY(tlfea_vbd_initialize_mass_diag_blocks(a));
+  TRY(tlfea_vbd_initialize_coloring(a));
+  if (!a->fixed_ready) TRY(tlfea_vbd_initialize_fixed_map(a));
+  if (s->n_constraints > 0 && !d->is_constraints_setup)
+    return fail("SyncedVBDSolver: n_constraints_ > 0 but constraint buffer is unavailable (did you call element constraint setup?)");
+  const int N = s->N, n = 3 * N;
+  const double dt = p.time_step;
+  s->prm.time_step = dt;  // the core's gradient (convergence checks) uses this solver's h and rho
+  s->prm.rho = p.rho;
+  hipEvent_t e0 = s->ev[2], e1 = s->ev[3];
+  HIP_TRY(hipEventRecord(e0, s->stream));
+  TRY(begin_step(s));  // vbd_update_pos_prev
+  int n_outer = 0, n_sweeps = 0;
+  double norm_g = 0.0, norm_c = 0.0;
+  for (int outer = 0; outer < p.max_outer; outer++) {
+    n_outer++;
+    launch_positions_from_prev(s->stream, N, s->d_v, s->d_xp, s->d_yp, s->d_zp, dt, d->d_x, d->d_y, d->d_z);
+    double R0 = -1.0;
+    if (p.convergence_check_interval > 0) {
+      TRY(eval_gradient(s, &R0));
+      if (a->verbose) std::printf("    [VBD check] init: ||g||=%.6e\n", R0);
+    }
+    for (int inner = 0; inner < p.max_inner; inner++) {
+      n_sweeps++;
+      TRY(vbd_sweep(a));
+      if (p.convergence_check_interval > 0 && (inner % p.convergence_check_interval == 0 || inner == p.max_inner - 1)) {
+        TRY(eval_gradient(s, &norm_g));
+        if (a->verbose) std::printf("    VBD sweep %3d: ||g|| = %.6e\n", inner, norm_g);
+        if (norm_g <= std::max(p.inner_tol, p.inner_rtol * (R0 >= 0.0 ? R0 : norm_g))) break;
+      }
+    }
+    launch_positions_from_prev(s->stream, N, s->d_v, s->d_xp, s->d_yp, s->d_zp, dt, d->d_x, d->d_y, d->d_z);
+    if (s->n_constraints > 0) {
+      launch_constraint(s->stream, d->n_fixed, d->d_fixed, d->d_x, d->d_y, d->d_z, d->d_xt, d->d_yt, d->d_zt, d->d_cons);
+      TRY(device_norm(s, d->d_cons, nullptr, s->n_constraints, &norm_c));
+      if (a->verbose) std::printf("VBD outer %d: ||c|| = %g\n", outer, norm_c);
+      if (norm_c < p.outer_tol) {
+        if (a->verbose) std::printf("VBD converged at outer iteration %d\n", outer);
+        break;
+      }
+      launch_dual_update(s->stream, s->n_constraints, d->d_cons, p.rho, s->d_lam);  // vbd_update_dual: lam += rho c
+    }
+  }
+  HIP_TRY(hipMemcpyAsync(s->d_vprev, s->d_v, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(e1, s->stream));
+  HIP_TRY(hipEventSynchronize(e1));
+  float ms = 0.f;
+  HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+  a->stats[0] = n_outer; a->stats[1] = n_sweeps; a->stats[2] = norm_g; a->stats[3] = norm_c; a->stats[4] = 0.0;
+  a->stats[5] = ms;
+  if (a->verbose) std::printf("OneStepVBD kernel time: %.3f ms\n", ms);
   return 0;
 }

@@ -4,7 +4,7 @@ from dataclasses import dataclass
 
 import numpy as np
 
-from .binding import (ALLREDUCE_FN, AdamWParamsC, LinSolveOptsC, NesterovParamsC, NewtonParams, check, dp, ip,
+from .binding import (ALLREDUCE_FN, AdamWParamsC, LinSolveOptsC, NesterovParamsC, NewtonParams, VbdParamsC, check, dp, ip,
                       load_library)
 
 
@@ -369,3 +369,93 @@ class SyncedNesterovSolver:
         st = np.zeros(6)
         check(self._lib.tlfea_nesterov_get_stats(self._h, dp(st)))
         return dict(outer=int(st[0]), inner=int(st[1]), norm_g=st[2], norm_c=st[3], inner_flag=int(st[4]), ms=st[5])
+
+
+@dataclass
+class SyncedVBDParams:
+    """SyncedVBDParams (SyncedVBD.cuh:13-21; driver values test_feat10_resolution.cc:379-380 with omega 1.8)."""
+    inner_tol: float = 1e-4
+    inner_rtol: float = 1e-4
+    outer_tol: float = 1e-4
+    rho: float = 1e14
+    max_outer: int = 5
+    max_inner: int = 500
+    time_step: float = 1e-3
+    omega: float = 1.0
+    hess_eps: float = 1e-12
+    convergence_check_interval: int = 25
+    color_group_size: int = 1
+
+
+class SyncedVBDSolver:
+    """SyncedVBDSolver (SyncedVBD.cuh:23-330): vertex block descent -- coloured per-node 3x3 Newton sweeps."""
+
+    def __init__(self, data, n_constraints):
+        self._lib = load_library()
+        self._data = data
+        self.n_coef = data.get_n_coef()
+        self.n_constraints = int(n_constraints)
+        self._h = C.c_void_p()
+        check(self._lib.tlfea_vbd_create(data._h, self.n_constraints, C.byref(self._h)))
+
+    def __del__(self):
+        try:
+            if self._h:
+                self._lib.tlfea_vbd_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def Setup(self):
+        check(self._lib.tlfea_vbd_setup(self._h))
+
+    def SetParameters(self, p):
+        c = VbdParamsC(p.inner_tol, p.inner_rtol, p.outer_tol, p.rho, p.max_outer, p.max_inner, p.time_step, p.omega,
+                       p.hess_eps, p.convergence_check_interval, p.color_group_size)
+        check(self._lib.tlfea_vbd_set_parameters(self._h, C.byref(c)))
+
+    def InitializeColoring(self):
+        check(self._lib.tlfea_vbd_initialize_coloring(self._h))
+
+    def InitializeMassDiagBlocks(self):
+        check(self._lib.tlfea_vbd_initialize_mass_diag_blocks(self._h))
+
+    def InitializeFixedMap(self):
+        check(self._lib.tlfea_vbd_initialize_fixed_map(self._h))
+
+    def Solve(self):
+        check(self._lib.tlfea_vbd_solve(self._h))
+
+    OneStepVBD = Solve
+
+    def SetVerbose(self, v):
+        check(self._lib.tlfea_vbd_set_verbose(self._h, int(v)))
+
+    def GetColoring(self):
+        """colors[N], color_offsets, color_nodes, group_offsets, group_colors of InitializeColoring"""
+        nc, ng = C.c_int(), C.c_int()
+        check(self._lib.tlfea_vbd_coloring_sizes(self._h, C.byref(nc), C.byref(ng)))
+        out = dict(n_colors=nc.value, n_groups=ng.value, colors=np.zeros(self.n_coef, dtype=np.int32),
+                   color_offsets=np.zeros(nc.value + 1, dtype=np.int32), color_nodes=np.zeros(self.n_coef, dtype=np.int32),
+                   group_offsets=np.zeros(ng.value + 1, dtype=np.int32), group_colors=np.zeros(nc.value, dtype=np.int32))
+        check(self._lib.tlfea_vbd_retrieve_coloring(self._h, ip(out["colors"]), ip(out["color_offsets"]),
+                                                    ip(out["color_nodes"]), ip(out["group_offsets"]), ip(out["group_colors"])))
+        return out
+
+    def GetVelocityGuessDevicePtr(self):
+        return self._lib.tlfea_vbd_velocity_guess_device_ptr(self._h)
+
+    def RetrieveVelocityToCPU(self):
+        v = np.zeros(3 * self.n_coef)
+        check(self._lib.tlfea_vbd_retrieve_velocity(self._h, dp(v)))
+        return v
+
+    def RetrieveLambdaToCPU(self):
+        lam = np.zeros(self.n_constraints)
+        check(self._lib.tlfea_vbd_retrieve_lambda(self._h, dp(lam)))
+        return lam
+
+    def GetStats(self):
+        st = np.zeros(6)
+        check(self._lib.tlfea_vbd_get_stats(self._h, dp(st)))
+        return dict(outer=int(st[0]), sweeps=int(st[1]), norm_g=st[2], norm_c=st[3], ms=st[5])
