@@ -64,17 +64,24 @@ def test_t10_fixed_sweeps_match_oracle(matname):
     the same coloured recurrence; positions, velocities and multipliers agree to round-off."""
     X, o, d = t10_pair("beam_3x2x1", matname)
     kw = params(inner_tol=0.0, inner_rtol=0.0, outer_tol=0.0, max_outer=2, max_inner=15, convergence_check_interval=0)
+    if "damped" in matname:
+        # the local Hessian has no Kelvin-Voigt block (FEAT10DataFunc.cuh:295-395 adds the elastic K_aa only) while the
+        # residual carries the viscous stress: with eta = 1e5 the sweep is not a contraction and amplifies round-off,
+        # in any implementation; few sweeps without over-relaxation keep the comparison at round-off level
+        kw.update(max_inner=3, omega=1.0)
     s, oprm = vbd_pair(d, o, kw)
     for step in range(2):
         s.Solve()
         st_o = o.vbd_step(oprm)
         st = s.GetStats()
-        assert (st["outer"], st["sweeps"]) == (int(st_o[0]), int(st_o[1])) == (2, 30)
+        assert (st["outer"], st["sweeps"]) == (int(st_o[0]), int(st_o[1])) == (2, 2 * kw["max_inner"])
         xg = np.stack(d.RetrievePositionToCPU(), axis=1)
         xo = np.stack([o.x, o.y, o.z], axis=1)
         assert disp_err_ok(xg, xo, X), (matname, step)
         assert relerr(s.RetrieveVelocityToCPU(), o.v) < 1e-9
-        assert relerr(s.RetrieveLambdaToCPU(), o.lam) < 1e-9
+        # lambda += rho c with c = x - X a difference of O(1) coordinates: one ulp of x is worth rho * 2e-16 in lambda
+        lam_floor = kw["rho"] * 8 * np.finfo(np.float64).eps * np.abs(xo).max() * kw["max_outer"] * (step + 1)
+        assert np.abs(s.RetrieveLambdaToCPU() - o.lam).max() <= 1e-9 * np.abs(o.lam).max() + lam_floor
     del s
     d.Destroy()
 
@@ -90,8 +97,11 @@ def test_t10_driver_parameters_match_oracle(mesh):
         st_o = o.vbd_step(oprm)
         st = s.GetStats()
         assert (st["outer"], st["sweeps"]) == (int(st_o[0]), int(st_o[1])), (st, st_o)
-        assert abs(st["norm_g"] - st_o[2]) <= 1e-7 * max(st_o[2], 1e-12) + 1e-9
-        assert abs(st["norm_c"] - st_o[3]) <= 1e-7 * st_o[3] + 1e-18
+        # g holds h rho c on the pinned nodes, c = x - X a difference of O(1) coordinates: an ulp of x is worth
+        # h rho 2e-16 there, whatever the implementation
+        g_floor = 1e-3 * 1e14 * np.finfo(np.float64).eps * np.abs(X).max()
+        assert abs(st["norm_g"] - st_o[2]) <= 1e-9 * st_o[2] + g_floor
+        assert abs(st["norm_c"] - st_o[3]) <= 1e-9 * st_o[3] + np.finfo(np.float64).eps * np.abs(X).max()  # same floor
         xg = np.stack(d.RetrievePositionToCPU(), axis=1)
         xo = np.stack([o.x, o.y, o.z], axis=1)
         assert disp_err_ok(xg, xo, X), (mesh, step)
@@ -137,12 +147,24 @@ def test_ancf_fixed_sweeps_match_oracle(pname, group_size):
 
 
 def test_vbd_rejects_general_linear_constraints():
-    from tests.test_gpu_ancf import PROBLEMS, SVK_D, make_pair
-    o, d = make_pair(PROBLEMS["beam3243"](), SVK_D, with_constraints=False)
+    """The reference's VBD knows pinned nodes only (its fixed map, SyncedVBD.cu:146-160, 1087-1135)."""
+    from tests.test_gpu_ancf import PROBLEMS, SVK
+    Q = tl.quadrature
+    kind, x, y, z, conn, (L, W, H), fixed, f_ext = PROBLEMS["beam3243"]()
+    d = tl.GPU_ANCF3243_Data(len(x) // 4, conn.shape[0])
+    d.Initialize()
+    d.SetExternalForce(f_ext)
+    d.Setup(L, W, H, Q.gauss_xi_m_6, Q.gauss_xi_3, Q.gauss_eta_2, Q.gauss_zeta_2, Q.weight_xi_m_6, Q.weight_xi_3,
+            Q.weight_eta_2, Q.weight_zeta_2, x, y, z, conn)
+    d.SetDensity(SVK["rho0"])
+    d.SetDamping(0.0, 0.0)
+    d.SetSVK(SVK["E"], SVK["nu"])
     b = tl.mesh_utils.LinearConstraintBuilder(3 * d.get_n_coef())
     b.AddFixedDof(0, 0.0)
     csr = b.ToCSR()
     d.SetLinearConstraintsCSR(csr.offsets, csr.columns, csr.values, csr.rhs)
+    d.CalcDsDuPre()
+    d.CalcMassMatrix()
     s = tl.SyncedVBDSolver(d, d.get_n_constraint())
     s.Setup()
     with pytest.raises(tl.TlfeaError):
