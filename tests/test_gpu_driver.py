@@ -19,7 +19,7 @@ def test_cpp_driver_matches_oracle(tmp_path):
     if not os.path.exists(DRIVER):
         subprocess.check_call(["make", "-C", os.path.dirname(DRIVER)])
     csv = tmp_path / "hist.csv"
-    out = subprocess.run([DRIVER, "--res=2", "--steps=3", "--dt=1e-3", f"--mesh_dir={MESHES}", f"--csv_path={csv}"],
+    out = subprocess.run([DRIVER, "--res=2", "--steps=3", "--dt=1e-3", "--solver=newton", f"--mesh_dir={MESHES}", f"--csv_path={csv}"],
                          capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr
     rows = np.loadtxt(csv, delimiter=",", skiprows=1)
@@ -149,3 +149,41 @@ def test_cpp_facade_reference_unit_tests(tmp_path):
     assert out.returncode == 0, out.stdout + out.stderr
     assert "[FAIL]" not in out.stdout and out.stdout.count("[ OK ]") >= 39
     assert "=== Elem 0 Quadrature Point 11 detJ_ref=0.25 ===" in out.stdout and "Shape 7: " in out.stdout
+
+
+@pytest.mark.gpu
+def test_cpp_driver_vbd_matches_oracle(tmp_path):
+    """--solver=vbd of lib_bin/beam_sag/test_feat10_resolution.cc:377-391 ({1e-4,1e-4,1e-4,1e14,5,500,dt,omega 1.8,
+    1e-12,25,1}; Setup, SetParameters, InitializeColoring, InitializeMassDiagBlocks, InitializeFixedMap, Solve) vs the
+    oracle's restatement: the node history of the CSV."""
+    csv = tmp_path / "hist_vbd.csv"
+    out = subprocess.run([DRIVER, "--res=2", "--steps=2", "--dt=1e-3", "--solver=vbd", f"--mesh_dir={MESHES}", f"--csv_path={csv}"],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    rows = np.loadtxt(csv, delimiter=",", skiprows=1)
+    X, conn = load_mesh("res2")
+    fixed = fixed_x0(X)
+    f_ext = np.zeros(3 * X.shape[0])
+    face = np.where(np.abs(X[:, 0] - 3.0) < 1e-8)[0]
+    f_ext[3 * face] = 5000.0 / len(face)
+    o = make_oracle(X, conn, MATERIALS["svk"], fixed, f_ext)
+    o.vbd_coloring(1)
+    prm = orc.VbdParams(1e-4, 1e-4, 1e-4, 1e14, 5, 500, 1e-3, 1.8, 1e-12, 25, 1)
+    for step in range(2):
+        o.vbd_step(prm)
+        ref = o.x[89]
+        assert abs(rows[step, 1] - ref) <= 1e-10 * np.max(np.abs(o.x - X[:, 0])) + 8e-16 * abs(ref)
+
+
+@pytest.mark.gpu
+def test_cpp_driver_default_solver_is_adamw(tmp_path):
+    """The reference driver's default --solver is adamw (test_feat10_resolution.cc:47) with the res-dependent
+    parameters of :394-416; --omega is validated like there."""
+    csv = tmp_path / "hist_adamw.csv"
+    out = subprocess.run([DRIVER, "--res=2", "--steps=1", "--dt=1e-3", f"--mesh_dir={MESHES}", f"--csv_path={csv}"],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    rows = np.loadtxt(csv, delimiter=",", skiprows=1).reshape(-1, 2)
+    assert rows.shape == (1, 2) and np.isfinite(rows[0, 1]) and abs(rows[0, 1] - 3.0) < 1e-3 and rows[0, 1] != 3.0
+    bad = subprocess.run([DRIVER, "--solver=vbd", "--omega=-1"], capture_output=True, text=True)
+    assert bad.returncode == 1 and "Invalid --omega" in bad.stderr

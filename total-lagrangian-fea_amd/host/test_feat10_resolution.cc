@@ -1,8 +1,10 @@
 // test_feat10_resolution -- the reference's T10 beam driver flow (lib_bin/beam_sag/test_feat10_resolution.cc:
-// 209-431, Newton branch) on the MI355X engine, same flags and CSV schema (`step,x_position`, 17 digits).
-//   ./test_feat10_resolution --mesh_dir=tests/golden/meshes --res=2 --steps=5 --dt=1e-3 [--csv] [--csv_path=...]
+// 209-431) on the MI355X engine, same flags, solver kinds, parameters and CSV schema (`step,x_position`, 17 digits).
+//   ./test_feat10_resolution --mesh_dir=tests/golden/meshes --res=2 --steps=5 --dt=1e-3 [--solver=adamw|newton|vbd]
+//                            [--omega=1.8] [--csv] [--csv_path=...]
 #include <cmath>
 #include <iomanip>
+#include <limits>
 
 #include "tlfea_facade.h"
 
@@ -12,7 +14,8 @@ struct Options {
   int res = 0, steps = 50;
   double dt = 1e-3;
   bool write_csv = false;
-  std::string csv_path, mesh_dir = "data/meshes/T10/resolution";
+  std::string csv_path, mesh_dir = "data/meshes/T10/resolution", solver = "adamw";  // default of the reference (:47)
+  double omega = std::numeric_limits<double>::quiet_NaN();                          // VBD only (:50)
 };
 bool StartsWith(const std::string& s, const std::string& p) { return s.rfind(p, 0) == 0; }
 bool ParseArgs(int argc, char** argv, Options& o) {
@@ -24,7 +27,14 @@ bool ParseArgs(int argc, char** argv, Options& o) {
     else if (a == "--csv") o.write_csv = true;
     else if (StartsWith(a, "--csv_path=")) { o.csv_path = a.substr(11); o.write_csv = true; }
     else if (StartsWith(a, "--mesh_dir=")) o.mesh_dir = a.substr(11);
-    else if (StartsWith(a, "--solver=")) { if (a.substr(9) != "newton") { std::cerr << "only --solver=newton is built\n"; return false; } }
+    else if (StartsWith(a, "--solver=")) {
+      o.solver = a.substr(9);
+      if (o.solver != "newton" && o.solver != "vbd" && o.solver != "adamw") { std::cerr << "Invalid --solver: " << o.solver << "\n"; return false; }
+    }
+    else if (StartsWith(a, "--omega=")) {
+      o.omega = std::atof(a.c_str() + 8);
+      if (!(o.omega > 0.0)) { std::cerr << "Invalid --omega: " << a.substr(8) << "\n"; return false; }
+    }
     else { std::cerr << "Unknown argument: " << a << std::endl; return false; }
   }
   return true;
@@ -73,27 +83,63 @@ int main(int argc, char** argv) {
   data.CalcConstraintData();
   data.ConvertToCSR_ConstraintJacT();
   data.BuildConstraintJacobianCSR();
-  data.CalcP();
-  data.CalcInternalForce();
+  if (opt.solver != "adamw") {  // :330-333
+    data.CalcP();
+    data.CalcInternalForce();
+  }
 
   std::ofstream csv;
   if (opt.write_csv) {
-    csv.open(opt.csv_path.empty() ? "node_x_history_feat10_res" + res_str + "_newton.csv" : opt.csv_path);
+    csv.open(opt.csv_path.empty() ? "node_x_history_feat10_res" + res_str + "_" + opt.solver + ".csv" : opt.csv_path);
     csv << std::fixed << std::setprecision(17) << "step,x_position\n";
   }
-  SyncedNewtonParams params = {1e-4, 1e-4, 1e-4, 1e14, 5, 10, opt.dt};  // :365
-  SyncedNewtonSolver solver(&data, data.get_n_constraint());
-  solver.Setup();
-  solver.SetParameters(&params);
-  solver.AnalyzeHessianSparsity();
-  solver.SetFixedSparsityPattern(true);
-  for (int step = 0; step < opt.steps; ++step) {
-    solver.Solve();
+  auto record_step = [&](int step) {
     tlfea::VectorXd x, y, z;
     data.RetrievePositionToCPU(x, y, z);
     std::cout << "Step " << step << ": node " << plot_target_node << " x = " << std::setprecision(17)
               << x(plot_target_node) << std::endl;
     if (opt.write_csv) csv << step << "," << x(plot_target_node) << "\n";
+  };
+  if (opt.solver == "newton") {
+    SyncedNewtonParams params = {1e-4, 1e-4, 1e-4, 1e14, 5, 10, opt.dt};  // :365
+    SyncedNewtonSolver solver(&data, data.get_n_constraint());
+    solver.Setup();
+    solver.SetParameters(&params);
+    solver.AnalyzeHessianSparsity();
+    solver.SetFixedSparsityPattern(true);
+    for (int step = 0; step < opt.steps; ++step) {
+      solver.Solve();
+      record_step(step);
+    }
+  } else if (opt.solver == "vbd") {
+    const double omega = std::isnan(opt.omega) ? 1.8 : opt.omega;  // :378-380
+    SyncedVBDParams params = {1e-4, 1e-4, 1e-4, 1e14, 5, 500, opt.dt, omega, 1e-12, 25, 1};
+    SyncedVBDSolver solver(&data, data.get_n_constraint());
+    solver.Setup();
+    solver.SetParameters(&params);
+    solver.InitializeColoring();
+    solver.InitializeMassDiagBlocks();
+    solver.InitializeFixedMap();
+    for (int step = 0; step < opt.steps; ++step) {
+      solver.Solve();
+      record_step(step);
+    }
+  } else {
+    // :394-416 (lr 2.5e-4 / decay 0.998 from res 8 up)
+    const bool fine = opt.res >= 8;
+    if (opt.res != 0 && opt.res != 2 && opt.res != 4 && opt.res != 8 && opt.res != 16) {
+      std::cerr << "Unsupported resolution" << std::endl;
+      return 1;
+    }
+    SyncedAdamWNocoopParams params = {fine ? 2.5e-4 : 2e-4, 0.9, 0.999, 1e-8, 1e-4, fine ? 0.998 : 0.995, 1e-1,
+                                      1e-6, 1e14, 5, 800, opt.dt, 20, 1e-4};
+    SyncedAdamWNocoopSolver solver(&data, data.get_n_constraint());
+    solver.Setup();
+    solver.SetParameters(&params);
+    for (int step = 0; step < opt.steps; ++step) {
+      solver.Solve();
+      record_step(step);
+    }
   }
   data.Destroy();
   return 0;

@@ -964,6 +964,46 @@ class SyncedNesterovSolver : public SolverBase {
   tlfea_nesterov_t a_ = nullptr;
 };
 
+// SyncedVBDSolver (SyncedVBD.cuh:13-330): vertex block descent
+struct SyncedVBDParams {
+  double inner_tol, inner_rtol, outer_tol, rho;
+  int max_outer, max_inner;
+  double time_step;
+  double omega;
+  double hess_eps;
+  int convergence_check_interval;
+  int color_group_size;
+};
+class SyncedVBDSolver : public SolverBase {
+ public:
+  SyncedVBDSolver(ElementBase* data, int n_constraints) {
+    TLFEA_HANDLE_ERROR(tlfea_vbd_create(static_cast<GPU_FEAT10_Data*>(data)->h, n_constraints, &a_));
+  }
+  ~SyncedVBDSolver() override { tlfea_vbd_destroy(a_); }
+  void Setup() { TLFEA_HANDLE_ERROR(tlfea_vbd_setup(a_)); }
+  void SetParameters(void* params) override {
+    const SyncedVBDParams* p = static_cast<SyncedVBDParams*>(params);
+    tlfea_vbd_params c{p->inner_tol, p->inner_rtol, p->outer_tol, p->rho, p->max_outer, p->max_inner, p->time_step,
+                       p->omega, p->hess_eps, p->convergence_check_interval, p->color_group_size};
+    TLFEA_HANDLE_ERROR(tlfea_vbd_set_parameters(a_, &c));
+  }
+  void InitializeColoring() { TLFEA_HANDLE_ERROR(tlfea_vbd_initialize_coloring(a_)); }
+  void InitializeMassDiagBlocks() { TLFEA_HANDLE_ERROR(tlfea_vbd_initialize_mass_diag_blocks(a_)); }
+  void InitializeFixedMap() { TLFEA_HANDLE_ERROR(tlfea_vbd_initialize_fixed_map(a_)); }
+  void OneStepVBD() { TLFEA_HANDLE_ERROR(tlfea_vbd_solve(a_)); }
+  void Solve() override { OneStepVBD(); }
+  int GetNumColors() const {
+    int nc = 0;
+    TLFEA_SOFT(tlfea_vbd_coloring_sizes(a_, &nc, nullptr));
+    return nc;
+  }
+  double* GetVelocityGuessDevicePtr() const { return tlfea_vbd_velocity_guess_device_ptr(a_); }
+  void SetVerbose(int v) { tlfea_vbd_set_verbose(a_, v); }
+
+ private:
+  tlfea_vbd_t a_ = nullptr;
+};
+
 // SyncedAdamWNocoopSolver (SyncedAdamWNocoop.cuh:20-198); SyncedAdamWParams field order of SyncedAdamW.cuh:27-34
 struct SyncedAdamWParams {
   double lr, beta1, beta2, eps, weight_decay, lr_decay;
