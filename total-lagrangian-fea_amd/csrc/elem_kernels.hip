@@ -1027,7 +1027,7 @@ __device__ __forceinline__ void vbd_diag_block(const double F[3][3], const doubl
     }
 }
 
-template <int S, int Q>
+template <int S, int Q, int LPN>
 __global__ __launch_bounds__(256) void vbd_color_kernel(ElemView m, Material mat, Incidence inc,
                                                         const int* __restrict__ nodes, int count,
                                                         const double* __restrict__ mval, const double* __restrict__ f_ext,
@@ -1038,9 +1038,11 @@ __global__ __launch_bounds__(256) void vbd_color_kernel(ElemView m, Material mat
                                                         const double* __restrict__ xp, const double* __restrict__ yp,
                                                         const double* __restrict__ zp, double* v, double* x, double* y,
                                                         double* z) {
-  const int lane = threadIdx.x & 63;
-  const int slot = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  if (slot >= count) return;  // whole wave
+  // LPN lanes per node (16 | 32 | 64, chosen per colour from its nodes' item counts: mid-edge nodes of a tet mesh
+  // have 20-40 items, corner nodes 100+); a group's lanes stay together through the shuffles below
+  const int lane = threadIdx.x & (LPN - 1);
+  const int slot = blockIdx.x * (256 / LPN) + threadIdx.x / LPN;
+  if (slot >= count) return;  // whole group
   const int i = nodes[slot];
   const double inv_h = 1.0 / h;
   const bool damp = (mat.eta != 0.0 || mat.lamd != 0.0);
@@ -1048,7 +1050,7 @@ __global__ __launch_bounds__(256) void vbd_color_kernel(ElemView m, Material mat
 #pragma unroll
   for (int k = 0; k < 12; k++) acc[k] = 0.0;
   // mass row (consistent mass, all neighbours)
-  for (int k = inc.off[i] + lane; k < inc.off[i + 1]; k += 64) {
+  for (int k = inc.off[i] + lane; k < inc.off[i + 1]; k += LPN) {
     const int j = inc.cols[k];
     const double mij = mval[k];
 #pragma unroll
@@ -1056,7 +1058,7 @@ __global__ __launch_bounds__(256) void vbd_color_kernel(ElemView m, Material mat
   }
   // element items
   const int i0 = inc.n2e_off[i], n_items = (inc.n2e_off[i + 1] - i0) * Q;
-  for (int w = lane; w < n_items; w += 64) {
+  for (int w = lane; w < n_items; w += LPN) {
     const int k = w / Q, q = w - k * Q;
     const int code = inc.n2e[i0 + k];
     const int e = code / S, a = code - e * S;
@@ -1118,7 +1120,7 @@ __global__ __launch_bounds__(256) void vbd_color_kernel(ElemView m, Material mat
       for (int cc = 0; cc < 3; cc++) acc[3 + 3 * r + cc] += K[r][cc];
   }
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1)
+  for (int o = LPN / 2; o > 0; o >>= 1)
 #pragma unroll
     for (int k = 0; k < 12; k++) acc[k] += __shfl_xor(acc[k], o);
   if (lane != 0) return;
@@ -1173,18 +1175,31 @@ __global__ __launch_bounds__(256) void vbd_color_kernel(ElemView m, Material mat
   z[i] = xpi[2] + vn[2] * h;
 }
 
-void launch_vbd_color(hipStream_t s, const ElemView& m, const Material& mat, const Incidence& inc, const int* nodes,
-                      int count, const double* mval, const double* f_ext, const int* fixed_slot, const double* xt,
-                      const double* yt, const double* zt, const double* lam, double h, double rho, double omega,
-                      double hess_eps, const double* v_prev, const double* xp, const double* yp, const double* zp,
-                      double* v, double* x, double* y, double* z) {
-  if (count <= 0) return;
-  const dim3 grid((count + 3) / 4), block(256);
+template <int S, int Q>
+static void launch_vbd_color_t(hipStream_t s, int lanes, const ElemView& m, const Material& mat, const Incidence& inc,
+                               const int* nodes, int count, const double* mval, const double* f_ext, const int* fixed_slot,
+                               const double* xt, const double* yt, const double* zt, const double* lam, double h, double rho,
+                               double omega, double hess_eps, const double* v_prev, const double* xp, const double* yp,
+                               const double* zp, double* v, double* x, double* y, double* z) {
+  const dim3 block(256), grid((count + 256 / lanes - 1) / (256 / lanes));
 #define TLFEA_VBD_ARGS m, mat, inc, nodes, count, mval, f_ext, fixed_slot, xt, yt, zt, lam, h, rho, omega, hess_eps, v_prev, xp, yp, zp, v, x, y, z
-  if (m.S == 10) hipLaunchKernelGGL((vbd_color_kernel<10, 5>), grid, block, 0, s, TLFEA_VBD_ARGS);
-  else if (m.S == 8) hipLaunchKernelGGL((vbd_color_kernel<8, 12>), grid, block, 0, s, TLFEA_VBD_ARGS);
-  else hipLaunchKernelGGL((vbd_color_kernel<16, 48>), grid, block, 0, s, TLFEA_VBD_ARGS);
+  if (lanes == 16) hipLaunchKernelGGL((vbd_color_kernel<S, Q, 16>), grid, block, 0, s, TLFEA_VBD_ARGS);
+  else if (lanes == 32) hipLaunchKernelGGL((vbd_color_kernel<S, Q, 32>), grid, block, 0, s, TLFEA_VBD_ARGS);
+  else hipLaunchKernelGGL((vbd_color_kernel<S, Q, 64>), grid, block, 0, s, TLFEA_VBD_ARGS);
 #undef TLFEA_VBD_ARGS
+}
+
+void launch_vbd_color(hipStream_t s, int lanes, const ElemView& m, const Material& mat, const Incidence& inc,
+                      const int* nodes, int count, const double* mval, const double* f_ext, const int* fixed_slot,
+                      const double* xt, const double* yt, const double* zt, const double* lam, double h, double rho,
+                      double omega, double hess_eps, const double* v_prev, const double* xp, const double* yp,
+                      const double* zp, double* v, double* x, double* y, double* z) {
+  if (count <= 0) return;
+#define TLFEA_VBD_FWD s, lanes, m, mat, inc, nodes, count, mval, f_ext, fixed_slot, xt, yt, zt, lam, h, rho, omega, hess_eps, v_prev, xp, yp, zp, v, x, y, z
+  if (m.S == 10) launch_vbd_color_t<10, 5>(TLFEA_VBD_FWD);
+  else if (m.S == 8) launch_vbd_color_t<8, 12>(TLFEA_VBD_FWD);
+  else launch_vbd_color_t<16, 48>(TLFEA_VBD_FWD);
+#undef TLFEA_VBD_FWD
 }
 
 }  // namespace tlfea

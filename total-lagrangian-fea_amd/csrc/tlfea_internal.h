@@ -64,8 +64,8 @@ void launch_tangent_blocks(hipStream_t s, const ElemView& m, const Material& mat
 void launch_assemble_rows(hipStream_t s, int N, int S, int maxdeg, const Incidence& inc, const double* Kbuf,
                           const double* mval, double inv_h, const int* fixed_slot, const double* nw,
                           double penalty, double* Hval);
-void launch_vbd_color(hipStream_t s, const ElemView& m, const Material& mat, const Incidence& inc, const int* nodes,
-                      int count, const double* mval, const double* f_ext, const int* fixed_slot, const double* xt,
+void launch_vbd_color(hipStream_t s, int lanes /*16|32|64 per node*/, const ElemView& m, const Material& mat,
+                      const Incidence& inc, const int* nodes, int count, const double* mval, const double* f_ext, const int* fixed_slot, const double* xt,
                       const double* yt, const double* zt, const double* lam, double h, double rho, double omega,
                       double hess_eps, const double* v_prev, const double* xp, const double* yp, const double* zp,
                       double* v, double* x, double* y, double* z);

@@ -35,15 +35,14 @@ inline void vbd_build_coloring(int S, int E, int N, const int* conn, const int* 
   std::iota(order.begin(), order.end(), 0);
   std::sort(order.begin(), order.end(), [&degrees](int a, int b) { return degrees[a] > degrees[b]; });
   o.colors.assign((size_t)N, -1);
-  std::vector<char> used((size_t)N + 1);
+  std::vector<int> used((size_t)N + 1, -1);  // used[c] == v: colour c is taken around v (no table clear per node)
   for (int v : order) {
-    std::fill(used.begin(), used.end(), 0);
     for (int k = off[v]; k < off[v + 1]; k++) {
       const int c = o.colors[cols[k]];
-      if (cols[k] != v && c >= 0) used[c] = 1;
+      if (cols[k] != v && c >= 0) used[c] = v;
     }
     int c = 0;
-    while (used[c]) ++c;
+    while (used[c] == v) ++c;
     o.colors[v] = c;
     o.n_colors = std::max(o.n_colors, c + 1);
   }
