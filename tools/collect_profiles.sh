@@ -15,6 +15,12 @@ F=$(find $O/pmc_fetch -name "*counter_collection.csv" | head -1); W=$(find $O/pm
 python3 tools/summarize_pmc.py "$F" "$W" > $O/pmc_summary.txt || exit 1
 cp profiles/r01_configB_pmc_hbm.csv $O/
 S=$(find $O/kt -name "*kernel_stats.csv" | head -1); cp "$S" $O/r01_configB_kernel_stats.csv
+# SyncedVBD sweep (config C): kernel trace of tools/vbd_bench.py + its JSON lines
+rocprofv3 --kernel-trace --stats -d $O/kt_vbd -o run --output-format csv -- python3 tools/vbd_bench.py C > $O/kv.log 2>&1 || { tail -20 $O/kv.log; exit 1; }
+SV=$(find $O/kt_vbd -name "*kernel_stats.csv" | head -1); cp "$SV" $O/r01_vbd_configC_kernel_stats.csv
+rm -rf $O/kt_vbd
+python3 tools/vbd_bench.py B C > $O/r01_vbd_sweep.json 2> $O/vbd.err || { tail -20 $O/vbd.err; exit 1; }
+echo "vbd done"
 # keep only the small summaries in gpurun_out (the raw traces are tens of MB)
 rm -rf $O/kt $O/pmc_fetch $O/pmc_write
 python3 bench.py > $O/r01_bench_configB.json 2> $O/bench_B.err || { tail -20 $O/bench_B.err; exit 1; }
