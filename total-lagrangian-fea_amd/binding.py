@@ -1,7 +1,9 @@
 """ctypes binding of libtlfea_hip.so -- argument/return types for every symbol in include/tlfea_c.h."""
 import ctypes as C
+import importlib.util
 import os
 import re
+import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TLFEA_LIB_PATH") or os.path.join(_HERE, "libtlfea_hip.so")  # override: A/B experiments
@@ -52,6 +54,27 @@ def exported_symbols():
     return sorted(set(re.findall(r"\b(tlfea_[a-z0-9_]+)\s*\(", txt)) - {"tlfea_allreduce_fn"})
 
 
+def _share_hip_runtime_with_torch():
+    """PyTorch-ROCm wheels bundle their own libamdhip64 / libhsa-runtime64 and link them by UNVERSIONED file name.  If
+    this library has already mapped /opt/rocm's copies (soname libamdhip64.so.7), a later `import torch` therefore maps
+    the wheel's copies as a SECOND HIP runtime in the process -- and that one finds no GPU ("No HIP GPUs are
+    available").  Mapping the wheel's copies first makes both sides resolve to one runtime, in either import order.
+    Nothing of torch is imported or executed here; TLFEA_SYSTEM_HIP=1 keeps /opt/rocm's runtime."""
+    if "torch" in sys.modules or os.environ.get("TLFEA_SYSTEM_HIP"):
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return
+        libdir = os.path.join(list(spec.submodule_search_locations)[0], "lib")
+        for name in ("libhsa-runtime64.so", "libamdhip64.so"):
+            path = os.path.join(libdir, name)
+            if os.path.exists(path):
+                C.CDLL(path, mode=C.RTLD_GLOBAL)
+    except OSError:
+        pass  # no usable bundled runtime: the system one is used
+
+
 def load_library():
     """dlopen the HIP library; fails loudly when it has not been built (no CPU path exists)."""
     global _LIB
@@ -60,6 +83,7 @@ def load_library():
     if not os.path.exists(LIB_PATH):
         raise TlfeaError(f"{LIB_PATH} is missing: build it with `make -C {_HERE}` "
                          "(or python -c 'import __graft_entry__ as g; g.build()').")
+    _share_hip_runtime_with_torch()
     lib = C.CDLL(LIB_PATH)
     lib.tlfea_last_error.restype = C.c_char_p
     for name in ("tlfea_t10_x12_device_ptr", "tlfea_t10_y12_device_ptr", "tlfea_t10_z12_device_ptr",
