@@ -10,6 +10,7 @@
 #include <climits>
 #include <cmath>
 #include <initializer_list>
+#include <set>
 #include <stdexcept>
 #include <utility>
 #include <cstdio>
@@ -225,6 +226,66 @@ class GridMeshGenerator {
   int nx_ = 0, ny_ = 0;
   std::vector<std::pair<int, int>> elems_;
 };
+
+// Vertex colouring helpers of SyncedVBDSolver (cpu_utils.h:13-58, cpu_utils.cc:18-123).  element_connectivity:
+// n_elem x nodes_per_elem; greedy colouring in std::sort's "degree descending" order, as the reference.
+inline std::vector<std::set<int>> BuildVertexAdjacency(const tlfea::MatrixXi& element_connectivity, int n_nodes) {
+  std::vector<std::set<int>> adj(static_cast<size_t>(n_nodes));
+  for (int e = 0; e < element_connectivity.rows(); e++)
+    for (int i = 0; i < element_connectivity.cols(); i++)
+      for (int j = i + 1; j < element_connectivity.cols(); j++) {
+        const int a = element_connectivity(e, i), b = element_connectivity(e, j);
+        adj[a].insert(b);
+        adj[b].insert(a);
+      }
+  return adj;
+}
+inline tlfea::VectorXi GreedyVertexColoring(const std::vector<std::set<int>>& adjacency) {
+  const int n = static_cast<int>(adjacency.size());
+  std::vector<int> degrees(static_cast<size_t>(n)), order(static_cast<size_t>(n));
+  for (int i = 0; i < n; i++) {
+    degrees[i] = static_cast<int>(adjacency[i].size());
+    order[i] = i;
+  }
+  std::sort(order.begin(), order.end(), [&degrees](int a, int b) { return degrees[a] > degrees[b]; });
+  tlfea::VectorXi colors(n);
+  for (int i = 0; i < n; i++) colors(i) = -1;
+  std::vector<int> taken(static_cast<size_t>(n) + 1, -1);  // taken[c] == v: colour c is used around v
+  for (int v : order) {
+    for (int nb : adjacency[v])
+      if (colors(nb) >= 0) taken[colors(nb)] = v;
+    int c = 0;
+    while (taken[c] == v) ++c;
+    colors(v) = c;
+  }
+  return colors;
+}
+inline bool ValidateColoring(const tlfea::MatrixXi& element_connectivity, const tlfea::VectorXi& colors) {
+  for (int e = 0; e < element_connectivity.rows(); e++) {
+    std::set<int> seen;
+    for (int i = 0; i < element_connectivity.cols(); i++) {
+      const int c = colors(element_connectivity(e, i));
+      if (!seen.insert(c).second) {
+        std::cerr << "Invalid coloring: element " << e << " has duplicate color " << c << std::endl;
+        return false;
+      }
+    }
+  }
+  return true;
+}
+inline std::vector<std::vector<std::pair<int, int>>> BuildNodeIncidence(const tlfea::MatrixXi& element_connectivity,
+                                                                        int n_nodes) {
+  std::vector<std::vector<std::pair<int, int>>> inc(static_cast<size_t>(n_nodes));
+  for (int e = 0; e < element_connectivity.rows(); e++)
+    for (int a = 0; a < element_connectivity.cols(); a++) inc[element_connectivity(e, a)].push_back({e, a});
+  return inc;
+}
+inline std::vector<std::vector<int>> BuildColorToNodes(const tlfea::VectorXi& colors, int n_colors) {
+  std::vector<std::vector<int>> out(static_cast<size_t>(n_colors));
+  for (int i = 0; i < colors.size(); i++)
+    if (colors(i) >= 0 && colors(i) < n_colors) out[colors(i)].push_back(i);
+  return out;
+}
 
 // ANCF3243_B12_matrix / ANCF3443_B12_matrix and their per-element packers (cpu_utils.cc:125-209, 211-441): (B^T)^-1
 inline void ANCF_B12_matrix_impl(int kind, double L, double W, double H, tlfea::MatrixXd& B_inv_out, int n_shape) {

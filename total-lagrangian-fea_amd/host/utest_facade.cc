@@ -279,6 +279,32 @@ void vtu_known_answers(const std::string& tmp) {
   check(ok && np == 5 && nc == 1, "ExportMeshWithDisplacement / ExportMeshToVTU: corner tets, |(3,4,0)| = 5 at node 1");
 }
 
+// cpu_utils.cc:18-123 colouring helpers (host only) on the 36-element bar
+void coloring_known_answers(const std::string& d) {
+  tlfea::MatrixXi elems;
+  tlfea::MatrixXd nodes;
+  const int n = ANCFCPUUtils::FEAT10_read_nodes(d + "/beam_3x2x1.1.node", nodes);
+  ANCFCPUUtils::FEAT10_read_elements(d + "/beam_3x2x1.1.ele", elems);
+  auto adj = ANCFCPUUtils::BuildVertexAdjacency(elems, n);
+  tlfea::VectorXi colors = ANCFCPUUtils::GreedyVertexColoring(adj);
+  int n_colors = 0;
+  for (int i = 0; i < n; i++) n_colors = std::max(n_colors, colors(i) + 1);
+  bool proper = true;
+  for (int i = 0; i < n; i++)
+    for (int nb : adj[i]) proper = proper && colors(nb) != colors(i);
+  check(n == 105 && ANCFCPUUtils::ValidateColoring(elems, colors) && proper && n_colors == 12,
+        "GreedyVertexColoring: proper colouring of beam_3x2x1 with 12 colours, ValidateColoring accepts it");
+  auto c2n = ANCFCPUUtils::BuildColorToNodes(colors, n_colors);
+  auto inc = ANCFCPUUtils::BuildNodeIncidence(elems, n);
+  size_t total = 0, incs = 0;
+  for (auto& v : c2n) total += v.size();
+  for (auto& v : inc) incs += v.size();
+  check(total == 105 && incs == 360 && inc[elems(3, 7)].size() >= 1, "BuildColorToNodes / BuildNodeIncidence cover every node / (element, local) pair");
+  tlfea::VectorXi bad = colors;
+  bad(elems(0, 1)) = bad(elems(0, 0));
+  check(!ANCFCPUUtils::ValidateColoring(elems, bad), "ValidateColoring rejects a repeated colour inside an element");
+}
+
 // mesh_manager.cc:180-220, 443-570 semantics (host only)
 void mesh_manager_known_answers(const std::string& d) {
   ANCFCPUUtils::MeshManager mm;
@@ -396,6 +422,7 @@ int main(int argc, char** argv) {
   }
   utils_known_answers();  // host-only
   mesh_manager_known_answers(data_dir);
+  coloring_known_answers(data_dir);
   vtu_known_answers(tmp_dir);
   if (tlfea_device_count() <= 0) {
     std::cerr << "No HIP device visible" << std::endl;
