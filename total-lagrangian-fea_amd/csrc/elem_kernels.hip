@@ -1027,8 +1027,8 @@ __device__ __forceinline__ void vbd_diag_block(const double F[3][3], const doubl
     }
 }
 
-template <int S, int Q, int LPN>
-__global__ __launch_bounds__(256) void vbd_color_kernel(ElemView m, Material mat, Incidence inc,
+template <int S, int Q, int LPN, int MODEL, bool DAMP>
+__global__ __launch_bounds__(256) void vbd_color_kernel(ElemView m, Material mat_in, Incidence inc,
                                                         const int* __restrict__ nodes, int count,
                                                         const double* __restrict__ mval, const double* __restrict__ f_ext,
                                                         const int* __restrict__ fixed_slot, const double* __restrict__ xt,
@@ -1037,7 +1037,7 @@ __global__ __launch_bounds__(256) void vbd_color_kernel(ElemView m, Material mat
                                                         double hess_eps, const double* __restrict__ v_prev,
                                                         const double* __restrict__ xp, const double* __restrict__ yp,
                                                         const double* __restrict__ zp, double* v, double* x, double* y,
-                                                        double* z) {
+                                                        double* z, const int* __restrict__ conn_rm, double* xyz) {
   // LPN lanes per node (16 | 32 | 64, chosen per colour from its nodes' item counts: mid-edge nodes of a tet mesh
   // have 20-40 items, corner nodes 100+); a group's lanes stay together through the shuffles below
   const int lane = threadIdx.x & (LPN - 1);
@@ -1045,7 +1045,9 @@ __global__ __launch_bounds__(256) void vbd_color_kernel(ElemView m, Material mat
   if (slot >= count) return;  // whole group
   const int i = nodes[slot];
   const double inv_h = 1.0 / h;
-  const bool damp = (mat.eta != 0.0 || mat.lamd != 0.0);
+  Material mat = mat_in;
+  mat.model = MODEL;  // compile-time material and damping: the other branch's registers (42 doubles of Mooney-Rivlin
+  constexpr bool damp = DAMP;  // state, the 9 of Fdot) are not reserved -- occupancy is what hides the gathers here
   double acc[12];
 #pragma unroll
   for (int k = 0; k < 12; k++) acc[k] = 0.0;
@@ -1066,8 +1068,10 @@ __global__ __launch_bounds__(256) void vbd_color_kernel(ElemView m, Material mat
     double F[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, Fd[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
 #pragma unroll 2
     for (int b = 0; b < S; b++) {
-      const int c = m.conn[(size_t)b * m.E + e];
-      const double X[3] = {x[c], y[c], z[c]};
+      // element-major connectivity and interleaved coordinates (kept by the solver next to the engine's column-major /
+      // SoA arrays): one cache line per element and per node instead of S and 3
+      const int c = conn_rm[(size_t)e * S + b];
+      const double X[3] = {xyz[3 * c], xyz[3 * c + 1], xyz[3 * c + 2]};
       const double hb[3] = {g[b], g[S + b], g[2 * S + b]};
 #pragma unroll
       for (int r = 0; r < 3; r++)
@@ -1170,35 +1174,71 @@ __global__ __launch_bounds__(256) void vbd_color_kernel(ElemView m, Material mat
   v[3 * i] = vn[0];
   v[3 * i + 1] = vn[1];
   v[3 * i + 2] = vn[2];
-  x[i] = xpi[0] + vn[0] * h;  // vbd_update_pos_from_vel_color
-  y[i] = xpi[1] + vn[1] * h;
-  z[i] = xpi[2] + vn[2] * h;
+  const double xn[3] = {xpi[0] + vn[0] * h, xpi[1] + vn[1] * h, xpi[2] + vn[2] * h};  // vbd_update_pos_from_vel_color
+  x[i] = xn[0];
+  y[i] = xn[1];
+  z[i] = xn[2];
+  xyz[3 * i] = xn[0];
+  xyz[3 * i + 1] = xn[1];
+  xyz[3 * i + 2] = xn[2];
 }
 
-template <int S, int Q>
+__global__ void interleave_xyz_kernel(int N, const double* __restrict__ x, const double* __restrict__ y,
+                                      const double* __restrict__ z, double* __restrict__ xyz) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  xyz[3 * i] = x[i];
+  xyz[3 * i + 1] = y[i];
+  xyz[3 * i + 2] = z[i];
+}
+void launch_interleave_xyz(hipStream_t s, int N, const double* x, const double* y, const double* z, double* xyz) {
+  hipLaunchKernelGGL(interleave_xyz_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, x, y, z, xyz);
+}
+
+template <int S, int Q, int MODEL, bool DAMP>
 static void launch_vbd_color_t(hipStream_t s, int lanes, const ElemView& m, const Material& mat, const Incidence& inc,
                                const int* nodes, int count, const double* mval, const double* f_ext, const int* fixed_slot,
                                const double* xt, const double* yt, const double* zt, const double* lam, double h, double rho,
                                double omega, double hess_eps, const double* v_prev, const double* xp, const double* yp,
-                               const double* zp, double* v, double* x, double* y, double* z) {
+                               const double* zp, double* v, double* x, double* y, double* z, const int* conn_rm,
+                               double* xyz) {
   const dim3 block(256), grid((count + 256 / lanes - 1) / (256 / lanes));
-#define TLFEA_VBD_ARGS m, mat, inc, nodes, count, mval, f_ext, fixed_slot, xt, yt, zt, lam, h, rho, omega, hess_eps, v_prev, xp, yp, zp, v, x, y, z
-  if (lanes == 16) hipLaunchKernelGGL((vbd_color_kernel<S, Q, 16>), grid, block, 0, s, TLFEA_VBD_ARGS);
-  else if (lanes == 32) hipLaunchKernelGGL((vbd_color_kernel<S, Q, 32>), grid, block, 0, s, TLFEA_VBD_ARGS);
-  else hipLaunchKernelGGL((vbd_color_kernel<S, Q, 64>), grid, block, 0, s, TLFEA_VBD_ARGS);
+#define TLFEA_VBD_ARGS m, mat, inc, nodes, count, mval, f_ext, fixed_slot, xt, yt, zt, lam, h, rho, omega, hess_eps, v_prev, xp, yp, zp, v, x, y, z, conn_rm, xyz
+  if (lanes == 16) hipLaunchKernelGGL((vbd_color_kernel<S, Q, 16, MODEL, DAMP>), grid, block, 0, s, TLFEA_VBD_ARGS);
+  else if (lanes == 32) hipLaunchKernelGGL((vbd_color_kernel<S, Q, 32, MODEL, DAMP>), grid, block, 0, s, TLFEA_VBD_ARGS);
+  else hipLaunchKernelGGL((vbd_color_kernel<S, Q, 64, MODEL, DAMP>), grid, block, 0, s, TLFEA_VBD_ARGS);
 #undef TLFEA_VBD_ARGS
+}
+
+template <int S, int Q>
+static void launch_vbd_color_m(hipStream_t s, int lanes, const ElemView& m, const Material& mat, const Incidence& inc,
+                               const int* nodes, int count, const double* mval, const double* f_ext, const int* fixed_slot,
+                               const double* xt, const double* yt, const double* zt, const double* lam, double h, double rho,
+                               double omega, double hess_eps, const double* v_prev, const double* xp, const double* yp,
+                               const double* zp, double* v, double* x, double* y, double* z, const int* conn_rm,
+                               double* xyz) {
+  const bool damp = mat.eta != 0.0 || mat.lamd != 0.0;
+#define TLFEA_VBD_FWD s, lanes, m, mat, inc, nodes, count, mval, f_ext, fixed_slot, xt, yt, zt, lam, h, rho, omega, hess_eps, v_prev, xp, yp, zp, v, x, y, z, conn_rm, xyz
+  if (mat.model == kMooneyRivlin) {
+    if (damp) launch_vbd_color_t<S, Q, kMooneyRivlin, true>(TLFEA_VBD_FWD);
+    else launch_vbd_color_t<S, Q, kMooneyRivlin, false>(TLFEA_VBD_FWD);
+  } else {
+    if (damp) launch_vbd_color_t<S, Q, kSVK, true>(TLFEA_VBD_FWD);
+    else launch_vbd_color_t<S, Q, kSVK, false>(TLFEA_VBD_FWD);
+  }
+#undef TLFEA_VBD_FWD
 }
 
 void launch_vbd_color(hipStream_t s, int lanes, const ElemView& m, const Material& mat, const Incidence& inc,
                       const int* nodes, int count, const double* mval, const double* f_ext, const int* fixed_slot,
                       const double* xt, const double* yt, const double* zt, const double* lam, double h, double rho,
                       double omega, double hess_eps, const double* v_prev, const double* xp, const double* yp,
-                      const double* zp, double* v, double* x, double* y, double* z) {
+                      const double* zp, double* v, double* x, double* y, double* z, const int* conn_rm, double* xyz) {
   if (count <= 0) return;
-#define TLFEA_VBD_FWD s, lanes, m, mat, inc, nodes, count, mval, f_ext, fixed_slot, xt, yt, zt, lam, h, rho, omega, hess_eps, v_prev, xp, yp, zp, v, x, y, z
-  if (m.S == 10) launch_vbd_color_t<10, 5>(TLFEA_VBD_FWD);
-  else if (m.S == 8) launch_vbd_color_t<8, 12>(TLFEA_VBD_FWD);
-  else launch_vbd_color_t<16, 48>(TLFEA_VBD_FWD);
+#define TLFEA_VBD_FWD s, lanes, m, mat, inc, nodes, count, mval, f_ext, fixed_slot, xt, yt, zt, lam, h, rho, omega, hess_eps, v_prev, xp, yp, zp, v, x, y, z, conn_rm, xyz
+  if (m.S == 10) launch_vbd_color_m<10, 5>(TLFEA_VBD_FWD);
+  else if (m.S == 8) launch_vbd_color_m<8, 12>(TLFEA_VBD_FWD);
+  else launch_vbd_color_m<16, 48>(TLFEA_VBD_FWD);
 #undef TLFEA_VBD_FWD
 }
 

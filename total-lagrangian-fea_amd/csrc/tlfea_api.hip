@@ -2416,6 +2416,8 @@ struct tlfea_vbd_s {
   VbdColoring col;
   std::vector<int> color_lanes;  // lanes per node of each colour's launch (16 | 32 | 64)
   int* d_color_nodes = nullptr;
+  int* d_conn_rm = nullptr;   // [E][S] element-major copy of the connectivity for the sweep's gathers
+  double* d_xyz = nullptr;    // [N][3] interleaved copy of the current coordinates, kept in step by the sweep
   bool coloring_ready = false, mass_ready = false, fixed_ready = false;
   int colored_group_size = 0;
   hipGraphExec_t sweep_graph = nullptr;
@@ -2440,6 +2442,8 @@ extern "C" int tlfea_vbd_destroy(tlfea_vbd_t a) {
   if (!a) return 0;
   vbd_drop_graph(a);
   if (a->d_color_nodes) (void)hipFree(a->d_color_nodes);
+  if (a->d_conn_rm) (void)hipFree(a->d_conn_rm);
+  if (a->d_xyz) (void)hipFree(a->d_xyz);
   (void)tlfea_newton_destroy(a->core);
   delete a;
   return 0;
@@ -2473,6 +2477,14 @@ extern "C" int tlfea_vbd_initialize_coloring(tlfea_vbd_t a) {
   a->d_color_nodes = nullptr;
   TRY(dmalloc(&a->d_color_nodes, (size_t)d->N));
   HIP_TRY(hipMemcpy(a->d_color_nodes, a->col.color_nodes.data(), (size_t)d->N * sizeof(int), hipMemcpyHostToDevice));
+  if (!a->d_conn_rm) {
+    std::vector<int> rm((size_t)d->E * d->S);
+    for (int e = 0; e < d->E; e++)
+      for (int b = 0; b < d->S; b++) rm[(size_t)e * d->S + b] = d->h_conn[(size_t)b * d->E + e];
+    TRY(dmalloc(&a->d_conn_rm, rm.size()));
+    HIP_TRY(hipMemcpy(a->d_conn_rm, rm.data(), rm.size() * sizeof(int), hipMemcpyHostToDevice));
+    TRY(dmalloc(&a->d_xyz, 3 * (size_t)d->N));
+  }
   // lanes per node: enough for the colour's average (element, point) item count in one or two rounds
   a->color_lanes.assign((size_t)a->col.n_colors, 64);
   for (int k = 0; k < a->col.n_colors; k++) {
@@ -2543,7 +2555,7 @@ static void vbd_enqueue_sweep(tlfea_vbd_t a, hipStream_t st) {
       launch_vbd_color(st, a->color_lanes[k], d->view(), d->mat, d->inc(), a->d_color_nodes + c.color_offsets[k],
                        c.color_offsets[k + 1] - c.color_offsets[k], d->d_mval, d->d_fext, pinned ? d->d_fixed_slot : nullptr,
                        d->d_xt, d->d_yt, d->d_zt, s->d_lam, p.time_step, p.rho, p.omega, p.hess_eps, s->d_vprev, s->d_xp,
-                       s->d_yp, s->d_zp, s->d_v, d->d_x, d->d_y, d->d_z);
+                       s->d_yp, s->d_zp, s->d_v, d->d_x, d->d_y, d->d_z, a->d_conn_rm, a->d_xyz);
     }
 }
 
@@ -2593,6 +2605,7 @@ extern "C" int tlfea_vbd_solve(tlfea_vbd_t a) {
   for (int outer = 0; outer < p.max_outer; outer++) {
     n_outer++;
     launch_positions_from_prev(s->stream, N, s->d_v, s->d_xp, s->d_yp, s->d_zp, dt, d->d_x, d->d_y, d->d_z);
+    launch_interleave_xyz(s->stream, N, d->d_x, d->d_y, d->d_z, a->d_xyz);
     double R0 = -1.0;
     if (p.convergence_check_interval > 0) {
       TRY(eval_gradient(s, &R0));

@@ -68,7 +68,8 @@ void launch_vbd_color(hipStream_t s, int lanes /*16|32|64 per node*/, const Elem
                       const Incidence& inc, const int* nodes, int count, const double* mval, const double* f_ext, const int* fixed_slot, const double* xt,
                       const double* yt, const double* zt, const double* lam, double h, double rho, double omega,
                       double hess_eps, const double* v_prev, const double* xp, const double* yp, const double* zp,
-                      double* v, double* x, double* y, double* z);
+                      double* v, double* x, double* y, double* z, const int* conn_rm /*[E][S]*/, double* xyz /*[N][3]*/);
+void launch_interleave_xyz(hipStream_t s, int N, const double* x, const double* y, const double* z, double* xyz);
 void launch_mass_values(hipStream_t s, const ElemView& m, const Incidence& inc, const double* qx,
                         const double* qy, const double* qz, double rho0, double* mval);
 void launch_grad(hipStream_t s, int N, const Incidence& inc, const double* fbuf, const double* mval,
