@@ -996,6 +996,11 @@ static int resident_blocks(K kernel, int tpb) {  // workgroups of this kernel re
   return per_cu * cus;
 }
 
+static int c32_bandwidth_rows() {
+  static const int n = std::getenv("TLFEA_C32_BW_N") ? std::atoi(std::getenv("TLFEA_C32_BW_N")) : 100000;
+  return n;
+}
+
 template <typename T, int LL>
 static void launch_cheb32_t(hipStream_t s, int N, const Incidence& inc, const void* B8, const void* B1,
                             const float* Dinv_f, const double* sc, const float* d_old, const double* coef,
@@ -1006,7 +1011,7 @@ static void launch_cheb32_t(hipStream_t s, int N, const Incidence& inc, const vo
     constexpr int TPB = 1024, G = TPB / LL;
     const dim3 g(std::max(1, std::min(kNPart, (N + G - 1) / G))), b(TPB);
     hipLaunchKernelGGL((cheb32_kernel<T, LL, true, TPB, false>), g, b, 0, s, TLFEA_C32_ARGS);
-  } else if (N > 200000) {  // bandwidth regime: two rows per lane group, 256-thread workgroups, resident grid
+  } else if (N > c32_bandwidth_rows()) {  // bandwidth regime: two rows per lane group, 256-thread workgroups, resident grid
     constexpr int TPB = 256, G = TPB / LL;
     static const int resident = resident_blocks(cheb32_kernel<T, LL, false, TPB, true>, TPB);
     const dim3 g(std::max(1, std::min(resident, (N + 2 * G - 1) / (2 * G)))), b(TPB);
@@ -1023,14 +1028,21 @@ void launch_cheb32(hipStream_t s, int N, int nnz_coef, const Incidence& inc, con
                    const float* Dinv_f, const double* sc, const float* d_old, const double* coef, float* d_new,
                    const float* z, float* z_new, const float* res, float* res_new, const double* r, double* z_out,
                    double* rz_part, bool last) {
-  const int L = lp_lanes(N, nnz_coef) >= 32 ? 32 : 16;
+  // lanes per row: two blocks per lane and round; the vertex level of the p-multigrid cycle has ~15 blocks per row
+  // (8 lanes hold them in one round with every lane busy), quadratic tets ~30 (16 lanes), the ANCF shells 100+ (32)
+  static const int forced = std::getenv("TLFEA_C32_LANES") ? std::atoi(std::getenv("TLFEA_C32_LANES")) : 0;
+  const double avg = (double)nnz_coef / std::max(1, N);
+  int L = lp_lanes(N, nnz_coef) >= 32 ? 32 : (avg <= 18.0 ? 8 : 16);
+  if (forced == 8 || forced == 16 || forced == 32) L = forced;
 #define TLFEA_C32(T, LL) \
   launch_cheb32_t<T, LL>(s, N, inc, B8, B1, Dinv_f, sc, d_old, coef, d_new, z, z_new, res, res_new, r, z_out, rz_part, last)
   if (bits == 16) {
     if (L == 32) TLFEA_C32(_Float16, 32);
+    else if (L == 8) TLFEA_C32(_Float16, 8);
     else TLFEA_C32(_Float16, 16);
   } else {
     if (L == 32) TLFEA_C32(float, 32);
+    else if (L == 8) TLFEA_C32(float, 8);
     else TLFEA_C32(float, 16);
   }
 #undef TLFEA_C32
