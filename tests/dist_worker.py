@@ -149,15 +149,28 @@ def main():
     ap.add_argument("--out", default="")
     ap.add_argument("--precond", default="exchange", choices=("local", "exchange"),
                     help="rank-local polynomial preconditioner (owners set) or one exchange per polynomial step")
+    ap.add_argument("--backend", default="gloo", choices=("gloo", "nccl"),
+                    help="nccl = RCCL on device buffers (the production exchange); one rank per GPU")
+    ap.add_argument("--fake-iface", action="store_true",
+                    help="world_size 1: declare a band of nodes an 'interface' of multiplicity 1, so that every exchange "
+                         "of the partitioned path runs (as an identity all-reduce) on the one GPU of the test box")
     args = ap.parse_args()
     import torch
     import torch.distributed as dist
-    dist.init_process_group("gloo")
+    if args.backend == "nccl":
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+    dist.init_process_group(args.backend)
     rank, world = dist.get_rank(), dist.get_world_size()
     X, conn, fixed, f_ext = problem(args.mesh)
     m = helpers.MATERIALS["svk"]
     owner = par.slab_owner(X, conn, world)
     part = par.partition_from_global(X, conn, owner, rank, world)
+    if args.fake_iface:
+        assert world == 1
+        band = np.argsort(np.abs(X[:, 0] - 0.5 * X[:, 0].max()), kind="stable")[:40].astype(np.int32)
+        band.sort()
+        part = par.Partition(0, 1, part.X, part.conn, part.l2g, band, np.arange(len(band)), len(band), part.node_weight,
+                             part.elem_ids, part.node_owned)
     fixed_loc = part.localize_nodes(fixed)
     f_share = part.share_of_nodal_vector(f_ext)
     prm = orc.NewtonParams(1e-4, 0.0, 1e-6, 1e14, 5, 12, 1e-3)
@@ -168,7 +181,8 @@ def main():
         counts = [oracle_dist_step(o, part, ex, prm, f_share) for _ in range(args.steps)]
         x_loc = np.stack([o.x, o.y, o.z], axis=1)
     else:
-        torch.cuda.set_device(0)
+        if args.backend != "nccl":
+            torch.cuda.set_device(0)
         d = helpers.make_gpu(part.X, part.conn, m, fixed_loc, f_share)
         s = tl.SyncedNewtonSolver(d, d.get_n_constraint())
         s.SetParameters(tl.SyncedNewtonParams(1e-4, 0.0, 1e-6, 1e14, 5, 12, 1e-3))
@@ -218,7 +232,7 @@ def main():
         print(json.dumps(report), flush=True)
         if args.out:
             json.dump(report, open(args.out, "w"))
-    flag = torch.tensor([1 if ok else 0])
+    flag = torch.tensor([1 if ok else 0], device="cuda" if args.backend == "nccl" else "cpu")
     dist.broadcast(flag, 0)
     dist.destroy_process_group()
     sys.exit(0 if int(flag[0]) == 1 else 1)

@@ -116,6 +116,16 @@ def test_rank_local_preconditioner_needs_fewer_collectives(tmp_path):
 
 
 @pytest.mark.gpu
+def test_rccl_exchange_path_single_rank(tmp_path):
+    """The production exchange (torch.distributed 'nccl' = RCCL, in place on the engine's device buffers, default-stream
+    ordering, no host copy) cannot run with two ranks on the one GPU of the test box; with world_size 1 and a band of
+    nodes declared an interface of multiplicity 1 every collective of the partitioned path still runs -- as an identity
+    all-reduce -- and the step must reproduce the un-partitioned oracle."""
+    rep = launch(1, ["--engine", "hip", "--mesh", "res2", "--steps", "2", "--backend", "nccl", "--fake-iface"], tmp_path)
+    assert rep["ok"] and rep["n_iface"] == 40 and rep["collectives"] > 100, rep
+
+
+@pytest.mark.gpu
 def test_bench_two_ranks_rehearsal(tmp_path):
     """bench.py --gpus 2 end to end (slab construction, interface attach, timing loop, JSON line) with the gloo
     rehearsal backend: both ranks share the one GPU of the test box; production uses nccl (RCCL)."""
