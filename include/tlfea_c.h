@@ -174,6 +174,12 @@ int tlfea_newton_get_linsolve_info(tlfea_newton_t s, int *cheb_degree, int *cheb
 /* preconditioner a solve would use now: 0 block-Jacobi, 1 Chebyshev polynomial, 2 p-multigrid */
 int tlfea_newton_get_precond(tlfea_newton_t s);
 /* degree of the coarse-level polynomial of the p-multigrid cycle (grows with the coarse mesh); 0 without p-multigrid */
+/* third level of the cycle (rigid-body-mode aggregates of the vertex level; present on large meshes): number of
+ * aggregates (0: two levels), 3x3 blocks of H3 (2 nodes per aggregate: translation, rotation), polynomial degree there;
+ * retrieve: aggregate of every vertex node, x_i - c_A (zero where rotations are off), usable-rotation flags, the
+ * level-3 block CSR and H3 = P2^T Hc P2 in the DOF-level layout of the other levels */
+int tlfea_newton_pmg3_sizes(tlfea_newton_t s, int *n_aggregates, int *nnz_blocks, int *degree);
+int tlfea_newton_pmg3_retrieve(tlfea_newton_t s, int *agg, double *rvec, int *active, int *off3, int *cols3, double *H3);
 int tlfea_newton_pmg_coarse_degree(tlfea_newton_t s);
 /* p-multigrid test hooks: coarse sizes; parent map [N] x 2, coarse block-CSR pattern and Hc = P^T H P of the current H
  * (9 nnz values in the DOF-level layout of H: node row -> [d][k][e]) */

@@ -171,5 +171,179 @@ inline bool pmg_build(int N, int E, const int* conn, const int* off, const int* 
   return true;
 }
 
+// ---- third level: aggregation of the vertex mesh with rigid-body modes ---------------------------------------------
+// The vertex (P1) problem is still elasticity on the full mesh; a polynomial on it needs a degree that grows with the
+// mesh (31 at config C).  Below it sits one more Galerkin level: greedy aggregates of a vertex and its neighbours
+// (about 15 vertices), each carrying the six rigid-body modes of its members about their centroid,
+//     u_i = t_A + w_A x (x_i - c_A)      (i in A),
+// stored as TWO level-3 "nodes" per aggregate (2A: translation t_A, 2A+1: rotation w_A), so that the 3x3-block
+// kernels of the other levels run unchanged on it.  Integer bookkeeping in a fixed order, like the level above.
+struct AggHost {
+  int Nc = 0, Na = 0, N3 = 0, nnz3 = 0, n_pairs = 0;
+  std::vector<int> agg;                    // [Nc] aggregate of every vertex node
+  std::vector<double> rvec;                // [3 Nc] x_i - c_A (zeroed where the aggregate's rotations are unusable)
+  std::vector<int> active;                 // [Na] 1: rotation modes usable (members span 3-D)
+  std::vector<int> mem_off, mem;           // members of every aggregate, ascending
+  std::vector<int> off3, cols3, diag3;     // level-3 node adjacency (N3 = 2 Na rows, sorted columns)
+  std::vector<int> pair_A, pair_pos, pair_B;  // aggregate pairs (A, B in adj(A)): A, position of B in adj(A), B
+  std::vector<int> pcon_off, pcon_base, pcon_deg, pcon_i, pcon_j;  // vertex-level blocks feeding every pair
+};
+
+// c_off / c_cols: vertex adjacency (sorted, self included); X: [3][Nc] reference coordinates of the vertex nodes
+inline bool agg_build(int Nc, const int* c_off, const int* c_cols, const double* X, AggHost& o) {
+  o = AggHost();
+  o.Nc = Nc;
+  o.agg.assign((size_t)Nc, -1);
+  int Na = 0;
+  // pass 1: a vertex whose whole neighbourhood is free founds an aggregate with it
+  for (int i = 0; i < Nc; i++) {
+    bool free_nb = true;
+    for (int k = c_off[i]; k < c_off[i + 1] && free_nb; k++) free_nb = o.agg[c_cols[k]] < 0;
+    if (!free_nb) continue;
+    for (int k = c_off[i]; k < c_off[i + 1]; k++) o.agg[c_cols[k]] = Na;
+    Na++;
+  }
+  // pass 2: leftovers join the neighbouring aggregate of pass 1 they touch most often (ties: lowest id)
+  {
+    std::vector<int> joined(o.agg);
+    std::vector<int> cnt;
+    for (int i = 0; i < Nc; i++) {
+      if (o.agg[i] >= 0) continue;
+      int best = -1, best_n = 0;
+      for (int k = c_off[i]; k < c_off[i + 1]; k++) {
+        const int a = o.agg[c_cols[k]];
+        if (a < 0) continue;
+        int n = 0;
+        for (int k2 = c_off[i]; k2 < c_off[i + 1]; k2++) n += o.agg[c_cols[k2]] == a;
+        if (n > best_n || (n == best_n && a < best)) {
+          best = a;
+          best_n = n;
+        }
+      }
+      joined[i] = best;
+    }
+    o.agg.swap(joined);
+  }
+  // pass 3: what is still free (a vertex all of whose neighbours were leftovers) founds small aggregates
+  for (int i = 0; i < Nc; i++) {
+    if (o.agg[i] >= 0) continue;
+    o.agg[i] = Na;
+    for (int k = c_off[i]; k < c_off[i + 1]; k++)
+      if (o.agg[c_cols[k]] < 0) o.agg[c_cols[k]] = Na;
+    Na++;
+  }
+  o.Na = Na;
+  o.N3 = 2 * Na;
+  if (Na < 1 || Na >= Nc) return false;
+  // members, centroids, offsets from the centroid, usable rotations
+  o.mem_off.assign((size_t)Na + 1, 0);
+  for (int i = 0; i < Nc; i++) o.mem_off[o.agg[i] + 1]++;
+  for (int a = 0; a < Na; a++) o.mem_off[a + 1] += o.mem_off[a];
+  o.mem.resize((size_t)Nc);
+  {
+    std::vector<int> cur(o.mem_off.begin(), o.mem_off.end() - 1);
+    for (int i = 0; i < Nc; i++) o.mem[cur[o.agg[i]]++] = i;
+  }
+  o.rvec.assign((size_t)3 * Nc, 0.0);
+  o.active.assign((size_t)Na, 0);
+  for (int a = 0; a < Na; a++) {
+    double c[3] = {0, 0, 0};
+    const int n = o.mem_off[a + 1] - o.mem_off[a];
+    for (int t = o.mem_off[a]; t < o.mem_off[a + 1]; t++)
+      for (int d = 0; d < 3; d++) c[d] += X[(size_t)d * Nc + o.mem[t]];
+    for (int d = 0; d < 3; d++) c[d] /= n;
+    double M[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};  // rotational inertia sum(|r|^2 I - r r^T): singular for collinear members
+    for (int t = o.mem_off[a]; t < o.mem_off[a + 1]; t++) {
+      const int i = o.mem[t];
+      double r[3];
+      for (int d = 0; d < 3; d++) r[d] = o.rvec[(size_t)3 * i + d] = X[(size_t)d * Nc + i] - c[d];
+      const double rr = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
+      for (int d = 0; d < 3; d++)
+        for (int e = 0; e < 3; e++) M[d][e] += (d == e ? rr : 0.0) - r[d] * r[e];
+    }
+    const double det = M[0][0] * (M[1][1] * M[2][2] - M[1][2] * M[2][1]) - M[0][1] * (M[1][0] * M[2][2] - M[1][2] * M[2][0]) +
+                       M[0][2] * (M[1][0] * M[2][1] - M[1][1] * M[2][0]);
+    const double tr = M[0][0] + M[1][1] + M[2][2];
+    o.active[a] = (n >= 3 && tr > 0.0 && det > 1e-6 * tr * tr * tr / 27.0) ? 1 : 0;
+    if (!o.active[a])
+      for (int t = o.mem_off[a]; t < o.mem_off[a + 1]; t++)
+        for (int d = 0; d < 3; d++) o.rvec[(size_t)3 * o.mem[t] + d] = 0.0;
+  }
+  // aggregate adjacency and the pairs
+  std::vector<int> aoff((size_t)Na + 1, 0), aadj;
+  {
+    std::vector<int> tmp;
+    for (int a = 0; a < Na; a++) {
+      tmp.clear();
+      for (int t = o.mem_off[a]; t < o.mem_off[a + 1]; t++) {
+        const int i = o.mem[t];
+        for (int k = c_off[i]; k < c_off[i + 1]; k++) tmp.push_back(o.agg[c_cols[k]]);
+      }
+      std::sort(tmp.begin(), tmp.end());
+      tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
+      aadj.insert(aadj.end(), tmp.begin(), tmp.end());
+      aoff[a + 1] = (int)aadj.size();
+    }
+  }
+  o.n_pairs = (int)aadj.size();
+  o.pair_A.resize((size_t)o.n_pairs);
+  o.pair_pos.resize((size_t)o.n_pairs);
+  o.pair_B = aadj;
+  for (int a = 0; a < Na; a++)
+    for (int p = aoff[a]; p < aoff[a + 1]; p++) {
+      o.pair_A[p] = a;
+      o.pair_pos[p] = p - aoff[a];
+    }
+  // level-3 node pattern: row 2A+s holds 2B, 2B+1 for every B in adj(A)
+  o.off3.assign((size_t)o.N3 + 1, 0);
+  for (int a = 0; a < Na; a++)
+    for (int s2 = 0; s2 < 2; s2++) o.off3[2 * a + s2 + 1] = 2 * (aoff[a + 1] - aoff[a]);
+  for (int r = 0; r < o.N3; r++) o.off3[r + 1] += o.off3[r];
+  o.nnz3 = o.off3[o.N3];
+  o.cols3.resize((size_t)o.nnz3);
+  o.diag3.resize((size_t)o.N3);
+  for (int a = 0; a < Na; a++)
+    for (int s2 = 0; s2 < 2; s2++) {
+      const int r = 2 * a + s2;
+      for (int p = aoff[a]; p < aoff[a + 1]; p++) {
+        o.cols3[o.off3[r] + 2 * (p - aoff[a])] = 2 * aadj[p];
+        o.cols3[o.off3[r] + 2 * (p - aoff[a]) + 1] = 2 * aadj[p] + 1;
+        if (aadj[p] == a) o.diag3[r] = 2 * (p - aoff[a]) + s2;
+      }
+    }
+  // contributions: every vertex-level block (i, j) feeds the pair (agg i, agg j), ascending block order
+  o.pcon_off.assign((size_t)o.n_pairs + 1, 0);
+  const int nnz2 = c_off[Nc];
+  std::vector<int> blk_pair((size_t)nnz2);
+  for (int i = 0; i < Nc; i++) {
+    const int a = o.agg[i];
+    for (int k = c_off[i]; k < c_off[i + 1]; k++) {
+      const int b = o.agg[c_cols[k]];
+      const int* lo = aadj.data() + aoff[a];
+      const int* hi = aadj.data() + aoff[a + 1];
+      const int pos = (int)(std::lower_bound(lo, hi, b) - lo);
+      blk_pair[k] = aoff[a] + pos;
+      o.pcon_off[(size_t)blk_pair[k] + 1]++;
+    }
+  }
+  for (int p = 0; p < o.n_pairs; p++) o.pcon_off[p + 1] += o.pcon_off[p];
+  o.pcon_base.resize((size_t)nnz2);
+  o.pcon_deg.resize((size_t)nnz2);
+  o.pcon_i.resize((size_t)nnz2);
+  o.pcon_j.resize((size_t)nnz2);
+  {
+    std::vector<int> cur(o.pcon_off.begin(), o.pcon_off.end() - 1);
+    for (int i = 0; i < Nc; i++)
+      for (int k = c_off[i]; k < c_off[i + 1]; k++) {
+        const int u = cur[blk_pair[k]]++;
+        o.pcon_base[u] = 9 * c_off[i] + 3 * (k - c_off[i]);
+        o.pcon_deg[u] = c_off[i + 1] - c_off[i];
+        o.pcon_i[u] = i;
+        o.pcon_j[u] = c_cols[k];
+      }
+  }
+  return true;
+}
+
 }  // namespace tlfea
 #endif

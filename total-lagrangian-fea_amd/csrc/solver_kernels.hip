@@ -1159,6 +1159,163 @@ void launch_pmg_prolong(hipStream_t s, int N, const int* par0, const int* par1, 
   hipLaunchKernelGGL(pmg_prolong_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, par0, par1, z_c, sc_c, sc_f, z_f, d_f);
 }
 
+// ---- third level (pmg_host.h agg_build): rigid-body-mode aggregation of the vertex level ---------------------------
+// Level-3 node 2A carries the translation t_A, node 2A+1 the rotation w_A of aggregate A;  u_i = t_A + w_A x r_i with
+// r_i = x_i - c_A, i.e. the prolongation blocks are W_i0 = I, W_i1 = -[r_i]x (r_i is stored as zero where the
+// aggregate's rotations are unusable, which switches them off everywhere below).
+__device__ __forceinline__ void cross3(const double a[3], const double b[3], double o[3]) {
+  o[0] = a[1] * b[2] - a[2] * b[1];
+  o[1] = a[2] * b[0] - a[0] * b[2];
+  o[2] = a[0] * b[1] - a[1] * b[0];
+}
+
+// H3 = P2^T Hc P2 by gather: one thread owns one aggregate pair (A, B) = four 3x3 blocks and adds the vertex-level
+// blocks (i in A, j in B) in ascending order (no atomics).  Both matrices in the DOF-level layout [row][d][k][e].
+__global__ __launch_bounds__(128) void agg_galerkin_kernel(int n_pairs, const int* __restrict__ pair_A,
+                                                          const int* __restrict__ pair_pos, const int* __restrict__ pair_B,
+                                                          const int* __restrict__ pcon_off, const int* __restrict__ pcon_base,
+                                                          const int* __restrict__ pcon_deg, const int* __restrict__ pcon_i,
+                                                          const int* __restrict__ pcon_j, const double* __restrict__ rvec,
+                                                          const int* __restrict__ active, const int* __restrict__ off3,
+                                                          const double* __restrict__ Hc, double* __restrict__ H3) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n_pairs) return;
+  double tt[3][3] = {{0}}, tr[3][3] = {{0}}, rt[3][3] = {{0}}, rr[3][3] = {{0}};
+  for (int u = pcon_off[p]; u < pcon_off[p + 1]; u++) {
+    const int deg3 = 3 * pcon_deg[u];
+    const double* Hi = Hc + pcon_base[u];
+    const double* ri = rvec + 3 * (size_t)pcon_i[u];
+    const double* rj = rvec + 3 * (size_t)pcon_j[u];
+    double K[3][3], KR[3][3];
+#pragma unroll
+    for (int d = 0; d < 3; d++)
+#pragma unroll
+      for (int e = 0; e < 3; e++) K[d][e] = Hi[(size_t)d * deg3 + e];
+    // KR = K (-[rj]x): row d of KR = -(K_d x rj)... (K [r]x)_de = sum_m K_dm [r]x_me, [r]x = [[0,-r2,r1],[r2,0,-r0],[-r1,r0,0]]
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+      KR[d][0] = -(K[d][1] * rj[2] - K[d][2] * rj[1]);
+      KR[d][1] = -(K[d][2] * rj[0] - K[d][0] * rj[2]);
+      KR[d][2] = -(K[d][0] * rj[1] - K[d][1] * rj[0]);
+    }
+    // W_i1^T M = [ri]x M: column e of the result = ri x (column e of M)
+#pragma unroll
+    for (int e = 0; e < 3; e++) {
+      const double ck[3] = {K[0][e], K[1][e], K[2][e]}, ckr[3] = {KR[0][e], KR[1][e], KR[2][e]};
+      double a[3], b[3];
+      cross3(ri, ck, a);
+      cross3(ri, ckr, b);
+#pragma unroll
+      for (int d = 0; d < 3; d++) {
+        tt[d][e] += K[d][e];
+        tr[d][e] += KR[d][e];
+        rt[d][e] += a[d];
+        rr[d][e] += b[d];
+      }
+    }
+  }
+  const int A = pair_A[p], B = pair_B[p], pos = pair_pos[p];
+  if (A == B && !active[A]) {  // unusable rotations: identity keeps the level-3 matrix definite, the modes stay at zero
+#pragma unroll
+    for (int d = 0; d < 3; d++)
+#pragma unroll
+      for (int e = 0; e < 3; e++) rr[d][e] = (d == e) ? 1.0 : 0.0;
+  }
+#pragma unroll
+  for (int s2 = 0; s2 < 2; s2++) {
+    const int row = 2 * A + s2, o3 = off3[row], deg3 = 3 * (off3[row + 1] - o3);
+#pragma unroll
+    for (int t2 = 0; t2 < 2; t2++) {
+      double* out = H3 + (size_t)9 * o3 + 3 * (2 * pos + t2);
+#pragma unroll
+      for (int d = 0; d < 3; d++)
+#pragma unroll
+        for (int e = 0; e < 3; e++)
+          out[(size_t)d * deg3 + e] = s2 == 0 ? (t2 == 0 ? tt[d][e] : tr[d][e]) : (t2 == 0 ? rt[d][e] : rr[d][e]);
+    }
+  }
+}
+void launch_agg_galerkin(hipStream_t s, int n_pairs, const int* pair_A, const int* pair_pos, const int* pair_B,
+                         const int* pcon_off, const int* pcon_base, const int* pcon_deg, const int* pcon_i,
+                         const int* pcon_j, const double* rvec, const int* active, const int* off3, const double* Hc,
+                         double* H3) {
+  hipLaunchKernelGGL(agg_galerkin_kernel, dim3((n_pairs + 127) / 128), dim3(128), 0, s, n_pairs, pair_A, pair_pos, pair_B,
+                     pcon_off, pcon_base, pcon_deg, pcon_i, pcon_j, rvec, active, off3, Hc, H3);
+}
+
+// r^_3 = S_3 P2^T S_2^-1 res^_2 ;  d = (S_3 D_3 S_3)^-1 r^_3 / theta_3 ; z = d ; res = r^_3   (16 lanes per level-3 node)
+__global__ __launch_bounds__(256) void agg_restrict_init_kernel(
+    int N3, const int* __restrict__ mem_off, const int* __restrict__ mem, const double* __restrict__ rvec,
+    const float* __restrict__ res2, const double* __restrict__ sc2, const double* __restrict__ sc3,
+    const float* __restrict__ Dinv3, const double* __restrict__ coef3, float* __restrict__ d3, float* __restrict__ z3,
+    float* __restrict__ res3) {
+  const int lane = threadIdx.x & 15;
+  const int I = blockIdx.x * 16 + (threadIdx.x >> 4);
+  if (I >= N3) return;
+  const int A = I >> 1, rot = I & 1;
+  double r[3] = {0.0, 0.0, 0.0};
+  for (int t = mem_off[A] + lane; t < mem_off[A + 1]; t += 16) {
+    const int n = mem[t];
+    const double v[3] = {(double)res2[3 * n] / sc2[3 * n], (double)res2[3 * n + 1] / sc2[3 * n + 1],
+                         (double)res2[3 * n + 2] / sc2[3 * n + 2]};
+    if (rot) {
+      double c[3];
+      cross3(rvec + 3 * (size_t)n, v, c);  // W_i1^T v = r_i x v
+      r[0] += c[0]; r[1] += c[1]; r[2] += c[2];
+    } else {
+      r[0] += v[0]; r[1] += v[1]; r[2] += v[2];
+    }
+  }
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) {
+    r[0] += __shfl_xor(r[0], o);
+    r[1] += __shfl_xor(r[1], o);
+    r[2] += __shfl_xor(r[2], o);
+  }
+  if (lane >= 3) return;
+  const int c = lane;
+  const float inv_theta = (float)coef3[0];
+  const float rs0 = (float)(r[0] * sc3[3 * I]), rs1 = (float)(r[1] * sc3[3 * I + 1]), rs2 = (float)(r[2] * sc3[3 * I + 2]);
+  const float* D = Dinv3 + (size_t)9 * I + 3 * c;
+  const float v = (D[0] * rs0 + D[1] * rs1 + D[2] * rs2) * inv_theta;
+  d3[3 * I + c] = v;
+  z3[3 * I + c] = v;
+  res3[3 * I + c] = (c == 0) ? rs0 : ((c == 1) ? rs1 : rs2);
+}
+void launch_agg_restrict_init(hipStream_t s, int N3, const int* mem_off, const int* mem, const double* rvec,
+                              const float* res2, const double* sc2, const double* sc3, const float* Dinv3,
+                              const double* coef3, float* d3, float* z3, float* res3) {
+  hipLaunchKernelGGL(agg_restrict_init_kernel, dim3((N3 + 15) / 16), dim3(256), 0, s, N3, mem_off, mem, rvec, res2, sc2,
+                     sc3, Dinv3, coef3, d3, z3, res3);
+}
+
+// corr^_2 = S_2^-1 P2 S_3 z^_3 ;  z^_2 += corr ; d_2 := corr
+__global__ __launch_bounds__(256) void agg_prolong_kernel(int Nc, const int* __restrict__ agg,
+                                                         const double* __restrict__ rvec, const float* __restrict__ z3,
+                                                         const double* __restrict__ sc3, const double* __restrict__ sc2,
+                                                         float* __restrict__ z2, float* __restrict__ d2) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= Nc) return;
+  const int A = agg[i];
+  double t[3], w[3], wr[3];
+#pragma unroll
+  for (int c = 0; c < 3; c++) {
+    t[c] = sc3[6 * A + c] * (double)z3[6 * A + c];
+    w[c] = sc3[6 * A + 3 + c] * (double)z3[6 * A + 3 + c];
+  }
+  cross3(w, rvec + 3 * (size_t)i, wr);  // u_i = t + w x r_i
+#pragma unroll
+  for (int c = 0; c < 3; c++) {
+    const float corr = (float)((t[c] + wr[c]) / sc2[3 * i + c]);
+    d2[3 * i + c] = corr;
+    z2[3 * i + c] += corr;
+  }
+}
+void launch_agg_prolong(hipStream_t s, int Nc, const int* agg, const double* rvec, const float* z3, const double* sc3,
+                        const double* sc2, float* z2, float* d2) {
+  hipLaunchKernelGGL(agg_prolong_kernel, dim3((Nc + 255) / 256), dim3(256), 0, s, Nc, agg, rvec, z3, sc3, sc2, z2, d2);
+}
+
 // the same step with the SpMV result q = H d_old already summed over ranks (multi-GPU path)
 template <bool LAST>
 __global__ __launch_bounds__(256) void cheb_update_kernel(int N, const double* __restrict__ Dinv,

@@ -869,6 +869,21 @@ struct tlfea_newton_s {
     double* d_coef = nullptr;  // [0..7] fine smoother, [8..] coarse polynomial
     double lam_c = 0.0;
     Incidence inc() const { return Incidence{nullptr, nullptr, nullptr, d_c_off, d_c_cols, d_c_diagpos}; }
+    // third level: rigid-body-mode aggregates of the vertex level (pmg_host.h agg_build); N3 = 2 Na nodes
+    struct Agg {
+      bool ok = false;
+      int Na = 0, N3 = 0, nnz3 = 0, n_pairs = 0;
+      int *d_agg = nullptr, *d_active = nullptr, *d_mem_off = nullptr, *d_mem = nullptr, *d_off3 = nullptr,
+          *d_cols3 = nullptr, *d_diag3 = nullptr, *d_pair_A = nullptr, *d_pair_pos = nullptr, *d_pair_B = nullptr,
+          *d_pcon_off = nullptr, *d_pcon_base = nullptr, *d_pcon_deg = nullptr, *d_pcon_i = nullptr, *d_pcon_j = nullptr;
+      double *d_rvec = nullptr, *d_H3 = nullptr, *d_D3 = nullptr, *d_Dinv3 = nullptr, *d_sc3 = nullptr,
+             *d_Dinv_s3 = nullptr, *d_eigv3 = nullptr, *d_q3 = nullptr, *d_p3 = nullptr;
+      void *d_B8 = nullptr, *d_B1 = nullptr;
+      int bits_alloc = 0;
+      float* d_f32 = nullptr;  // level-3 d, z^, res^ ping-pong pairs (6 x 3 N3) + (S D S)^-1 (9 N3)
+      double lam3 = 0.0;
+      Incidence inc() const { return Incidence{nullptr, nullptr, nullptr, d_off3, d_cols3, d_diag3}; }
+    } agg;
   } pmg;
   float* d_f32 = nullptr;  // single-precision polynomial (single GPU): d, z, res ping-pong pairs (6 x 3N) + (SDS)^-1 (9N)
   bool fixed_pattern = false, sparsity_done = false;
@@ -967,6 +982,12 @@ extern "C" int tlfea_newton_destroy(tlfea_newton_t s) {
                   m.d_con_off, m.d_con_base, m.d_con_deg, m.d_child_w, m.d_con_w, m.d_Hc, m.d_Dc, m.d_Dinv_c, m.d_sc_c,
                   m.d_Dinv_s_c, m.d_eigv_c, m.d_q_c, m.d_p_c, m.d_B8c, m.d_B1c, m.d_f32c, m.d_coef};
     for (void* q : pp)
+      if (q) (void)hipFree(q);
+    auto& g = m.agg;
+    void* gg[] = {g.d_agg, g.d_active, g.d_mem_off, g.d_mem, g.d_off3, g.d_cols3, g.d_diag3, g.d_pair_A, g.d_pair_pos,
+                  g.d_pair_B, g.d_pcon_off, g.d_pcon_base, g.d_pcon_deg, g.d_pcon_i, g.d_pcon_j, g.d_rvec, g.d_H3, g.d_D3,
+                  g.d_Dinv3, g.d_sc3, g.d_Dinv_s3, g.d_eigv3, g.d_q3, g.d_p3, g.d_B8, g.d_B1, g.d_f32};
+    for (void* q : gg)
       if (q) (void)hipFree(q);
   }
   if (s->d_coef) (void)hipFree(s->d_coef);
@@ -1507,6 +1528,25 @@ static double pmg_kappa_coarse(int kc) {
   return forced > 1.0 ? forced : 1.5 * kc * kc;
 }
 static const double kPmgKappaS = std::getenv("TLFEA_PMG_KAPPA_S") ? std::atof(std::getenv("TLFEA_PMG_KAPPA_S")) : 8.0;
+// third level: from this many vertex nodes on (TLFEA_PMG_LEVELS=2|3 forces), smoother interval of the vertex level
+// when it is no longer the coarsest, and the degree / interval of the level-3 polynomial
+static const int kPmgLevel3MinNodes = 20000;
+static int pmg_levels_wanted(int n_vertex) {
+  static const int forced = std::getenv("TLFEA_PMG_LEVELS") ? std::atoi(std::getenv("TLFEA_PMG_LEVELS")) : 0;
+  if (forced == 2 || forced == 3) return forced;
+  return n_vertex >= kPmgLevel3MinNodes ? 3 : 2;
+}
+static const double kPmgKappaS2 = std::getenv("TLFEA_PMG_KAPPA_S2") ? std::atof(std::getenv("TLFEA_PMG_KAPPA_S2")) : 8.0;
+static int pmg_level3_degree(int n3) {
+  static const int forced = std::getenv("TLFEA_PMG_KC3") ? std::atoi(std::getenv("TLFEA_PMG_KC3")) : 0;
+  if (forced > 1) return std::min(forced, kPmgMaxCoarseDeg - 4);
+  const double kc = 12.0 + 3.2 * (std::log2((double)std::max(2, n3)) - 11.1);
+  return std::max(8, std::min(kPmgMaxCoarseDeg - 4, (int)std::lround(kc)));
+}
+static double pmg_kappa_level3(int kc) {
+  static const double forced = std::getenv("TLFEA_PMG_KAPPA_C3") ? std::atof(std::getenv("TLFEA_PMG_KAPPA_C3")) : 0.0;
+  return forced > 1.0 ? forced : 1.5 * kc * kc;
+}
 
 template <typename T>
 static int upload_vec(T** dst, const std::vector<T>& v) {
@@ -1552,6 +1592,37 @@ static int pmg_prepare(tlfea_newton_t s) {
   TRY(dmalloc(&m.d_coef, (size_t)8 + 2 * kPmgMaxCoarseDeg));
   m.ok = true;
   if (s->verbose) std::printf("p-multigrid: %d fine nodes -> %d vertex nodes, %d coarse blocks\n", d->N, m.Nc, m.nnz_c);
+  if (pmg_levels_wanted(m.Nc) == 3) {
+    // reference coordinates of the vertex nodes (slot 0 of a coarse node's children is the vertex itself)
+    std::vector<double> xf((size_t)3 * d->N), Xv((size_t)3 * m.Nc);
+    D2H(xf.data(), d->d_xt, (size_t)d->N);
+    D2H(xf.data() + d->N, d->d_yt, (size_t)d->N);
+    D2H(xf.data() + 2 * (size_t)d->N, d->d_zt, (size_t)d->N);
+    for (int I = 0; I < m.Nc; I++) {
+      const int n = h.child[h.child_off[I]];
+      for (int c = 0; c < 3; c++) Xv[(size_t)c * m.Nc + I] = xf[(size_t)c * d->N + n];
+    }
+    AggHost a;
+    auto& g = m.agg;
+    if (agg_build(m.Nc, h.c_off.data(), h.c_cols.data(), Xv.data(), a)) {
+      g.Na = a.Na; g.N3 = a.N3; g.nnz3 = a.nnz3; g.n_pairs = a.n_pairs;
+      TRY(upload_vec(&g.d_agg, a.agg)); TRY(upload_vec(&g.d_active, a.active)); TRY(upload_vec(&g.d_rvec, a.rvec));
+      TRY(upload_vec(&g.d_mem_off, a.mem_off)); TRY(upload_vec(&g.d_mem, a.mem));
+      TRY(upload_vec(&g.d_off3, a.off3)); TRY(upload_vec(&g.d_cols3, a.cols3)); TRY(upload_vec(&g.d_diag3, a.diag3));
+      TRY(upload_vec(&g.d_pair_A, a.pair_A)); TRY(upload_vec(&g.d_pair_pos, a.pair_pos)); TRY(upload_vec(&g.d_pair_B, a.pair_B));
+      TRY(upload_vec(&g.d_pcon_off, a.pcon_off)); TRY(upload_vec(&g.d_pcon_base, a.pcon_base));
+      TRY(upload_vec(&g.d_pcon_deg, a.pcon_deg)); TRY(upload_vec(&g.d_pcon_i, a.pcon_i)); TRY(upload_vec(&g.d_pcon_j, a.pcon_j));
+      const size_t n3 = 3 * (size_t)g.N3;
+      TRY(dmalloc(&g.d_H3, (size_t)9 * g.nnz3));
+      TRY(dmalloc(&g.d_D3, (size_t)9 * g.N3)); TRY(dmalloc(&g.d_Dinv3, (size_t)9 * g.N3));
+      TRY(dmalloc(&g.d_sc3, n3)); TRY(dmalloc(&g.d_Dinv_s3, (size_t)9 * g.N3));
+      TRY(dmalloc(&g.d_eigv3, n3)); TRY(dmalloc(&g.d_q3, n3)); TRY(dmalloc(&g.d_p3, n3));
+      TRY(dmalloc(&g.d_f32, 6 * n3 + (size_t)9 * g.N3));
+      g.ok = true;
+      if (s->verbose)
+        std::printf("p-multigrid: third level, %d aggregates with rigid-body modes (%d nodes, %d blocks)\n", g.Na, g.N3, g.nnz3);
+    }
+  }
   return 0;
 }
 
@@ -1575,6 +1646,25 @@ static int pmg_build_level(tlfea_newton_t s) {
   launch_lp_scale(s->stream, m.Nc, m.d_Dc, m.d_Dinv_c, m.d_sc_c, m.d_Dinv_s_c);
   launch_lp_convert(s->stream, m.Nc, ic, m.d_Hc, m.d_sc_c, nullptr, m.d_Dc, m.d_B8c, m.d_B1c, bits);
   launch_to_float(s->stream, (size_t)9 * m.Nc, m.d_Dinv_s_c, m.d_f32c + (size_t)18 * m.Nc);
+  if (m.agg.ok) {  // third level: H3 = P2^T Hc P2, its scaling and low-precision copy
+    auto& g = m.agg;
+    launch_agg_galerkin(s->stream, g.n_pairs, g.d_pair_A, g.d_pair_pos, g.d_pair_B, g.d_pcon_off, g.d_pcon_base,
+                        g.d_pcon_deg, g.d_pcon_i, g.d_pcon_j, g.d_rvec, g.d_active, g.d_off3, m.d_Hc, g.d_H3);
+    if (g.bits_alloc != bits) {
+      if (g.d_B8) (void)hipFree(g.d_B8);
+      if (g.d_B1) (void)hipFree(g.d_B1);
+      g.d_B8 = g.d_B1 = nullptr;
+      HIP_TRY(hipMalloc(&g.d_B8, (size_t)g.nnz3 * 8 * (bits / 8)));
+      HIP_TRY(hipMalloc(&g.d_B1, (size_t)g.nnz3 * (bits / 8)));
+      g.bits_alloc = bits;
+    }
+    const Incidence i3 = g.inc();
+    launch_extract_diag(s->stream, g.N3, i3, g.d_H3, g.d_D3);
+    launch_invert_diag(s->stream, g.N3, g.d_D3, g.d_Dinv3);
+    launch_lp_scale(s->stream, g.N3, g.d_D3, g.d_Dinv3, g.d_sc3, g.d_Dinv_s3);
+    launch_lp_convert(s->stream, g.N3, i3, g.d_H3, g.d_sc3, nullptr, g.d_D3, g.d_B8, g.d_B1, bits);
+    launch_to_float(s->stream, (size_t)9 * g.N3, g.d_Dinv_s3, g.d_f32 + (size_t)18 * g.N3);
+  }
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -1613,6 +1703,50 @@ static int pmg_coefficients(tlfea_newton_t s) {
     h[2] = rho1 * rho0; h[3] = 2.0 * rho1 / delta;
     h[4] = 0.0; h[5] = 0.0;
     h[6] = 0.0; h[7] = 1.0 / theta;
+  }
+  if (m.agg.ok) {
+    // three levels: the vertex level smooths like the fine one (d_coef[8..15], same four pairs), the polynomial
+    // solve moves to level 3 (d_coef[16..]); lambda_max(D3^-1 H3) by the same warm-started power iteration
+    auto& g = m.agg;
+    const int n3 = 3 * g.N3;
+    const Incidence i3 = g.inc();
+    const bool cold3 = !(g.lam3 > 0.0);
+    if (cold3) HIP_TRY(hipMemcpyAsync(g.d_eigv3, g.d_sc3, (size_t)n3 * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
+    launch_norm2(s->stream, g.d_eigv3, nullptr, n3, part(s, 5), s->d_scal);
+    launch_scale_inv_sqrt(s->stream, n3, s->d_scal, g.d_eigv3);
+    for (int k = 0; k < (cold3 ? 16 : 2); k++) {
+      launch_spmv_dir_dot(s->stream, g.N3, i3, g.d_H3, g.d_eigv3, g.d_eigv3, 1, part(s, 1), part(s, 0), g.d_p3, g.d_q3,
+                          part(s, 2), false, false);
+      launch_apply_dinv(s->stream, g.N3, g.d_Dinv3, g.d_q3, g.d_eigv3);
+      launch_norm2(s->stream, g.d_eigv3, nullptr, n3, part(s, 5), s->d_scal);
+      launch_scale_inv_sqrt(s->stream, n3, s->d_scal, g.d_eigv3);
+    }
+    double s3 = 0.0;
+    TRY(fetch_scalar(s, s->d_scal, &s3));
+    if (!(s3 > 0.0)) return fail("p-multigrid: level-3 lambda_max estimate failed");
+    g.lam3 = std::sqrt(s3);
+    {
+      const double b = s->lam_safety * m.lam_c, a = b / kPmgKappaS2;
+      const double theta = 0.5 * (b + a), delta = 0.5 * (b - a), sigma = theta / delta;
+      const double rho0 = 1.0 / sigma, rho1 = 1.0 / (2.0 * sigma - rho0);
+      h[8] = 1.0 / theta; h[9] = 0.0;
+      h[10] = rho1 * rho0; h[11] = 2.0 * rho1 / delta;
+      h[12] = 0.0; h[13] = 0.0;
+      h[14] = 0.0; h[15] = 1.0 / theta;
+    }
+    const int k3 = pmg_level3_degree(g.N3);
+    const double b = s->lam_safety * g.lam3, a = b / pmg_kappa_level3(k3);
+    const double theta = 0.5 * (b + a), delta = 0.5 * (b - a), sigma = theta / delta;
+    double rho = 1.0 / sigma;
+    h[16] = 1.0 / theta; h[17] = 0.0;
+    for (int k = 1; k < k3; k++) {
+      const double rho_new = 1.0 / (2.0 * sigma - rho);
+      h[16 + 2 * k] = rho_new * rho;
+      h[16 + 2 * k + 1] = 2.0 * rho_new / delta;
+      rho = rho_new;
+    }
+    HIP_TRY(hipMemcpyAsync(m.d_coef, h, (size_t)(16 + 2 * k3) * sizeof(double), hipMemcpyHostToDevice, s->stream));
+    return 0;
   }
   const int kc = pmg_coarse_degree(m.Nc);
   {
@@ -1653,13 +1787,41 @@ static int pmg_apply(tlfea_newton_t s, const double* d_r, double* d_z, double* r
   // coarse correction
   launch_pmg_restrict_init(s->stream, Nc, m.d_child_off, m.d_child, m.d_child_w, f_r, s->d_sc, m.d_sc_c, Dinv_fc, cf + 8,
                            c_d, c_z, c_r);
-  const int kc = pmg_coarse_degree(Nc);
-  for (int k = 1; k < kc; k++) {
-    launch_cheb32(s->stream, Nc, m.nnz_c, inc_c, m.d_B8c, m.d_B1c, bits, Dinv_fc, m.d_sc_c, c_d, cf + 8 + 2 * k, c_d2, c_z,
-                  c_z2, c_r, c_r2, d_r, d_z, rz_part, false);
-    std::swap(c_d, c_d2);
-    std::swap(c_z, c_z2);
-    std::swap(c_r, c_r2);
+  if (m.agg.ok) {
+    // vertex level as a smoothing level: the fine level's sequence once more, with the level-3 polynomial inside
+    auto& g = m.agg;
+    const size_t n3 = 3 * (size_t)g.N3;
+    float *a_d = g.d_f32, *a_d2 = a_d + n3, *a_z = a_d2 + n3, *a_z2 = a_z + n3, *a_r = a_z2 + n3, *a_r2 = a_r + n3;
+    const float* Dinv_f3 = a_r2 + n3;
+    const Incidence inc_3 = g.inc();
+#define TLFEA_L2(dold, co, dnew, zold, znew, rold, rnew)                                                                  \
+  launch_cheb32(s->stream, Nc, m.nnz_c, inc_c, m.d_B8c, m.d_B1c, bits, Dinv_fc, m.d_sc_c, dold, co, dnew, zold, znew, rold, \
+                rnew, d_r, d_z, rz_part, false)
+    TLFEA_L2(c_d, cf + 10, c_d2, c_z, c_z2, c_r, c_r2);   // Chebyshev step
+    TLFEA_L2(c_d2, cf + 12, c_d, c_z2, c_z, c_r2, c_r);   // (0,0): residual of the result; z^, res^ back in c_z, c_r
+    launch_agg_restrict_init(s->stream, g.N3, g.d_mem_off, g.d_mem, g.d_rvec, c_r, m.d_sc_c, g.d_sc3, Dinv_f3, cf + 16, a_d,
+                             a_z, a_r);
+    const int k3 = pmg_level3_degree(g.N3);
+    for (int k = 1; k < k3; k++) {
+      launch_cheb32(s->stream, g.N3, g.nnz3, inc_3, g.d_B8, g.d_B1, bits, Dinv_f3, g.d_sc3, a_d, cf + 16 + 2 * k, a_d2, a_z,
+                    a_z2, a_r, a_r2, d_r, d_z, rz_part, false);
+      std::swap(a_d, a_d2);
+      std::swap(a_z, a_z2);
+      std::swap(a_r, a_r2);
+    }
+    launch_agg_prolong(s->stream, Nc, g.d_agg, g.d_rvec, a_z, g.d_sc3, m.d_sc_c, c_z, c_d);  // z^ += corr ; d := corr
+    TLFEA_L2(c_d, cf + 14, c_d2, c_z, c_z2, c_r, c_r2);   // (0, 1/theta): res^ -= Hs corr, restart
+    TLFEA_L2(c_d2, cf + 10, c_d, c_z2, c_z, c_r2, c_r);   // second term; the vertex-level result is in c_z
+#undef TLFEA_L2
+  } else {
+    const int kc = pmg_coarse_degree(Nc);
+    for (int k = 1; k < kc; k++) {
+      launch_cheb32(s->stream, Nc, m.nnz_c, inc_c, m.d_B8c, m.d_B1c, bits, Dinv_fc, m.d_sc_c, c_d, cf + 8 + 2 * k, c_d2, c_z,
+                    c_z2, c_r, c_r2, d_r, d_z, rz_part, false);
+      std::swap(c_d, c_d2);
+      std::swap(c_z, c_z2);
+      std::swap(c_r, c_r2);
+    }
   }
   launch_pmg_prolong(s->stream, N, m.d_par0, m.d_par1, c_z, m.d_sc_c, s->d_sc, f_z, f_d);  // z^ += corr ; d := corr
   // post-smooth: res^ -= Hs corr ; d0' = (SDS)^-1 res^/theta ; z^ += d0'   == one step with coefficients (0, 1/theta)
@@ -1886,6 +2048,39 @@ extern "C" int tlfea_newton_pmg_retrieve(tlfea_newton_t s, int* par0, int* par1,
   D2H(c_off, m.d_c_off, (size_t)nc + 1);
   D2H(c_cols, m.d_c_cols, (size_t)nnz);
   D2H(Hc, m.d_Hc, (size_t)9 * nnz);
+  return 0;
+}
+
+// third level (present from kPmgLevel3MinNodes vertex nodes on, or with TLFEA_PMG_LEVELS=3): sizes, and everything
+// needed to rebuild P2 and check H3 = P2^T Hc P2 on the host
+extern "C" int tlfea_newton_pmg3_sizes(tlfea_newton_t s, int* n_aggregates, int* nnz_blocks, int* degree) {
+  int nc = 0, nnz = 0;
+  TRY(tlfea_newton_pmg_sizes(s, &nc, &nnz));
+  const auto& g = s->pmg.agg;
+  if (n_aggregates) *n_aggregates = g.ok ? g.Na : 0;
+  if (nnz_blocks) *nnz_blocks = g.ok ? g.nnz3 : 0;
+  if (degree) *degree = g.ok ? pmg_level3_degree(g.N3) : 0;
+  return 0;
+}
+extern "C" int tlfea_newton_pmg3_retrieve(tlfea_newton_t s, int* agg, double* rvec, int* active, int* off3, int* cols3,
+                                          double* H3) {
+  int nc = 0, nnz = 0;
+  TRY(tlfea_newton_pmg_sizes(s, &nc, &nnz));
+  auto& m = s->pmg;
+  auto& g = m.agg;
+  if (!g.ok) return fail("p-multigrid: no third level on this mesh");
+  launch_pmg_galerkin(s->stream, m.nnz_c, m.d_c_off, m.d_cblk_row, m.d_con_off, m.d_con_base, m.d_con_deg, m.d_con_w,
+                      s->d_H, m.d_Hc);
+  launch_agg_galerkin(s->stream, g.n_pairs, g.d_pair_A, g.d_pair_pos, g.d_pair_B, g.d_pcon_off, g.d_pcon_base, g.d_pcon_deg,
+                      g.d_pcon_i, g.d_pcon_j, g.d_rvec, g.d_active, g.d_off3, m.d_Hc, g.d_H3);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  D2H(agg, g.d_agg, (size_t)nc);
+  D2H(rvec, g.d_rvec, (size_t)3 * nc);
+  D2H(active, g.d_active, (size_t)g.Na);
+  D2H(off3, g.d_off3, (size_t)g.N3 + 1);
+  D2H(cols3, g.d_cols3, (size_t)g.nnz3);
+  D2H(H3, g.d_H3, (size_t)9 * g.nnz3);
   return 0;
 }
 

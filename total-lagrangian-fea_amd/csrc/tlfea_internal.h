@@ -132,6 +132,16 @@ void launch_pmg_galerkin(hipStream_t s, int nnz_c, const int* c_off, const int* 
 void launch_pmg_restrict_init(hipStream_t s, int Nc, const int* child_off, const int* child, const float* child_w,
                               const float* res_f, const double* sc_f, const double* sc_c, const float* Dinv_c,
                               const double* coef_c, float* d_c, float* z_c, float* res_c);
+// third level: rigid-body-mode aggregation of the vertex level (pmg_host.h agg_build)
+void launch_agg_galerkin(hipStream_t s, int n_pairs, const int* pair_A, const int* pair_pos, const int* pair_B,
+                         const int* pcon_off, const int* pcon_base, const int* pcon_deg, const int* pcon_i,
+                         const int* pcon_j, const double* rvec, const int* active, const int* off3, const double* Hc,
+                         double* H3);
+void launch_agg_restrict_init(hipStream_t s, int N3, const int* mem_off, const int* mem, const double* rvec,
+                              const float* res2, const double* sc2, const double* sc3, const float* Dinv3,
+                              const double* coef3, float* d3, float* z3, float* res3);
+void launch_agg_prolong(hipStream_t s, int Nc, const int* agg, const double* rvec, const float* z3, const double* sc3,
+                        const double* sc2, float* z2, float* d2);
 void launch_pmg_prolong(hipStream_t s, int N, const int* par0, const int* par1, const float* z_c, const double* sc_c,
                         const double* sc_f, float* z_f, float* d_f);
 // mode 0: Chebyshev step, 1: last step (z back in the unscaled space + r.z slots in out), 2: out = Hs d_old

@@ -81,6 +81,22 @@ class SyncedNewtonSolver:
         check(self._lib.tlfea_newton_pmg_retrieve(self._h, ip(par0), ip(par1), ip(c_off), ip(c_cols), dp(Hc)))
         return par0, par1, c_off, c_cols, Hc
 
+    def GetPmgLevel3Info(self):
+        """(aggregates, 3x3 blocks, polynomial degree) of the third level, (0, 0, 0) when the cycle has two levels"""
+        na, nnz, deg = C.c_int(), C.c_int(), C.c_int()
+        check(self._lib.tlfea_newton_pmg3_sizes(self._h, C.byref(na), C.byref(nnz), C.byref(deg)))
+        return na.value, nnz.value, deg.value
+
+    def RetrievePmgLevel3(self):
+        """(agg[Nc], rvec[Nc,3], active[Na], off3, cols3, H3_values): test hook for H3 = P2^T Hc P2"""
+        nc, nnz = C.c_int(), C.c_int()
+        check(self._lib.tlfea_newton_pmg_sizes(self._h, C.byref(nc), C.byref(nnz)))
+        na, nnz3, _ = self.GetPmgLevel3Info()
+        agg, rvec, active = np.zeros(nc.value, dtype=np.int32), np.zeros(3 * nc.value), np.zeros(na, dtype=np.int32)
+        off3, cols3, H3 = np.zeros(2 * na + 1, dtype=np.int32), np.zeros(nnz3, dtype=np.int32), np.zeros(9 * nnz3)
+        check(self._lib.tlfea_newton_pmg3_retrieve(self._h, ip(agg), dp(rvec), ip(active), ip(off3), ip(cols3), dp(H3)))
+        return agg, rvec.reshape(-1, 3), active, off3, cols3, H3
+
     def AnalyzeHessianSparsity(self):
         check(self._lib.tlfea_newton_analyze_hessian_sparsity(self._h))
 
