@@ -174,7 +174,7 @@ int tlfea_newton_get_linsolve_info(tlfea_newton_t s, int *cheb_degree, int *cheb
 /* preconditioner a solve would use now: 0 block-Jacobi, 1 Chebyshev polynomial, 2 p-multigrid */
 int tlfea_newton_get_precond(tlfea_newton_t s);
 /* degree of the coarse-level polynomial of the p-multigrid cycle (grows with the coarse mesh); 0 without p-multigrid */
-/* third level of the cycle (rigid-body-mode aggregates of the vertex level; present on large meshes): number of
+/* third level of the cycle (rigid-body-mode aggregates of the vertex level; opt-in, TLFEA_PMG_LEVELS=3): number of
  * aggregates (0: two levels), 3x3 blocks of H3 (2 nodes per aggregate: translation, rotation), polynomial degree there;
  * retrieve: aggregate of every vertex node, x_i - c_A (zero where rotations are off), usable-rotation flags, the
  * level-3 block CSR and H3 = P2^T Hc P2 in the DOF-level layout of the other levels */

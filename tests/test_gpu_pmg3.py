@@ -1,6 +1,6 @@
 """Third level of the p-multigrid cycle (rigid-body-mode aggregates of the vertex level): Galerkin operator against
-P2^T Hc P2 built on the host, definiteness, and the solve against the Chebyshev-preconditioned one.  On the test meshes
-the level is forced (TLFEA_PMG_LEVELS=3; by default it switches on from 20 000 vertex nodes)."""
+P2^T Hc P2 built on the host, definiteness, and the solve against the Chebyshev-preconditioned one.  The level is opt-in
+(TLFEA_PMG_LEVELS=3): measured at config C it trades 10-12 % cheaper CG iterations for 10-17 % more of them."""
 import json
 import os
 import subprocess

@@ -1528,15 +1528,18 @@ static double pmg_kappa_coarse(int kc) {
   return forced > 1.0 ? forced : 1.5 * kc * kc;
 }
 static const double kPmgKappaS = std::getenv("TLFEA_PMG_KAPPA_S") ? std::atof(std::getenv("TLFEA_PMG_KAPPA_S")) : 8.0;
-// third level: from this many vertex nodes on (TLFEA_PMG_LEVELS=2|3 forces), smoother interval of the vertex level
-// when it is no longer the coarsest, and the degree / interval of the level-3 polynomial
-static const int kPmgLevel3MinNodes = 20000;
+// Third level (rigid-body-mode aggregates below the vertex level): opt-in with TLFEA_PMG_LEVELS=3.  Measured at config C
+// it makes a CG iteration 10-12 % cheaper (4 vertex-level steps + a degree-20..32 polynomial on ~20 000 level-3 nodes
+// instead of 31 vertex-level steps) and costs 10-17 % more iterations (33-35 instead of 30, whatever the accuracy of
+// the level-3 solve or the vertex-level smoothing interval): 79.4-83.1 ms per Newton iteration against 81.3 ms -- no
+// gain, so two levels stay the default.  Below: smoother interval of the vertex level when it is not the coarsest,
+// degree / interval of the level-3 polynomial.
 static int pmg_levels_wanted(int n_vertex) {
+  (void)n_vertex;
   static const int forced = std::getenv("TLFEA_PMG_LEVELS") ? std::atoi(std::getenv("TLFEA_PMG_LEVELS")) : 0;
-  if (forced == 2 || forced == 3) return forced;
-  return n_vertex >= kPmgLevel3MinNodes ? 3 : 2;
+  return forced == 3 ? 3 : 2;
 }
-static const double kPmgKappaS2 = std::getenv("TLFEA_PMG_KAPPA_S2") ? std::atof(std::getenv("TLFEA_PMG_KAPPA_S2")) : 8.0;
+static const double kPmgKappaS2 = std::getenv("TLFEA_PMG_KAPPA_S2") ? std::atof(std::getenv("TLFEA_PMG_KAPPA_S2")) : 16.0;
 static int pmg_level3_degree(int n3) {
   static const int forced = std::getenv("TLFEA_PMG_KC3") ? std::atoi(std::getenv("TLFEA_PMG_KC3")) : 0;
   if (forced > 1) return std::min(forced, kPmgMaxCoarseDeg - 4);
@@ -2051,7 +2054,7 @@ extern "C" int tlfea_newton_pmg_retrieve(tlfea_newton_t s, int* par0, int* par1,
   return 0;
 }
 
-// third level (present from kPmgLevel3MinNodes vertex nodes on, or with TLFEA_PMG_LEVELS=3): sizes, and everything
+// third level (opt-in, TLFEA_PMG_LEVELS=3): sizes, and everything
 // needed to rebuild P2 and check H3 = P2^T Hc P2 on the host
 extern "C" int tlfea_newton_pmg3_sizes(tlfea_newton_t s, int* n_aggregates, int* nnz_blocks, int* degree) {
   int nc = 0, nnz = 0;
