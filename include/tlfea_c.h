@@ -148,6 +148,9 @@ int tlfea_ancf_b12_matrix(int kind /*3243|3443*/, double L, double W, double H, 
  * the coefficient pairs a row couples (SyncedNewton.cu:556-801).  Single-GPU path only. */
 int tlfea_t10_set_linear_constraints_csr(tlfea_t10_t h, int n_rows, const int *offsets, const int *columns,
                                          const double *values, const double *rhs);
+/* UpdateLinearConstraintRHS (ANCF3243Data.cuh / ANCF3443Data.cuh:977-997): new right-hand side of the CSR constraints,
+ * J / J^T and the sparsity stay (prescribed motion: the airless-tire driver rotates its hub this way every step) */
+int tlfea_t10_update_linear_constraint_rhs(tlfea_t10_t h, const double *rhs /*n_constraint*/, int n);
 /* GetConstraintMode (ANCF3243Data.cuh:436-441): 0 none, 1 kConstraintFixedCoefficients, 2 kConstraintLinearCSR */
 int tlfea_t10_get_constraint_mode(tlfea_t10_t h);
 /* nnz of J (sizes the buffers of tlfea_t10_retrieve_constraint_jac_csr / _jact_csr) */

@@ -221,3 +221,66 @@ def test_set_linear_constraints_errors():
     with pytest.raises(RuntimeError, match="already set up"):
         d.SetLinearConstraintsCSR([0, 1], [0], [1.0], [0.0])
     d.Destroy()
+
+
+def tire_drive_inputs(m, csr, hub_row0, hub_coefs, z12, step, theta, dt, ground_z=-0.2, k=5e4, fz_max=2e4):
+    """One step of the reference tire driver's inputs (test_ancf3443_mesh_newton.cc:86-121, 345-374): ground contact on
+    the ring nodes below the plane (penalty k, clamped) and the hub coefficients rotated about y by the ramped angle."""
+    f_ext = np.zeros(12 * m.n_nodes)
+    for nid in range(m.n_nodes):
+        if m.node_family[nid] == "R" and z12[4 * nid] < ground_z:
+            f_ext[(4 * nid) * 3 + 2] += min(k * (ground_z - z12[4 * nid]), fz_max)
+    s = np.clip(((step + 0.5) * dt) / 0.05, 0.0, 1.0)
+    theta = theta + 1.5 * np.pi * (s * s * (3.0 - 2.0 * s)) * dt
+    rhs = csr.rhs.copy()
+    c, sn = np.cos(theta), np.sin(theta)
+    for i, coef in enumerate(hub_coefs):
+        x, y, z = m.x12[coef], m.y12[coef], m.z12[coef]
+        rhs[hub_row0 + 3 * i:hub_row0 + 3 * i + 3] = (c * x + sn * z, y, -sn * x + c * z)
+    return f_ext, rhs, theta
+
+
+def test_tire_driver_flow_prescribed_hub_rotation_and_ground_contact():
+    """The loop of lib_bin/mesh_deform/test_ancf3443_mesh_newton.cc: every step recomputes the ground-contact forces from
+    the current ring positions (SetExternalForce) and moves the hub through UpdateLinearConstraintRHS (J and the
+    sparsity stay); device vs oracle over three steps.  Contact stiffness scaled down so that the undamped Newton
+    iteration of the test converges within the driver's 10 iterations."""
+    prob = tire_problem()
+    kind, m, dims, csr, _, mk, prm = prob
+    o, d = make_pair(prob)
+    hub_row0 = m.constraints.NumRows() if hasattr(m.constraints, "NumRows") else len(m.constraints.rhs)
+    r = np.hypot(m.x12[0::4], m.z12[0::4])
+    spoke = np.array([f == "S" for f in m.node_family])
+    hub = np.where(spoke & (r < r[spoke].min() + 1e-9))[0]
+    hub_coefs = [4 * int(n) + s_ for n in hub for s_ in range(4)]
+    assert hub_row0 + 3 * len(hub_coefs) == len(csr.rhs)
+    s = tl.SyncedNewtonSolver(d, d.get_n_constraint())
+    s.Setup()
+    s.SetParameters(tl.SyncedNewtonParams(*prm))
+    s.SetLinSolveOpts(tl.LinSolveOpts(1e-13, 50000, 10))
+    X0 = np.stack([o.xt, o.yt, o.zt], axis=1)
+    theta_g = theta_o = 0.0
+    with pytest.raises(tl.TlfeaError):
+        d.UpdateLinearConstraintRHS(np.zeros(3))          # size mismatch is refused
+    for step in range(3):
+        zg = d.RetrievePositionToCPU()[2]
+        fg, rg, theta_g = tire_drive_inputs(m, csr, hub_row0, hub_coefs, zg, step, theta_g, 1e-3, ground_z=-0.2, k=100.0)
+        fo, ro, theta_o = tire_drive_inputs(m, csr, hub_row0, hub_coefs, o.z, step, theta_o, 1e-3, ground_z=-0.2, k=100.0)
+        assert np.count_nonzero(fo) > 0 and np.abs(fg - fo).max() <= 1e-6 * np.abs(fo).max()
+        d.SetExternalForce(fg)
+        d.UpdateLinearConstraintRHS(rg)
+        o.f_ext[:] = fo
+        o.j_rhs[:] = ro
+        s.Solve()
+        o.newton_step_lin(orc.NewtonParams(*prm))
+        xg = np.stack(d.RetrievePositionToCPU(), axis=1)
+        xo = np.stack([o.x, o.y, o.z], axis=1)
+        assert disp_err_ok(xg, xo, X0), step
+    # the hub followed the prescribed rotation
+    hub_pos = [4 * int(n) for n in hub]
+    want = np.stack([np.cos(theta_o) * m.x12[hub_pos] + np.sin(theta_o) * m.z12[hub_pos],
+                     -np.sin(theta_o) * m.x12[hub_pos] + np.cos(theta_o) * m.z12[hub_pos]], axis=1)
+    got = np.stack([o.x[hub_pos], o.z[hub_pos]], axis=1)
+    assert np.abs(got - want).max() < 1e-8 and theta_o > 0
+    del s
+    d.Destroy()

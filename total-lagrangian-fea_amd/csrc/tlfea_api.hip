@@ -338,6 +338,14 @@ extern "C" int tlfea_t10_set_linear_constraints_csr(tlfea_t10_t h, int n_rows, c
   return 0;
 }
 // GetConstraintMode: 0 none, 1 kConstraintFixedCoefficients, 2 kConstraintLinearCSR
+extern "C" int tlfea_t10_update_linear_constraint_rhs(tlfea_t10_t h, const double* rhs, int n) {
+  if (!h->is_constraints_setup || h->n_constraint == 0) return fail("UpdateLinearConstraintRHS: constraints not set up.");
+  if (h->cons_mode != 2) return fail("UpdateLinearConstraintRHS: constraint mode is not CSR.");
+  if (n != h->n_constraint) return fail("UpdateLinearConstraintRHS: size mismatch.");
+  h->h_rhs.assign(rhs, rhs + n);
+  HIP_TRY(hipMemcpy(h->d_rhs, rhs, (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+  return 0;
+}
 extern "C" int tlfea_t10_get_constraint_mode(tlfea_t10_t h) { return h ? h->cons_mode : -1; }
 extern "C" int tlfea_t10_constraint_jac_nnz(tlfea_t10_t h) {
   if (!h || !h->is_constraints_setup) return 0;

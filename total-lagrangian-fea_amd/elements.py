@@ -80,6 +80,11 @@ class GPU_FEAT10_Data:
             raise ValueError("SetLinearConstraintsCSR: offsets.back != nnz.")
         check(self._lib.tlfea_t10_set_linear_constraints_csr(self._h, int(r.size), ip(off), ip(col), dp(val), dp(r)))
 
+    def UpdateLinearConstraintRHS(self, rhs):
+        """New right-hand side of the CSR constraints, J and the sparsity stay (ANCF3443Data.cuh:977-997)."""
+        r = _f64(rhs)
+        check(self._lib.tlfea_t10_update_linear_constraint_rhs(self._h, dp(r), int(r.size)))
+
     def GetConstraintMode(self):
         return int(self._lib.tlfea_t10_get_constraint_mode(self._h))
 

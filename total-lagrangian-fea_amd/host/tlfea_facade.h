@@ -841,6 +841,10 @@ struct GPU_ANCF_DataBase : public GPU_FEAT10_Data {
                                                     rhs.data()));
     n_constraint = tlfea_t10_get_n_constraint(h);
   }
+  // same misuse messages as ANCF3443Data.cuh:979-993, printed by the C-ABI; std::cerr + return
+  void UpdateLinearConstraintRHS(const tlfea::VectorXd& rhs) {
+    if (tlfea_t10_update_linear_constraint_rhs(h, rhs.data(), rhs.size()) != 0) std::cerr << tlfea_last_error() << std::endl;
+  }
   int GetConstraintMode() const { return tlfea_t10_get_constraint_mode(h); }
   // element connectivity in NODE ids, n_beam x (2 | 4) (ANCF3243Data.cu:630-642, ANCF3443Data.cu:597-603); the handle
   // keeps coefficient ids [S][E] (slot 0 of node n of the element = 4 * node)
