@@ -187,3 +187,45 @@ def test_cpp_driver_default_solver_is_adamw(tmp_path):
     assert rows.shape == (1, 2) and np.isfinite(rows[0, 1]) and abs(rows[0, 1] - 3.0) < 1e-3 and rows[0, 1] != 3.0
     bad = subprocess.run([DRIVER, "--solver=vbd", "--omega=-1"], capture_output=True, text=True)
     assert bad.returncode == 1 and "Invalid --omega" in bad.stderr
+
+
+@pytest.mark.gpu
+def test_cpp_ancf3443_airless_tire_driver(tmp_path):
+    """lib_bin/mesh_deform/test_ancf3443_mesh_newton.cc on the facade (host/test_ancf3443_mesh_newton.cc): mesh file with
+    its own weld constraints, hub driven through UpdateLinearConstraintRHS, ground contact on the ring, VTU export.  The
+    CSV it records is compared with the same loop run on the oracle (contact stiffness reduced with --load_fz so that
+    the test's Newton iterations converge)."""
+    from tests.test_gpu_linear_constraints import make_pair, tire_drive_inputs, tire_problem
+    from tests.test_linear_constraints import TIRE
+    drv = os.path.join(os.path.dirname(DRIVER), "test_ancf3443_mesh_newton")
+    if not os.path.exists(drv):
+        subprocess.check_call(["make", "-C", os.path.dirname(DRIVER)])
+    csv = tmp_path / "tire.csv"
+    out = subprocess.run([drv, f"--mesh={TIRE}", "--steps=2", "--dt=1e-3", "--load_fz=100", f"--csv_path={csv}",
+                          f"--vtu={tmp_path}/vtu"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "Hub prescribed rotation: coef_fixed=" in out.stdout and "Constraint residual: rows=" in out.stdout
+    assert os.listdir(tmp_path / "vtu") == ["ancf3443_mesh_000000.vtu"]
+    rows = np.loadtxt(csv, delimiter=",", skiprows=1).reshape(-1, 6)
+    prob = tire_problem()
+    kind, m, dims, csrc, _, mk, prm = prob
+    o, d = make_pair(prob)
+    d.Destroy()
+    hub_row0 = len(m.constraints.rhs)
+    r = np.hypot(m.x12[0::4], m.z12[0::4])
+    spoke = np.array([f == "S" for f in m.node_family])
+    hub = np.where(spoke & (r < r[spoke].min() + 1e-9))[0]
+    hub_coefs = [4 * int(n) + s_ for n in hub for s_ in range(4)]
+    ring = np.array([4 * n for n in range(m.n_nodes) if m.node_family[n] == "R"])
+    theta = 0.0
+    for step in range(2):
+        f, rhs, theta = tire_drive_inputs(m, csrc, hub_row0, hub_coefs, o.z, step, theta, 1e-3, ground_z=-0.2, k=100.0)
+        o.f_ext[:] = f
+        o.j_rhs[:] = rhs
+        o.newton_step_lin(orc.NewtonParams(*prm))
+        assert abs(rows[step, 1] - theta) <= 1e-15 + 1e-12 * theta and rows[step, 2] == np.count_nonzero(f)
+        scale = np.abs(o.z[ring] - m.z12[ring]).max() + np.abs(o.x[hub_coefs[0]] - m.x12[hub_coefs[0]])
+        assert abs(rows[step, 3] - o.x[hub_coefs[0]]) <= 1e-9 * scale + 1e-14
+        assert abs(rows[step, 5] - o.z[ring].min()) <= 1e-9 * scale + 1e-14
+    bad = subprocess.run([drv, "--steps=1"], capture_output=True, text=True)
+    assert bad.returncode == 2 and "--mesh is required" in bad.stderr
