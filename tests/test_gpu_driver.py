@@ -229,3 +229,40 @@ def test_cpp_ancf3443_airless_tire_driver(tmp_path):
         assert abs(rows[step, 5] - o.z[ring].min()) <= 1e-9 * scale + 1e-14
     bad = subprocess.run([drv, "--steps=1"], capture_output=True, text=True)
     assert bad.returncode == 2 and "--mesh is required" in bad.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("material", ["svk", "mr"])
+def test_cpp_feat10_bunny_newton_driver(tmp_path, material):
+    """lib_bin/mesh_deform/test_feat10_bunny_newton.cc on the facade (0-based TetGen mesh, z < -4 pinned, -35 kN on the
+    nodes with z > 4, Newton {1e-4,1e-6,1e-4,1e14,5,10,1e-3}; the source of BASELINE config B's material): three steps
+    with the load, one after its release, against the oracle; VTK frames as in the reference."""
+    drv = os.path.join(os.path.dirname(DRIVER), "test_feat10_bunny_newton")
+    if not os.path.exists(drv):
+        subprocess.check_call(["make", "-C", os.path.dirname(DRIVER)])
+    csv = tmp_path / "bunny.csv"
+    out = subprocess.run([drv, f"--mesh_dir={MESHES}", "--steps=4", "--release_step=3", f"--material={material}",
+                          f"--vtk_dir={tmp_path}/vtk", "--output_interval=2", f"--csv_path={csv}"], capture_output=True,
+                         text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "External force reset to zero at step 3" in out.stdout
+    assert sorted(os.listdir(tmp_path / "vtk")) == ["bunny_newton_step_0.vtk", "bunny_newton_step_1.vtk"]
+    rows = np.loadtxt(csv, delimiter=",", skiprows=1)
+    X, conn = load_mesh("bunny")
+    fixed = np.where(X[:, 2] < -4.0)[0].astype(np.int32)
+    f_ext = np.zeros(3 * X.shape[0])
+    f_ext[3 * np.where(X[:, 2] > 4.0)[0] + 2] = -35000.0
+    E, nu = 3.0e8, 0.40
+    mu, K = E / (2 * (1 + nu)), E / (3 * (1 - 2 * nu))
+    m = (dict(kind="svk", E=E, nu=nu, rho0=920.0, eta=0.0, lamd=0.0) if material == "svk" else
+         dict(kind="mr", mu10=0.30 * mu, mu01=0.20 * mu, kappa=1.5 * K, rho0=920.0, eta=0.0, lamd=0.0))
+    o = make_oracle(X, conn, m, fixed, f_ext)
+    top = int(np.argmax(X[:, 2]))
+    prm = orc.NewtonParams(1e-4, 1e-6, 1e-4, 1e14, 5, 10, 1e-3)
+    for step in range(4):
+        if step == 3:
+            o.f_ext[:] = 0.0
+        o.newton_step(prm, solver=0)
+        disp = np.sqrt((o.x - X[:, 0]) ** 2 + (o.y - X[:, 1]) ** 2 + (o.z - X[:, 2]) ** 2).max()
+        assert abs(rows[step, 1] - o.z[top]) <= 1e-9 * disp + 8e-16 * abs(o.z[top])
+        assert abs(rows[step, 2] - disp) <= 1e-9 * disp
