@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 from oracle import orc
-from tests.helpers import MATERIALS, MESHES, fixed_x0, load_mesh, make_oracle
+from tests.helpers import MATERIALS, MESHES, fixed_x0, load_mesh, make_oracle, tl
 from tests.test_gpu_parity import disp_err_ok
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -266,3 +266,42 @@ def test_cpp_feat10_bunny_newton_driver(tmp_path, material):
         disp = np.sqrt((o.x - X[:, 0]) ** 2 + (o.y - X[:, 1]) ** 2 + (o.z - X[:, 2]) ** 2).max()
         assert abs(rows[step, 1] - o.z[top]) <= 1e-9 * disp + 8e-16 * abs(o.z[top])
         assert abs(rows[step, 2] - disp) <= 1e-9 * disp
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("solver", ["newton", "vbd", "nesterov"])
+def test_cpp_ancf3443_strip_driver(tmp_path, solver):
+    """lib_bin/beam_sag/test_ancf3443.cc on the facade: strip constructor, left edge pinned, tip load split by --lrratio,
+    the reference's parameters per solver kind; CSV `step,tip_z` (mean z of the two tip nodes) against the oracle."""
+    from tests.test_gpu_ancf import SVK, make_pair
+    drv = os.path.join(os.path.dirname(DRIVER), "test_ancf3443")
+    if not os.path.exists(drv):
+        subprocess.check_call(["make", "-C", os.path.dirname(DRIVER)])
+    csv = tmp_path / "tip.csv"
+    out = subprocess.run([drv, f"--solver={solver}", "--n_beam=3", "--steps=2", "--dt=1e-3", "--lrratio=0.25",
+                          f"--csv={csv}", f"--vtu={tmp_path}/vtu"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert open(csv).readline().strip() == "step,tip_z"
+    assert os.listdir(tmp_path / "vtu") == [f"ancf3443_{solver}_000000.vtu"]
+    rows = np.loadtxt(csv, delimiter=",", skiprows=1)
+    x, y, z, conn = tl.mesh_utils.ANCF3443_generate_beam_coordinates(3)
+    fixed = np.array([4 * n + d_ for n in (conn[0, 0], conn[0, 3]) for d_ in range(4)], dtype=np.int32)
+    ta, tb = int(conn[-1, 1]), int(conn[-1, 2])
+    neg, pos = (ta, tb) if y[4 * ta] <= y[4 * tb] else (tb, ta)
+    f_ext = np.zeros(3 * len(x))
+    f_ext[(4 * neg) * 3 + 2] += 0.25 * -100.0
+    f_ext[(4 * pos) * 3 + 2] += 0.75 * -100.0
+    o, d = make_pair((3443, x, y, z, conn, (2.0, 1.0, 0.1), fixed, f_ext), SVK)
+    d.Destroy()
+    if solver == "vbd":
+        o.vbd_coloring(1)
+    for step in range(2):
+        if solver == "newton":
+            o.newton_step(orc.NewtonParams(1e-4, 0.0, 1e-6, 1e14, 5, 10, 1e-3))
+        elif solver == "vbd":
+            o.vbd_step(orc.VbdParams(1e-4, 1e-4, 1e-4, 1e14, 5, 500, 1e-3, 1.8, 1e-12, 25, 1))
+        else:
+            o.nesterov_step(orc.NesterovParams(1.0e-8, 1e14, 1.0e-6, 1.0e-6, 5, 300, 1e-3))
+        ref = 0.5 * (o.z[4 * ta] + o.z[4 * tb])
+        disp = np.abs(o.z - z).max()
+        assert disp > 0 and abs(rows[step, 1] - ref) <= 1e-9 * disp + 1e-15
