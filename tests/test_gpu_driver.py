@@ -305,3 +305,25 @@ def test_cpp_ancf3443_strip_driver(tmp_path, solver):
         ref = 0.5 * (o.z[4 * ta] + o.z[4 * tb])
         disp = np.abs(o.z - z).max()
         assert disp > 0 and abs(rows[step, 1] - ref) <= 1e-9 * disp + 1e-15
+
+
+@pytest.mark.gpu
+def test_cpp_other_solver_kinds_run(tmp_path):
+    """--solver=adamw of the bunny driver (lib_bin/mesh_deform/test_feat10_bunny_adamw.cc: -2 N, AdamW lr 1e-8 ...) and
+    --solver=nesterov of the resolution driver (parameters of lib_bin/beam_sag/test_feat10_nesterov.cc:181): the steps
+    run, the structure moves in the direction of the load, output files carry the solver's name."""
+    drv = os.path.join(os.path.dirname(DRIVER), "test_feat10_bunny_newton")
+    csv = tmp_path / "b.csv"
+    out = subprocess.run([drv, f"--mesh_dir={MESHES}", "--solver=adamw", "--steps=2", f"--vtk_dir={tmp_path}/vtk",
+                          "--output_interval=1", f"--csv_path={csv}"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert sorted(os.listdir(tmp_path / "vtk")) == ["bunny_adamw_step_0.vtk", "bunny_adamw_step_1.vtk"]
+    rows = np.loadtxt(csv, delimiter=",", skiprows=1)
+    assert rows.shape == (2, 3) and np.all(np.isfinite(rows)) and rows[1, 2] > 0
+    csv2 = tmp_path / "n.csv"
+    out = subprocess.run([DRIVER, "--res=2", "--steps=2", "--dt=1e-3", "--solver=nesterov", f"--mesh_dir={MESHES}",
+                          f"--csv_path={csv2}"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    r2 = np.loadtxt(csv2, delimiter=",", skiprows=1)
+    X, _ = load_mesh("res2")
+    assert r2.shape == (2, 2) and r2[1, 1] > X[89, 0] and r2[1, 1] - X[89, 0] < 1e-2   # pulled in +x, slightly

@@ -4,13 +4,16 @@
 // 0-based TetGen mesh bunny_ascii_26.1 (1066 elements), E = 3e8, nu = 0.4, rho = 920, nodes with z < -4 pinned, -35 kN
 // in z on every node with z > 4, released after 1000 steps, 8000 steps of dt = 1e-3, Newton {1e-4,1e-6,1e-4,1e14,5,10},
 // a VTK file every 10 steps.
-//   ./test_feat10_bunny_newton --mesh_dir=tests/golden/meshes [--steps=8000] [--release_step=1000] [--material=svk|mr]
+// --solver=adamw runs the sibling lib_bin/mesh_deform/test_feat10_bunny_adamw.cc instead (-2 N per loaded node, no
+// release, 20000 steps, VTK every 100, AdamW {1e-8,0.9,0.999,1e-8,1e-4,0.998,1e-1,1e-6,1e14,5,500,1e-3,20,0}, :182-183).
+//   ./test_feat10_bunny_newton --mesh_dir=tests/golden/meshes [--steps=8000] [--release_step=1000] [--material=svk|mr] [--solver=newton|adamw]
 //                              [--vtk_dir=output] [--output_interval=10] [--csv_path=FILE] [--dump]
 // --dump prints the reference gradients, detJ, P and f_int like the reference does; --csv_path records per step the
 // top node's z and the largest displacement (for the tests).
 #include <cmath>
 #include <filesystem>
 #include <iomanip>
+#include <memory>
 
 #include "tlfea_facade.h"
 
@@ -20,8 +23,8 @@ bool starts_with(const std::string& s, const std::string& p) { return s.rfind(p,
 }  // namespace
 
 int main(int argc, char** argv) {
-  std::string mesh_dir = "data/meshes/T10", material = "svk", vtk_dir = "output", csv_path;
-  int steps = 8000, release_step = 1000, output_interval = 10;
+  std::string mesh_dir = "data/meshes/T10", material = "svk", vtk_dir = "output", csv_path, solver_kind = "newton";
+  int steps = -1, release_step = -2, output_interval = -1;
   bool dump = false;
   for (int i = 1; i < argc; i++) {
     const std::string a(argv[i]);
@@ -29,6 +32,7 @@ int main(int argc, char** argv) {
     else if (starts_with(a, "--steps=")) steps = std::atoi(a.c_str() + 8);
     else if (starts_with(a, "--release_step=")) release_step = std::atoi(a.c_str() + 15);
     else if (starts_with(a, "--material=")) material = a.substr(11);
+    else if (starts_with(a, "--solver=")) solver_kind = a.substr(9);
     else if (starts_with(a, "--vtk_dir=")) vtk_dir = a.substr(10);
     else if (starts_with(a, "--output_interval=")) output_interval = std::atoi(a.c_str() + 18);
     else if (starts_with(a, "--csv_path=")) csv_path = a.substr(11);
@@ -38,6 +42,14 @@ int main(int argc, char** argv) {
       return 1;
     }
   }
+  if (solver_kind != "newton" && solver_kind != "adamw") {
+    std::cerr << "Invalid --solver (newton|adamw): " << solver_kind << std::endl;
+    return 1;
+  }
+  const bool adamw = solver_kind == "adamw";
+  if (steps < 0) steps = adamw ? 20000 : 8000;
+  if (release_step == -2) release_step = adamw ? -1 : 1000;
+  if (output_interval < 0) output_interval = adamw ? 100 : 10;
   if (material != "svk" && material != "mr") {
     std::cerr << "Invalid --material (svk|mr): " << material << std::endl;
     return 1;
@@ -71,7 +83,7 @@ int main(int argc, char** argv) {
   int loaded = 0;
   for (int i = 0; i < n_nodes; i++)
     if (z(i) > 4.0) {  // :80-85
-      f_ext(3 * i + 2) = -35000.0;
+      f_ext(3 * i + 2) = adamw ? -2.0 : -35000.0;  // bunny_adamw.cc:95
       loaded++;
     }
   std::cout << "Loaded nodes (z > 4.0): " << loaded << std::endl;
@@ -112,12 +124,23 @@ int main(int argc, char** argv) {
     for (int i = 0; i < fi.size(); i++) std::cout << fi(i) << " ";
     std::cout << std::endl;
   }
-  SyncedNewtonParams params = {1e-4, 1e-6, 1e-4, 1e14, 5, 10, 1e-3};  // :201
-  SyncedNewtonSolver solver(&data, data.get_n_constraint());
-  solver.Setup();
-  solver.SetParameters(&params);
-  solver.AnalyzeHessianSparsity();
-  solver.SetFixedSparsityPattern(true);
+  std::unique_ptr<SolverBase> solver_ptr;
+  if (adamw) {
+    SyncedAdamWParams p = {1e-8, 0.9, 0.999, 1e-8, 1e-4, 0.998, 1e-1, 1e-6, 1e14, 5, 500, 1e-3, 20, 0.0};
+    auto* sv = new SyncedAdamWNocoopSolver(&data, data.get_n_constraint());
+    sv->Setup();
+    sv->SetParameters(&p);
+    solver_ptr.reset(sv);
+  } else {
+    SyncedNewtonParams params = {1e-4, 1e-6, 1e-4, 1e14, 5, 10, 1e-3};  // :201
+    auto* sv = new SyncedNewtonSolver(&data, data.get_n_constraint());
+    sv->Setup();
+    sv->SetParameters(&params);
+    sv->AnalyzeHessianSparsity();
+    sv->SetFixedSparsityPattern(true);
+    solver_ptr.reset(sv);
+  }
+  SolverBase& solver = *solver_ptr;
   if (output_interval > 0 && !vtk_dir.empty()) std::filesystem::create_directories(vtk_dir);
   std::ofstream csv;
   if (!csv_path.empty()) {
@@ -134,7 +157,7 @@ int main(int argc, char** argv) {
     }
     solver.Solve();
     if (output_interval > 0 && !vtk_dir.empty() && i % output_interval == 0)
-      data.WriteOutputVTK(vtk_dir + "/bunny_newton_step_" + std::to_string(frame++) + ".vtk");
+      data.WriteOutputVTK(vtk_dir + "/bunny_" + solver_kind + "_step_" + std::to_string(frame++) + ".vtk");
     if (csv.is_open()) {
       data.RetrievePositionToCPU(xx, yy, zz);
       double md = 0.0;
@@ -145,6 +168,7 @@ int main(int argc, char** argv) {
   }
   data.RetrievePositionToCPU(xx, yy, zz);
   std::cout << std::fixed << std::setprecision(17) << "top node " << top << " z: " << zz(top) << std::endl;
+  solver_ptr.reset();
   data.Destroy();
   return 0;
 }

@@ -1,6 +1,6 @@
 // test_feat10_resolution -- the reference's T10 beam driver flow (lib_bin/beam_sag/test_feat10_resolution.cc:
 // 209-431) on the MI355X engine, same flags, solver kinds, parameters and CSV schema (`step,x_position`, 17 digits).
-//   ./test_feat10_resolution --mesh_dir=tests/golden/meshes --res=2 --steps=5 --dt=1e-3 [--solver=adamw|newton|vbd]
+//   ./test_feat10_resolution --mesh_dir=tests/golden/meshes --res=2 --steps=5 --dt=1e-3 [--solver=adamw|newton|vbd|nesterov]
 //                            [--omega=1.8] [--csv] [--csv_path=...]
 #include <cmath>
 #include <iomanip>
@@ -29,7 +29,7 @@ bool ParseArgs(int argc, char** argv, Options& o) {
     else if (StartsWith(a, "--mesh_dir=")) o.mesh_dir = a.substr(11);
     else if (StartsWith(a, "--solver=")) {
       o.solver = a.substr(9);
-      if (o.solver != "newton" && o.solver != "vbd" && o.solver != "adamw") { std::cerr << "Invalid --solver: " << o.solver << "\n"; return false; }
+      if (o.solver != "newton" && o.solver != "vbd" && o.solver != "adamw" && o.solver != "nesterov") { std::cerr << "Invalid --solver: " << o.solver << "\n"; return false; }
     }
     else if (StartsWith(a, "--omega=")) {
       o.omega = std::atof(a.c_str() + 8);
@@ -120,6 +120,16 @@ int main(int argc, char** argv) {
     solver.InitializeColoring();
     solver.InitializeMassDiagBlocks();
     solver.InitializeFixedMap();
+    for (int step = 0; step < opt.steps; ++step) {
+      solver.Solve();
+      record_step(step);
+    }
+  } else if (opt.solver == "nesterov") {
+    // not a kind of the reference's resolution driver: the parameters of its sibling lib_bin/beam_sag/test_feat10_nesterov.cc:181
+    SyncedNesterovParams params = {1.0e-8, 1e14, 1.0e-6, 1.0e-6, 5, 300, opt.dt};
+    SyncedNesterovSolver solver(&data, data.get_n_constraint());
+    solver.Setup();
+    solver.SetParameters(&params);
     for (int step = 0; step < opt.steps; ++step) {
       solver.Solve();
       record_step(step);
