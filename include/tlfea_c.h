@@ -269,6 +269,10 @@ int tlfea_adamw_retrieve_velocity(tlfea_adamw_t a, double *v);
 int tlfea_adamw_retrieve_lambda(tlfea_adamw_t a, double *lam);
 /* out6: outer iterations, inner iterations (total), last ||g||, last ||c||, inner-converged flag, device ms */
 int tlfea_adamw_get_stats(tlfea_adamw_t a, double *out6);
+/* 1: semantics of SyncedAdamWSolver, the cooperative-kernel sibling of the same solver (SyncedAdamW.cuh, SyncedAdamW.cu:
+ * 96-345): inner-converged flag cleared once per Solve(), lam += rho dt c applied once (Nocoop: twice), outer loop stops
+ * on ||c|| < outer_tol alone.  0 (default): SyncedAdamWNocoopSolver. */
+int tlfea_adamw_set_cooperative_semantics(tlfea_adamw_t a, int on);
 int tlfea_adamw_set_verbose(tlfea_adamw_t a, int v);
 
 /* ---- SyncedNesterovSolver (SyncedNesterov.cuh:26-260, SyncedNesterov.cu:95-372) ---------------------------------

@@ -478,6 +478,16 @@ class ElemOracle(VbdMixin):
             dp(self.v), dp(self.v_prev), dp(self.lam), dp(stats))
         return stats
 
+    def adamw_coop_step(self, prm):
+        """SyncedAdamWSolver::OneStepAdamW, the cooperative-kernel sibling (SyncedAdamW.cu:96-345)."""
+        stats = np.zeros(5)
+        self.L.orc_gen_adamw_coop_step(
+            self.S, self.Q, self.E, self.N, ip(self.conn_cm), dp(self.x), dp(self.y), dp(self.z), dp(self.xt),
+            dp(self.yt), dp(self.zt), dp(self.gradN), dp(self.detJ), dp(self.qw), C.byref(self.mat), ip(self.m_off),
+            ip(self.m_col), dp(self.m_val), ip(self.fixed), len(self.fixed), dp(self.f_ext), C.byref(prm),
+            dp(self.v), dp(self.v_prev), dp(self.lam), dp(stats))
+        return stats
+
     def newton_step(self, prm):
         stats = np.zeros(4)
         rc = self.L.orc_gen_newton_step(

@@ -614,11 +614,16 @@ typedef struct {
   double inner_rtol;
 } orc_adamw_params;
 
-int orc_gen_adamw_step(int S, int Q, int E, int N, const int *conn, double *x, double *y, double *z,
-                       const double *xt, const double *yt, const double *zt, const double *gradN,
-                       const double *detJ, const double *qw, const orc_material *mat, const int *mo, const int *mc,
-                       const double *mv, const int *fixed, int n_fixed, const double *f_ext,
-                       const orc_adamw_params *prm, double *v, double *v_prev, double *lam, double *stats) {
+/* coop = 0: SyncedAdamWNocoopSolver::OneStepAdamWNocoop (SyncedAdamWNocoop.cu:262-500);
+ * coop = 1: SyncedAdamWSolver, the cooperative-kernel sibling (SyncedAdamW.cu:96-345) -- the same moments and step, but
+ * as written there: the inner-converged flag is cleared once per Solve() (a converged inner loop is not re-entered by
+ * the later outer iterations), the multiplier update lam += rho dt c is applied once (Nocoop applies it twice), and
+ * the outer loop stops on ||c|| < outer_tol alone. */
+static int gen_adamw_step(int S, int Q, int E, int N, const int *conn, double *x, double *y, double *z,
+                          const double *xt, const double *yt, const double *zt, const double *gradN,
+                          const double *detJ, const double *qw, const orc_material *mat, const int *mo, const int *mc,
+                          const double *mv, const int *fixed, int n_fixed, const double *f_ext,
+                          const orc_adamw_params *prm, double *v, double *v_prev, double *lam, double *stats, int coop) {
   const int n = 3 * N, nc = 3 * n_fixed;
   const double dt = prm->time_step, rho = prm->rho;
   const int check_every = prm->convergence_check_interval > 0 ? prm->convergence_check_interval : 1;
@@ -634,7 +639,7 @@ int orc_gen_adamw_step(int S, int Q, int E, int N, const int *conn, double *x, d
     if (outer_flag) break;
     n_outer++;
     memset(g, 0, sizeof(double) * n); memset(m, 0, sizeof(double) * n); memset(va, 0, sizeof(double) * n);
-    inner_flag = 0;
+    if (!coop) inner_flag = 0;
     double ng0 = -1.0;
     for (int inner = 0; inner < prm->max_inner; inner++) {
       if (inner_flag) break;
@@ -667,15 +672,32 @@ int orc_gen_adamw_step(int S, int Q, int E, int N, const int *conn, double *x, d
     for (int i = 0; i < N; i++) { x[i] = xp[i] + dt * v[3 * i]; y[i] = xp[N + i] + dt * v[3 * i + 1]; z[i] = xp[2 * N + i] + dt * v[3 * i + 2]; }
     if (nc > 0) {
       for (int k = 0; k < n_fixed; k++) { c[3 * k] = x[fixed[k]] - xt[fixed[k]]; c[3 * k + 1] = y[fixed[k]] - yt[fixed[k]]; c[3 * k + 2] = z[fixed[k]] - zt[fixed[k]]; }
-      for (int k = 0; k < nc; k++) { lam[k] += rho * dt * c[k]; lam[k] += rho * dt * c[k]; }
+      for (int k = 0; k < nc; k++) { lam[k] += rho * dt * c[k]; if (!coop) lam[k] += rho * dt * c[k]; }
       ncn = 0.0; for (int k = 0; k < nc; k++) ncn += c[k] * c[k]; ncn = sqrt(ncn);
-      if (ncn < prm->outer_tol && inner_flag) outer_flag = 1;
+      if (ncn < prm->outer_tol && (coop || inner_flag)) outer_flag = 1;
     }
   }
   for (int i = 0; i < N; i++) { x[i] = xp[i] + dt * v[3 * i]; y[i] = xp[N + i] + dt * v[3 * i + 1]; z[i] = xp[2 * N + i] + dt * v[3 * i + 2]; }
   if (stats) { stats[0] = n_outer; stats[1] = n_inner; stats[2] = ng; stats[3] = ncn; stats[4] = inner_flag; }
   free(xp); free(P); free(f_int); free(g); free(m); free(va); free(c);
   return 0;
+}
+
+int orc_gen_adamw_step(int S, int Q, int E, int N, const int *conn, double *x, double *y, double *z,
+                       const double *xt, const double *yt, const double *zt, const double *gradN,
+                       const double *detJ, const double *qw, const orc_material *mat, const int *mo, const int *mc,
+                       const double *mv, const int *fixed, int n_fixed, const double *f_ext,
+                       const orc_adamw_params *prm, double *v, double *v_prev, double *lam, double *stats) {
+  return gen_adamw_step(S, Q, E, N, conn, x, y, z, xt, yt, zt, gradN, detJ, qw, mat, mo, mc, mv, fixed, n_fixed, f_ext, prm,
+                        v, v_prev, lam, stats, 0);
+}
+int orc_gen_adamw_coop_step(int S, int Q, int E, int N, const int *conn, double *x, double *y, double *z,
+                            const double *xt, const double *yt, const double *zt, const double *gradN,
+                            const double *detJ, const double *qw, const orc_material *mat, const int *mo, const int *mc,
+                            const double *mv, const int *fixed, int n_fixed, const double *f_ext,
+                            const orc_adamw_params *prm, double *v, double *v_prev, double *lam, double *stats) {
+  return gen_adamw_step(S, Q, E, N, conn, x, y, z, xt, yt, zt, gradN, detJ, qw, mat, mo, mc, mv, fixed, n_fixed, f_ext, prm,
+                        v, v_prev, lam, stats, 1);
 }
 
 

@@ -307,3 +307,44 @@ def test_nesterov_matches_oracle(pname):
         assert relerr(s.RetrieveLambdaToCPU(), o.lam) < 1e-6
     del s
     d.Destroy()
+
+
+def test_adamw_cooperative_sibling_semantics():
+    """SyncedAdamWSolver (SyncedAdamW.cu:96-345) vs the oracle's restatement of that file: unconstrained it is the Nocoop
+    recurrence to round-off; with pinned coefficients the multipliers receive rho*dt*c ONCE per outer iteration (Nocoop:
+    twice) and an inner loop that has converged is not re-entered by the later outer iterations of the same Solve()."""
+    o, d = make_pair(PROBLEMS["beam3243"](), SVK_D, with_constraints=False)
+    perturb(o, d, sigma=1e-4)
+    kw = _adamw_params(inner_tol=0.0, outer_tol=0.0, max_outer=2, max_inner=50)
+    s = tl.SyncedAdamWSolver(d, 0)
+    s.Setup()
+    s.SetParameters(tl.SyncedAdamWParams(**kw))
+    oprm = orc.AdamWParams(*[kw[k] for k, _ in orc.AdamWParams._fields_])
+    X0 = np.stack([o.xt, o.yt, o.zt], axis=1)
+    for _ in range(2):
+        s.Solve()
+        o.adamw_coop_step(oprm)
+        xg = np.stack(d.RetrievePositionToCPU(), axis=1)
+        assert disp_err_ok(xg, np.stack([o.x, o.y, o.z], axis=1), X0)
+        assert relerr(s.RetrieveVelocityToCPU(), o.v) < 1e-10
+    del s
+    d.Destroy()
+    # pinned coefficients, a tolerance the first check meets: inner loop runs once per Solve, three outer passes update
+    # the multipliers once each
+    o, d = make_pair(PROBLEMS["beam3243"](), SVK_D)
+    kw = _adamw_params(inner_tol=1e30, outer_tol=0.0, max_outer=3, max_inner=40)
+    out = {}
+    for name, cls, step in (("coop", tl.SyncedAdamWSolver, "adamw_coop_step"), ("nocoop", tl.SyncedAdamWNocoopSolver, "adamw_step")):
+        oo, dd = make_pair(PROBLEMS["beam3243"](), SVK_D)
+        ss = cls(dd, dd.get_n_constraint())
+        ss.Setup()
+        ss.SetParameters(tl.SyncedAdamWParams(**kw))
+        ss.Solve()
+        st_o = getattr(oo, step)(orc.AdamWParams(*[kw[k] for k, _ in orc.AdamWParams._fields_]))
+        st = ss.GetStats()
+        out[name] = (st["outer"], st["inner"], int(st_o[0]), int(st_o[1]))
+        del ss
+        dd.Destroy()
+    assert out["coop"] == (3, 1, 3, 1), out       # converged at the first check, never re-entered
+    assert out["nocoop"] == (3, 3, 3, 3), out     # flag cleared per outer iteration: one inner iteration each
+    d.Destroy()

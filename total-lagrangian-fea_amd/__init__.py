@@ -11,10 +11,10 @@ Import with importlib (the directory name carries a hyphen):
 from .binding import (LIB_PATH, TlfeaError, load_library, device_count, exported_symbols)  # noqa: F401
 from .elements import GPU_ANCF3243_Data, GPU_ANCF3443_Data, GPU_FEAT10_Data  # noqa: F401
 from .solvers import (SyncedNewtonParams, SyncedNewtonSolver, LinSolveOpts, SyncedAdamWNocoopParams,  # noqa: F401
-                      SyncedAdamWNocoopSolver, SyncedNesterovParams, SyncedNesterovSolver, SyncedVBDParams,
+                      SyncedAdamWNocoopSolver, SyncedAdamWSolver, SyncedAdamWParams, SyncedNesterovParams, SyncedNesterovSolver, SyncedVBDParams,
                       SyncedVBDSolver)
 from . import mesh_utils, quadrature  # noqa: F401
 from .mesh_manager import MeshManager  # noqa: F401
 
-__all__ = ["GPU_FEAT10_Data", "GPU_ANCF3243_Data", "GPU_ANCF3443_Data", "SyncedNewtonSolver", "SyncedNewtonParams", "LinSolveOpts", "SyncedAdamWNocoopSolver", "SyncedAdamWNocoopParams", "SyncedNesterovSolver", "SyncedNesterovParams", "SyncedVBDSolver", "SyncedVBDParams", "mesh_utils", "MeshManager",
+__all__ = ["GPU_FEAT10_Data", "GPU_ANCF3243_Data", "GPU_ANCF3443_Data", "SyncedNewtonSolver", "SyncedNewtonParams", "LinSolveOpts", "SyncedAdamWNocoopSolver", "SyncedAdamWNocoopParams", "SyncedAdamWSolver", "SyncedAdamWParams", "SyncedNesterovSolver", "SyncedNesterovParams", "SyncedVBDSolver", "SyncedVBDParams", "mesh_utils", "MeshManager",
            "quadrature", "load_library", "device_count", "TlfeaError", "LIB_PATH", "exported_symbols"]

@@ -2358,6 +2358,10 @@ struct tlfea_adamw_s {
   double *d_m = nullptr, *d_va = nullptr;
   double stats[6] = {0, 0, 0, 0, 0, 0};  // outer iterations, inner iterations (total), ||g||, ||c||, inner flag, ms
   int verbose = 0;
+  // 1: SyncedAdamWSolver, the cooperative-kernel sibling (SyncedAdamW.cu:96-345): same moments and step; as written
+  // there the inner-converged flag is cleared once per Solve(), lam += rho dt c is applied once, and the outer loop
+  // stops on ||c|| < outer_tol alone
+  int coop = 0;
 };
 
 extern "C" int tlfea_adamw_create(tlfea_t10_t data, int n_constraints, tlfea_adamw_t* out) {
@@ -2398,6 +2402,10 @@ extern "C" int tlfea_adamw_set_parameters(tlfea_adamw_t a, const tlfea_adamw_par
   HIP_TRY(hipMemset(s->d_lam, 0, (size_t)std::max(1, s->n_constraints) * sizeof(double)));
   return 0;
 }
+extern "C" int tlfea_adamw_set_cooperative_semantics(tlfea_adamw_t a, int on) {
+  a->coop = on ? 1 : 0;
+  return 0;
+}
 extern "C" int tlfea_adamw_set_verbose(tlfea_adamw_t a, int v) {
   a->verbose = v;
   return 0;
@@ -2435,7 +2443,7 @@ extern "C" int tlfea_adamw_solve(tlfea_adamw_t a) {
     HIP_TRY(hipMemsetAsync(s->d_g, 0, (size_t)n * sizeof(double), s->stream));
     HIP_TRY(hipMemsetAsync(a->d_m, 0, (size_t)n * sizeof(double), s->stream));
     HIP_TRY(hipMemsetAsync(a->d_va, 0, (size_t)n * sizeof(double), s->stream));
-    inner_flag = 0;
+    if (!a->coop) inner_flag = 0;
     double norm_g0 = -1.0;
     for (int inner = 0; inner < p.max_inner; inner++) {
       if (inner_flag) break;
@@ -2470,10 +2478,10 @@ extern "C" int tlfea_adamw_solve(tlfea_adamw_t a) {
         launch_constraint(s->stream, d->n_fixed, d->d_fixed, d->d_x, d->d_y, d->d_z, d->d_xt, d->d_yt, d->d_zt, d->d_cons);
       // adamw_dual_update_kernel adds rho*dt*c TWICE (SyncedAdamWNocoop.cu:260-264): reproduced as written
       launch_dual_update(s->stream, s->n_constraints, d->d_cons, p.rho * dt, s->d_lam);
-      launch_dual_update(s->stream, s->n_constraints, d->d_cons, p.rho * dt, s->d_lam);
+      if (!a->coop) launch_dual_update(s->stream, s->n_constraints, d->d_cons, p.rho * dt, s->d_lam);
       TRY(device_norm(s, d->d_cons, nullptr, s->n_constraints, &norm_c));
       if (a->verbose) std::printf("norm_constraint: %.17g\n", norm_c);
-      if (norm_c < p.outer_tol && inner_flag) outer_flag = 1;
+      if (norm_c < p.outer_tol && (a->coop || inner_flag)) outer_flag = 1;
     }
   }
   launch_positions_from_prev(s->stream, N, s->d_v, s->d_xp, s->d_yp, s->d_zp, dt, d->d_x, d->d_y, d->d_z);

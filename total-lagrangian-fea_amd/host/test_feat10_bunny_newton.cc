@@ -127,7 +127,7 @@ int main(int argc, char** argv) {
   std::unique_ptr<SolverBase> solver_ptr;
   if (adamw) {
     SyncedAdamWParams p = {1e-8, 0.9, 0.999, 1e-8, 1e-4, 0.998, 1e-1, 1e-6, 1e14, 5, 500, 1e-3, 20, 0.0};
-    auto* sv = new SyncedAdamWNocoopSolver(&data, data.get_n_constraint());
+    auto* sv = new SyncedAdamWSolver(&data, data.get_n_constraint());  // the cooperative class, as in the reference
     sv->Setup();
     sv->SetParameters(&p);
     solver_ptr.reset(sv);

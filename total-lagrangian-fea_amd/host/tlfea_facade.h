@@ -1098,6 +1098,16 @@ class SyncedAdamWNocoopSolver : public SolverBase {
   double* GetVelocityGuessDevicePtr() const { return tlfea_adamw_velocity_guess_device_ptr(a_); }
   void SetVerbose(int v) { tlfea_adamw_set_verbose(a_, v); }
 
- private:
+ protected:
   tlfea_adamw_t a_ = nullptr;
+};
+
+// SyncedAdamWSolver (SyncedAdamW.cuh, SyncedAdamW.cu:96-445): the cooperative-kernel sibling -- the same step as ordinary
+// launches, with that file's flag / multiplier semantics (tlfea_adamw_set_cooperative_semantics)
+class SyncedAdamWSolver : public SyncedAdamWNocoopSolver {
+ public:
+  SyncedAdamWSolver(ElementBase* data, int n_constraints) : SyncedAdamWNocoopSolver(data, n_constraints) {
+    TLFEA_HANDLE_ERROR(tlfea_adamw_set_cooperative_semantics(a_, 1));
+  }
+  void OneStepAdamW() { TLFEA_HANDLE_ERROR(tlfea_adamw_solve(a_)); }
 };

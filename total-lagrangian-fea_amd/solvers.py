@@ -322,6 +322,21 @@ class SyncedAdamWNocoopSolver:
         return dict(outer=int(st[0]), inner=int(st[1]), norm_g=st[2], norm_c=st[3], inner_flag=int(st[4]), ms=st[5])
 
 
+class SyncedAdamWSolver(SyncedAdamWNocoopSolver):
+    """SyncedAdamWSolver (SyncedAdamW.cuh, SyncedAdamW.cu:96-445): the cooperative-kernel sibling of the same solver; as
+    written there the inner-converged flag is cleared once per Solve(), the multipliers get rho*dt*c once and the outer
+    loop stops on ||c|| < outer_tol alone."""
+
+    def __init__(self, data, n_constraints):
+        super().__init__(data, n_constraints)
+        check(self._lib.tlfea_adamw_set_cooperative_semantics(self._h, 1))
+
+    OneStepAdamW = SyncedAdamWNocoopSolver.Solve
+
+
+SyncedAdamWParams = SyncedAdamWNocoopParams
+
+
 @dataclass
 class SyncedNesterovParams:
     """SyncedNesterovParams (SyncedNesterov.cuh:26-30; driver values test_ancf3243.cc:351-352)."""
