@@ -890,6 +890,17 @@ struct GPU_ANCF_DataBase : public GPU_FEAT10_Data {
     c.resize(n_constraint);
     TLFEA_SOFT(tlfea_t10_retrieve_constraint_data(h, c.data()));
   }
+  // dense n_constraint x 3 n_coef Jacobian (ANCF3243Data.cu:758-778: the selector rows of the pinned coefficients; the
+  // CSR rows when general linear constraints are set); all zeros before the constraints are set up
+  void RetrieveConstraintJacobianToCPU(tlfea::MatrixXd& constraint_jac) {
+    constraint_jac.resize(n_constraint, 3 * n_coef);
+    if (!tlfea_t10_is_constraint_setup(h) || n_constraint == 0) return;
+    std::vector<int> off, col;
+    std::vector<double> val;
+    RetrieveConstraintJacobianCSRToCPU(off, col, val);
+    for (int r = 0; r < n_constraint; r++)
+      for (int k = off[r]; k < off[r + 1]; k++) constraint_jac(r, col[k]) = val[k];
+  }
   int n_beam;
 
  protected:

@@ -207,6 +207,15 @@ void strip_3443() {
   double cmax = 0.0;
   for (int i = 0; i < c.size(); i++) cmax = std::max(cmax, std::fabs(c(i)));
   check(c.size() == 24 && cmax == 0.0, "3443 strip: 24 satisfied constraints (8 fixed coefficients)");
+  tlfea::MatrixXd Jd;
+  data.RetrieveConstraintJacobianToCPU(Jd);
+  bool jd = Jd.rows() == 24 && Jd.cols() == 96;
+  double jsum = 0.0;
+  for (int r = 0; jd && r < 24; r++) {
+    for (int cc = 0; cc < 96; cc++) jsum += Jd(r, cc);
+    jd = Jd(r, 3 * fixed(r / 3) + r % 3) == 1.0;
+  }
+  check(jd && jsum == 24.0, "3443 strip: dense constraint Jacobian = selector rows of the pinned coefficients");
   data.Destroy();
 }
 // visualization_utils.h:491-1097: the VTU files the drivers write (host only): point / cell counts and corner geometry
