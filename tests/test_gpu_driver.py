@@ -135,7 +135,7 @@ def test_cpp_facade_host_utilities_known_answers(tmp_path):
     without a GPU, after which the program stops with its "No HIP device" status when none is visible."""
     subprocess.check_call(["make", "-C", os.path.dirname(DRIVER)])
     out = subprocess.run([UTEST, f"--data_dir={MESHES}", f"--tmp_dir={tmp_path}"], capture_output=True, text=True, timeout=300)
-    assert out.stdout.count("[ OK ]") >= 21 and "[FAIL]" not in out.stdout, out.stdout + out.stderr
+    assert out.stdout.count("[ OK ]") >= 22 and "[FAIL]" not in out.stdout, out.stdout + out.stderr
     assert out.returncode in (0, 101)
 
 
@@ -147,7 +147,7 @@ def test_cpp_facade_reference_unit_tests(tmp_path):
         subprocess.check_call(["make", "-C", os.path.dirname(DRIVER)])
     out = subprocess.run([UTEST, f"--data_dir={MESHES}", f"--tmp_dir={tmp_path}", "--print_dsdu"], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
-    assert "[FAIL]" not in out.stdout and out.stdout.count("[ OK ]") >= 43
+    assert "[FAIL]" not in out.stdout and out.stdout.count("[ OK ]") >= 44
     assert "=== Elem 0 Quadrature Point 11 detJ_ref=0.25 ===" in out.stdout and "Shape 7: " in out.stdout
 
 

@@ -49,8 +49,33 @@ static const tlfea::VectorXd tet5pt_y = make5({0.25, kB, kB, 0.5, kB});
 static const tlfea::VectorXd tet5pt_z = make5({0.25, kB, kB, kB, 0.5});
 static const tlfea::VectorXd tet5pt_weights =
     make5({-4.0 / 5.0 * kB, 9.0 / 20.0 * kB, 9.0 / 20.0 * kB, 9.0 / 20.0 * kB, 9.0 / 20.0 * kB});
+// barycentric rows [L1..L4] and (xi, eta, zeta) = columns 1..3 of the Keast rule, and the struct that wraps them (:140-171)
+inline tlfea::MatrixXd make_tet5pt_bary() {
+  tlfea::MatrixXd m(5, 4);
+  for (int q = 0; q < 5; q++)
+    for (int c = 0; c < 4; c++) m(q, c) = q == 0 ? 0.25 : (c == q - 1 ? 0.5 : kB);
+  return m;
+}
+inline tlfea::MatrixXd make_tet5pt_xyz() {
+  tlfea::MatrixXd m(5, 3);
+  for (int q = 0; q < 5; q++) {
+    m(q, 0) = tet5pt_x(q);
+    m(q, 1) = tet5pt_y(q);
+    m(q, 2) = tet5pt_z(q);
+  }
+  return m;
+}
+static const tlfea::MatrixXd tet5pt_bary = make_tet5pt_bary();
+static const tlfea::MatrixXd tet5pt_xyz = make_tet5pt_xyz();
+struct Tet5ptQuadrature {
+  static constexpr int n_points = N_QP_T10_5;
+  static const tlfea::MatrixXd& barycentric() { return tet5pt_bary; }
+  static const tlfea::MatrixXd& xyz() { return tet5pt_xyz; }
+  static const tlfea::VectorXd& weights() { return tet5pt_weights; }
+};
 // Gauss-Legendre tables of the ANCF elements (quadrature_utils.h:8-128)
-constexpr int N_SHAPE_3243 = 8, N_SHAPE_3443 = 16, N_TOTAL_QP_3_2_2 = 12, N_TOTAL_QP_4_4_3 = 48;
+constexpr int N_QP_2 = 2, N_QP_3 = 3, N_QP_4 = 4, N_QP_5 = 5, N_QP_6 = 6, N_QP_7 = 7;
+constexpr int N_SHAPE_3243 = 8, N_SHAPE_3443 = 16, N_TOTAL_QP_3_2_2 = 12, N_TOTAL_QP_4_4_3 = 48, N_TOTAL_QP_7_7_3 = 147;
 inline tlfea::VectorXd makev(std::initializer_list<double> a) {
   tlfea::VectorXd v(static_cast<int>(a.size()));
   int i = 0;

@@ -109,6 +109,18 @@ void mass_known_answer(int n_beams, const std::string& data_dir) {
 }
 
 void utils_known_answers() {
+  {  // quadrature_utils.h:134-171: Keast rule (bary rows sum to 1, columns 1..3 = the points, weights sum to 1/6)
+    const tlfea::MatrixXd& b = Quadrature::Tet5ptQuadrature::barycentric();
+    double wsum = 0.0;
+    bool okq = b.rows() == 5 && b.cols() == 4 && Quadrature::Tet5ptQuadrature::n_points == 5;
+    for (int q = 0; okq && q < 5; q++) {
+      okq = std::fabs(b(q, 0) + b(q, 1) + b(q, 2) + b(q, 3) - 1.0) < 1e-15 && b(q, 1) == Quadrature::tet5pt_x(q) &&
+            Quadrature::tet5pt_xyz(q, 2) == Quadrature::tet5pt_z(q);
+      wsum += Quadrature::Tet5ptQuadrature::weights()(q);
+    }
+    check(okq && std::fabs(wsum - 1.0 / 6.0) < 1e-15 && Quadrature::tet5pt_weights(0) < 0.0 && Quadrature::N_TOTAL_QP_7_7_3 == 147,
+          "Quadrature: 5-point Keast rule (negative first weight), size constants");
+  }
   tlfea::VectorXi s, e;
   ANCFCPUUtils::ANCF3243_calculate_offsets(5, s, e);
   bool ok = s.size() == 5 && e.size() == 5;
