@@ -241,6 +241,16 @@ typedef int (*tlfea_allreduce_fn)(void *user, double *d_buf, int n);
 int tlfea_newton_set_interface(tlfea_newton_t s, const int *iface_nodes, const int *iface_slots, int n_local,
                                int n_global, const double *node_weight /*N*/, tlfea_allreduce_fn fn,
                                void *user, int sync_before_callback);
+/* Built-in all-reduce for tlfea_newton_set_interface: RCCL called from C++ on the solver's launch stream -- no host
+ * language in the loop, no host synchronisation (opt-in; the Python host layer's default goes through torch.distributed).
+ * The RCCL library is resolved at run time (the copy already mapped into the process -- e.g. a PyTorch wheel's -- else
+ * librccl.so from the loader path), so the engine carries no link-time dependency on it.
+ *   rank 0: tlfea_rccl_unique_id(id) -> ship the 128 bytes to every rank -> tlfea_rccl_comm_create(id, rank, world, &comm)
+ *   tlfea_newton_set_interface(..., tlfea_rccl_allreduce_fn(), comm, 0) ;  tlfea_rccl_comm_destroy(comm) at the end */
+int tlfea_rccl_unique_id(char *id128);
+int tlfea_rccl_comm_create(const char *id128, int rank, int world, void **comm_out);
+int tlfea_rccl_comm_destroy(void *comm);
+tlfea_allreduce_fn tlfea_rccl_allreduce_fn(void);
 /* Owners of the replicated partition-boundary nodes: owned[N] = 1 where this rank owns the node (every node has exactly
  * one owner over all ranks; interior nodes: 1).  Makes the polynomial preconditioner rank-local (block-Jacobi over ranks:
  * no exchange inside the polynomial, one packed all-reduce per CG iteration for its result) instead of one exchange per

@@ -151,6 +151,8 @@ def main():
                     help="rank-local polynomial preconditioner (owners set) or one exchange per polynomial step")
     ap.add_argument("--backend", default="gloo", choices=("gloo", "nccl"),
                     help="nccl = RCCL on device buffers (the production exchange); one rank per GPU")
+    ap.add_argument("--native-rccl", action="store_true",
+                    help="the engine's built-in RCCL all-reduce (tlfea_rccl_*) instead of the torch.distributed callback")
     ap.add_argument("--fake-iface", action="store_true",
                     help="world_size 1: declare a band of nodes an 'interface' of multiplicity 1, so that every exchange "
                          "of the partitioned path runs (as an identity all-reduce) on the one GPU of the test box")
@@ -187,7 +189,8 @@ def main():
         s = tl.SyncedNewtonSolver(d, d.get_n_constraint())
         s.SetParameters(tl.SyncedNewtonParams(1e-4, 0.0, 1e-6, 1e14, 5, 12, 1e-3))
         s.SetLinSolveOpts(tl.LinSolveOpts(1e-13, 20000, 10))
-        par.attach(s, part, torch, dist, local_preconditioner=(args.precond == "local"))
+        comm = par.rccl_communicator(dist, rank, world) if args.native_rccl else None
+        par.attach(s, part, torch, dist, local_preconditioner=(args.precond == "local"), native_rccl=comm)
         if os.environ.get("TLFEA_VERBOSE"):
             s.SetVerbose(1)
         counts = []
@@ -201,6 +204,8 @@ def main():
         x_loc = np.stack(d.RetrievePositionToCPU(), axis=1)
         del s
         d.Destroy()
+        if comm is not None:
+            par.rccl_destroy(comm)
 
     gathered = [None] * world
     dist.all_gather_object(gathered, (part.l2g, x_loc))

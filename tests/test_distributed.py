@@ -126,6 +126,16 @@ def test_rccl_exchange_path_single_rank(tmp_path):
 
 
 @pytest.mark.gpu
+def test_builtin_rccl_exchange_single_rank(tmp_path):
+    """The opt-in exchange that needs no host language in the loop (tlfea_rccl_*: RCCL resolved at run time, collectives
+    enqueued from C++ on the solver's stream): communicator creation from a shipped unique id, every exchange of the
+    partitioned path as a 1-rank all-reduce, same step as the un-partitioned oracle."""
+    rep = launch(1, ["--engine", "hip", "--mesh", "res2", "--steps", "2", "--backend", "nccl", "--fake-iface",
+                     "--native-rccl"], tmp_path)
+    assert rep["ok"] and rep["n_iface"] == 40, rep
+
+
+@pytest.mark.gpu
 def test_bench_two_ranks_rehearsal(tmp_path):
     """bench.py --gpus 2 end to end (slab construction, interface attach, timing loop, JSON line) with the gloo
     rehearsal backend: both ranks share the one GPU of the test box; production uses nccl (RCCL)."""

@@ -19,7 +19,7 @@ wl = importlib.import_module("total-lagrangian-fea_amd.workloads")
 par = importlib.import_module("total-lagrangian-fea_amd.partition")
 
 
-def run(with_iface):
+def run(with_iface, comm=None):
     w = wl.build("B")
     d, s = wl.make_engine(tl, w)
     s.SetLinSolveOpts(tl.LinSolveOpts(1e-12, 5000, 25, 0, 0.0, 0, 1))  # Chebyshev, as with an interface
@@ -28,14 +28,14 @@ def run(with_iface):
         plane = np.where(np.abs(X[:, 0] - 0.5) < 1e-9)[0].astype(np.int32)
         part = par.Partition(0, 1, X, None, np.arange(X.shape[0]), plane, np.arange(len(plane)), len(plane),
                              np.ones(X.shape[0]))
-        par.attach(s, part, torch, dist)
+        par.attach(s, part, torch, dist, native_rccl=comm)
     d.UpdatePositions(w["x0"][:, 0], w["x0"][:, 1], w["x0"][:, 2])
     for i in range(6):
         if i % 3 == 0:
             s.BeginStep()
         s.NewtonIteration()
     torch.cuda.synchronize()
-    c0 = s.n_collectives if with_iface else 0
+    c0 = s.n_collectives if (with_iface and comm is None) else 0
     t0 = time.perf_counter()
     its = []
     for i in range(12):
@@ -44,7 +44,7 @@ def run(with_iface):
         its.append(s.NewtonIteration()[1])
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) * 1e3 / 12
-    ncoll = (s.n_collectives - c0) / 12 if with_iface else 0
+    ncoll = (s.n_collectives - c0) / 12 if (with_iface and comm is None) else 0
     del s
     d.Destroy()
     return ms, float(np.mean(its)), ncoll
@@ -58,4 +58,9 @@ if __name__ == "__main__":
     print("no interface   : %.3f ms per Newton iteration, %.1f CG iterations" % a[:2])
     print("with interface : %.3f ms per Newton iteration, %.1f CG iterations, %.0f collectives" % b)
     print("per collective : %.1f us (1-rank identity all-reduce + callback)" % ((b[0] - a[0]) * 1e3 / max(1.0, b[2])))
+    comm = par.rccl_communicator(dist, 0, 1)
+    c = run(True, comm)
+    print("built-in RCCL  : %.3f ms per Newton iteration, %.1f CG iterations -> %.1f us per collective"
+          % (c[0], c[1], (c[0] - a[0]) * 1e3 / max(1.0, b[2])))
+    par.rccl_destroy(comm)
     dist.destroy_process_group()

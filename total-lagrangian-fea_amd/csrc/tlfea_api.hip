@@ -2,6 +2,7 @@
 // side of the sparsity analysis, and the ALM/Newton control flow of the reference
 // (SyncedNewton.cu:909-1146) with the device PCG in place of cuDSS.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cmath>
@@ -19,6 +20,10 @@
 #include "vbd_host.h"
 
 using namespace tlfea;
+
+struct RcclUniqueId {  // == ncclUniqueId (rccl.h): 128 opaque bytes, passed BY VALUE to ncclCommInitRank
+  char internal[128];
+};
 
 namespace {
 thread_local std::string g_err;
@@ -1149,6 +1154,77 @@ extern "C" int tlfea_newton_set_interface(tlfea_newton_t s, const int* iface_nod
   s->n_constraints_global = (int)(cnt + 0.5);
   return 0;
 }
+
+// ---- built-in RCCL all-reduce (opt-in): the collective is enqueued from C++ on the stream the solver launches on -------
+namespace {
+struct RcclApi {
+  void* lib = nullptr;
+  int (*get_unique_id)(void*) = nullptr;
+  int (*comm_init_rank)(void**, int, RcclUniqueId, int) = nullptr;
+  int (*all_reduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  int (*comm_destroy)(void*) = nullptr;
+  const char* (*error_string)(int) = nullptr;
+};
+RcclApi& rccl_api() {
+  static RcclApi a;
+  if (a.lib) return a;
+  for (const char* name : {"librccl.so", "librccl.so.1"}) {
+    a.lib = dlopen(name, RTLD_NOW | RTLD_NOLOAD);  // the copy the process already uses (torch's), if any
+    if (a.lib) break;
+  }
+  if (!a.lib)
+    for (const char* name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+      a.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+      if (a.lib) break;
+    }
+  if (!a.lib) return a;
+  a.get_unique_id = (int (*)(void*))dlsym(a.lib, "ncclGetUniqueId");
+  a.comm_init_rank = (int (*)(void**, int, RcclUniqueId, int))dlsym(a.lib, "ncclCommInitRank");
+  a.all_reduce = (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))dlsym(a.lib, "ncclAllReduce");
+  a.comm_destroy = (int (*)(void*))dlsym(a.lib, "ncclCommDestroy");
+  a.error_string = (const char* (*)(int))dlsym(a.lib, "ncclGetErrorString");
+  if (!a.get_unique_id || !a.comm_init_rank || !a.all_reduce || !a.comm_destroy) a.lib = nullptr;
+  return a;
+}
+int rccl_fail(const char* what, int rc) {
+  RcclApi& a = rccl_api();
+  return fail(std::string(what) + ": " + (a.error_string ? a.error_string(rc) : "RCCL error " + std::to_string(rc)));
+}
+int rccl_allreduce_cb(void* comm, double* d_buf, int n) {  // sum of n doubles in place, on the null stream (the solver's
+  RcclApi& a = rccl_api();                                  // launch stream once an interface is set)
+  const int rc = a.all_reduce(d_buf, d_buf, (size_t)n, /*ncclDouble*/ 8, /*ncclSum*/ 0, comm, nullptr);
+  return rc == 0 ? 0 : 1;
+}
+}  // namespace
+
+extern "C" int tlfea_rccl_unique_id(char* id128) {
+  RcclApi& a = rccl_api();
+  if (!a.lib) return fail("tlfea_rccl: librccl.so could not be resolved");
+  RcclUniqueId id;
+  const int rc = a.get_unique_id(&id);
+  if (rc) return rccl_fail("ncclGetUniqueId", rc);
+  std::memcpy(id128, id.internal, 128);
+  return 0;
+}
+extern "C" int tlfea_rccl_comm_create(const char* id128, int rank, int world, void** comm_out) {
+  RcclApi& a = rccl_api();
+  if (!a.lib) return fail("tlfea_rccl: librccl.so could not be resolved");
+  RcclUniqueId id;
+  std::memcpy(id.internal, id128, 128);
+  void* comm = nullptr;
+  const int rc = a.comm_init_rank(&comm, world, id, rank);
+  if (rc) return rccl_fail("ncclCommInitRank", rc);
+  *comm_out = comm;
+  return 0;
+}
+extern "C" int tlfea_rccl_comm_destroy(void* comm) {
+  RcclApi& a = rccl_api();
+  if (!a.lib || !comm) return 0;
+  HIP_TRY(hipDeviceSynchronize());
+  const int rc = a.comm_destroy(comm);
+  return rc ? rccl_fail("ncclCommDestroy", rc) : 0;
+}
+extern "C" tlfea_allreduce_fn tlfea_rccl_allreduce_fn(void) { return rccl_allreduce_cb; }
 
 // Which of the replicated partition-boundary nodes this rank OWNS (exactly one owner per node over all ranks; interior
 // nodes are owned by definition).  With owners set, the polynomial preconditioner becomes rank-local: each rank

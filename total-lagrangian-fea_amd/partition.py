@@ -127,14 +127,40 @@ def make_allreduce(torch, dist, backend):
     return ar_host, 1
 
 
-def attach(solver, part, torch, dist, local_preconditioner=False):
+def rccl_communicator(dist, rank, world):
+    """A RCCL communicator owned by the engine (tlfea_rccl_*): rank 0 creates the unique id, torch.distributed ships its
+    128 bytes once, every rank joins.  -> opaque handle for SyncedNewtonSolver.SetInterfaceRccl / rccl_destroy."""
+    import ctypes as C
+
+    from . import binding
+    lib = binding.load_library()
+    buf = C.create_string_buffer(128)
+    if rank == 0:
+        binding.check(lib.tlfea_rccl_unique_id(buf))
+    box = [buf.raw]
+    if world > 1:
+        dist.broadcast_object_list(box, src=0)
+    comm = C.c_void_p()
+    binding.check(lib.tlfea_rccl_comm_create(box[0], int(rank), int(world), C.byref(comm)))
+    return comm
+
+
+def rccl_destroy(comm):
+    from . import binding
+    binding.check(binding.load_library().tlfea_rccl_comm_destroy(comm))
+
+
+def attach(solver, part, torch, dist, local_preconditioner=False, native_rccl=None):
     """Wire a SyncedNewtonSolver to its partition's interface exchange.  local_preconditioner: rank-local polynomial
     preconditioner on the owned nodes (one collective per CG iteration for its result) instead of one exchange per
     polynomial step.  Off by default: without overlap the decoupled blocks cost 3-4x more CG iterations (measured:
     two config-B slabs 35 -> 96 iterations), which outweighs the saved collectives unless the
     fabric latency is far above the kernel times."""
-    ar, sync = make_allreduce(torch, dist, dist.get_backend())
-    solver.SetInterface(part.iface_nodes, part.iface_slots, part.n_global_iface, part.node_weight, ar, sync)
+    if native_rccl is not None:   # opt-in: the engine's own RCCL communicator, collectives enqueued from C++
+        solver.SetInterfaceRccl(part.iface_nodes, part.iface_slots, part.n_global_iface, part.node_weight, native_rccl)
+    else:
+        ar, sync = make_allreduce(torch, dist, dist.get_backend())
+        solver.SetInterface(part.iface_nodes, part.iface_slots, part.n_global_iface, part.node_weight, ar, sync)
     if local_preconditioner:
         solver.SetInterfaceOwners(part.node_owned)
 

@@ -240,6 +240,21 @@ class SyncedNewtonSolver:
                                                    int(n_global_iface), dp(w), self._cb, None,
                                                    int(sync_before_callback)))
 
+    def SetInterfaceRccl(self, iface_nodes, iface_slots, n_global_iface, node_weight, comm):
+        """The same interface with the library's built-in RCCL all-reduce (tlfea_rccl_allreduce_fn): the collective is
+        enqueued from C++ on the solver's launch stream, no Python in the loop.  comm: handle from
+        partition.rccl_communicator()."""
+        nodes = np.ascontiguousarray(iface_nodes, dtype=np.int32)
+        slots = np.ascontiguousarray(iface_slots, dtype=np.int32)
+        w = np.ascontiguousarray(node_weight, dtype=np.float64)
+        assert w.size == self.n_coef and nodes.size == slots.size
+        self._lib.tlfea_rccl_allreduce_fn.restype = C.c_void_p
+        fn = C.cast(self._lib.tlfea_rccl_allreduce_fn(), ALLREDUCE_FN)
+        self.n_collectives = -1   # not counted on this path
+        self._cb = fn
+        check(self._lib.tlfea_newton_set_interface(self._h, ip(nodes), ip(slots), int(nodes.size),
+                                                   int(n_global_iface), dp(w), fn, comm, 0))
+
     def SetInterfaceOwners(self, node_owned):
         """node_owned[n_coef] = 1 where this rank owns the node (one owner per replicated node over all ranks):
         switches the polynomial preconditioner to its rank-local form (see tlfea_c.h)."""
