@@ -61,6 +61,10 @@ def main():
                          "(clock ramp / first-touch events of a fresh process), then the state is reset")
     ap.add_argument("--local-precond", action="store_true",
                     help="multi-GPU: rank-local polynomial preconditioner (fewer collectives, 3-4x more CG iterations)")
+    ap.add_argument("--native-rccl", action="store_true",
+                    help="multi-GPU: the engine's built-in RCCL all-reduce (enqueued from C++, ~1.6 us of host time per "
+                         "exchange instead of ~15-29 us through torch.distributed); validated with one rank only so far, "
+                         "hence opt-in (also TLFEA_BENCH_NATIVE_RCCL=1)")
     ap.add_argument("--precond", type=int, default=0, choices=(0, 1, 2),
                     help="0 auto, 1 Chebyshev polynomial, 2 two-level p-multigrid (T10, one GPU)")
     ap.add_argument("--cheb-kappa", type=float, default=0.0, help="polynomial interval [lmax/kappa, lmax] (0 = default)")
@@ -109,7 +113,9 @@ def main():
     d, s = wl.make_engine(tl, w)
     s.SetLinSolveOpts(tl.LinSolveOpts(args.rel_tol, args.max_pcg, 25, args.cheb_deg, args.cheb_kappa, args.cheb_bits, args.precond))
     if world > 1:
-        par.attach(s, part, torch, dist, local_preconditioner=args.local_precond)
+        native = args.native_rccl or bool(os.environ.get("TLFEA_BENCH_NATIVE_RCCL"))
+        comm = par.rccl_communicator(dist, rank, world) if (native and backend == "nccl") else None
+        par.attach(s, part, torch, dist, local_preconditioner=args.local_precond, native_rccl=comm)
     d.UpdatePositions(w["x0"][:, 0], w["x0"][:, 1], w["x0"][:, 2])
     E, N = w["conn"].shape[0], w["X"].shape[0]
     nnz_coef = int(d.RetrieveMassCSRToCPU()[0][-1])
