@@ -575,9 +575,11 @@ struct TangentLds {
   static constexpr int kH = ((3 * S + 1) / 2) * 2;               // hs[QC][3][S]  (global order)
   static constexpr int kF = kH + ((QC * 3 * S + 1) / 2) * 2;     // Fs[QC][9]
   static constexpr int kU = kF + ((QC * 9 + 1) / 2) * 2;         // SVK: Fh | FFT | sc ; MR: st | At
-  static constexpr int kUsize = (MODEL == kSVK) ? (QC * 3 * S + QC * 6 + QC * 4) : (QC * 64 + QC * 81);
+  // SVK: per (point, node) the packed record {h0,h1,h2,Fh0,Fh1,Fh2} (three 16-byte LDS reads per node in the pair loop)
+  static constexpr int kUsize = (MODEL == kSVK) ? (QC * 6 * S + QC * 6 + QC * 4) : (QC * 64 + QC * 81);
   static constexpr int kPairs = S * (S + 1) / 2;
-  static constexpr int kTotal = (kU + kUsize > kPairs * 9) ? (kU + kUsize) : (kPairs * 9);
+  static constexpr int kRaw = (kU + kUsize > kPairs * 9) ? (kU + kUsize) : (kPairs * 9);
+  static constexpr int kTotal = ((kRaw + 1) / 2) * 2;  // even: every wave's slice stays 16-byte aligned
 };
 
 // WPB wavefronts per workgroup, one element each (own LDS slice); all waves run the same barrier sequence, so
@@ -588,7 +590,7 @@ __global__ __launch_bounds__(64 * WPB) void tangent_blocks_kernel(ElemView m, Ma
   using LD = TangentLds<S, Q, QC, MODEL>;
   constexpr int P = LD::kPairs;
   constexpr int NPL = (P + 63) / 64;  // pairs per lane
-  __shared__ double lds_all[LD::kTotal * WPB];
+  __shared__ __attribute__((aligned(16))) double lds_all[LD::kTotal * WPB];
   double* lds = lds_all + (threadIdx.x >> 6) * LD::kTotal;
   double* xs = lds + LD::kX;
   double* hs = lds + LD::kH;
@@ -633,13 +635,21 @@ __global__ __launch_bounds__(64 * WPB) void tangent_blocks_kernel(ElemView m, Ma
     __syncthreads();
 
     if (MODEL == kSVK) {
-      double* Fh = U;                 // [QC][S][3]
-      double* FFT = U + QC * 3 * S;   // [QC][6]  (00,01,02,11,12,22)
+      double* G = U;                  // [QC][S][6]: h_a (3), F h_a (3), 16-byte aligned records
+      double* FFT = U + QC * 6 * S;   // [QC][6]  (00,01,02,11,12,22)
       double* sc = FFT + QC * 6;      // [QC][4]
-      for (int t = lane; t < QC * 3 * S; t += 64) {  // Fh_a^q[r] = sum_c F_q[r][c] h_a^q[c]
-        const int q = t / (3 * S), a = (t % (3 * S)) / 3, r = t % 3;
+      for (int t = lane; t < QC * S; t += 64) {  // Fh_a^q[r] = sum_c F_q[r][c] h_a^q[c]
+        const int q = t / S, a = t - q * S;
         const double* hq = hs + q * 3 * S;
-        Fh[t] = Fs[q * 9 + r * 3 + 0] * hq[a] + Fs[q * 9 + r * 3 + 1] * hq[S + a] + Fs[q * 9 + r * 3 + 2] * hq[2 * S + a];
+        const double* F = Fs + q * 9;
+        const double h0 = hq[a], h1 = hq[S + a], h2 = hq[2 * S + a];
+        double* g = G + (size_t)t * 6;
+        g[0] = h0;
+        g[1] = h1;
+        g[2] = h2;
+        g[3] = F[0] * h0 + F[1] * h1 + F[2] * h2;
+        g[4] = F[3] * h0 + F[4] * h1 + F[5] * h2;
+        g[5] = F[6] * h0 + F[7] * h1 + F[8] * h2;
       }
       for (int t = lane; t < QC * 6; t += 64) {
         const int q = t / 6, k = t % 6;
@@ -669,21 +679,23 @@ __global__ __launch_bounds__(64 * WPB) void tangent_blocks_kernel(ElemView m, Ma
         const int i = pi[n], j = pj[n];
 #pragma unroll 1
         for (int q = 0; q < QC; q++) {
-          const double* hq = hs + q * 3 * S;
-          const double hi0 = hq[i], hi1 = hq[S + i], hi2 = hq[2 * S + i];
-          const double hj0 = hq[j], hj1 = hq[S + j], hj2 = hq[2 * S + j];
-          const double* fi = Fh + q * 3 * S + i * 3;
-          const double* fj = Fh + q * 3 * S + j * 3;
-          const double fi0 = fi[0], fi1 = fi[1], fi2 = fi[2];
-          const double fj0 = fj[0], fj1 = fj[1], fj2 = fj[2];
-          const double A1 = sc[q * 4 + 0], B1 = sc[q * 4 + 1], C0 = sc[q * 4 + 2], C1 = sc[q * 4 + 3];
+          const double2* gi = reinterpret_cast<const double2*>(G + ((size_t)q * S + i) * 6);
+          const double2* gj = reinterpret_cast<const double2*>(G + ((size_t)q * S + j) * 6);
+          const double2 i01 = gi[0], i23 = gi[1], i45 = gi[2], j01 = gj[0], j23 = gj[1], j45 = gj[2];
+          const double hi0 = i01.x, hi1 = i01.y, hi2 = i23.x, fi0 = i23.y, fi1 = i45.x, fi2 = i45.y;
+          const double hj0 = j01.x, hj1 = j01.y, hj2 = j23.x, fj0 = j23.y, fj1 = j45.x, fj2 = j45.y;
+          const double2* scq = reinterpret_cast<const double2*>(sc + q * 4);
+          const double2 s01 = scq[0], s23 = scq[1];
+          const double A1 = s01.x, B1 = s01.y, C0 = s23.x, C1 = s23.y;
           const double s = hi0 * hj0 + hi1 * hj1 + hi2 * hj2;
           const double t = fi0 * fj0 + fi1 * fj1 + fi2 * fj2;
           const double bs = B1 * s;
           const double cd = C0 * s + C1 * t;
           const double u0 = A1 * fi0, u1 = A1 * fi1, u2 = A1 * fi2;
           const double w0 = B1 * fj0, w1 = B1 * fj1, w2 = B1 * fj2;
-          const double* T = FFT + q * 6;
+          const double2* Tq = reinterpret_cast<const double2*>(FFT + q * 6);
+          const double2 t01 = Tq[0], t23 = Tq[1], t45 = Tq[2];
+          const double T[6] = {t01.x, t01.y, t23.x, t23.y, t45.x, t45.y};
           acc[n][0] += u0 * fj0 + w0 * fi0 + bs * T[0] + cd;
           acc[n][1] += u0 * fj1 + w0 * fi1 + bs * T[1];
           acc[n][2] += u0 * fj2 + w0 * fi2 + bs * T[2];
