@@ -75,7 +75,7 @@ def test_cpp_ancf3243_cantilever_config_a(tmp_path):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("joint", ["welded", "pinned"])
-def test_cpp_ancf3243_net_driver(joint):
+def test_cpp_ancf3243_net_driver(joint, tmp_path):
     """lib_bin/mesh_deform/test_ancf3243_net_newton.cc flow through the C++ facade (mesh reader, LinearConstraintBuilder,
     corner clamps as AddFixedDof rows, SetLinearConstraintsCSR) vs the oracle: centre deflection per step."""
     from tests.test_gpu_linear_constraints import make_pair, net_problem
@@ -84,9 +84,10 @@ def test_cpp_ancf3243_net_driver(joint):
     if not os.path.exists(drv):
         subprocess.check_call(["make", "-C", os.path.dirname(DRIVER)])
     path = NET_W if joint == "welded" else NET_P
-    out = subprocess.run([drv, f"--joint={joint}", "--steps=2", f"--mesh={path}"], capture_output=True, text=True,
-                         timeout=300)
+    out = subprocess.run([drv, f"--joint={joint}", "--steps=2", f"--mesh={path}", f"--vtu={tmp_path}/vtu"],
+                         capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr
+    assert os.listdir(tmp_path / "vtu") == ["ancf3243_net_000000.vtu"]   # every 10th step
     lines = out.stdout.strip().splitlines()
     k = lines.index("step,centre_z,constraint_norm")
     rows = np.array([[float(v) for v in ln.split(",")] for ln in lines[k + 1:]])

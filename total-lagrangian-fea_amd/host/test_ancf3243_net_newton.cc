@@ -2,10 +2,12 @@
 // lib_bin/mesh_deform/test_ancf3243_net_newton.cc (:385-505) on the facade over the C-ABI.
 // Same options (--joint --steps --dt --W --H --center_force_z --verbose), materials (:32-37), corner clamps written as
 // AddFixedDof rows appended to the mesh file's joint constraints (:233-276), centre point load (:278-337) and solver
-// parameters (:484).  --mesh=PATH replaces the reference's data/ paths; the VTU export (--vtu) is out of scope.
+// parameters (:484).  --mesh=PATH replaces the reference's data/ paths; --vtu[=DIR] writes one hexahedron per beam every
+// 10 steps to output/ancf3243_net/ancf3243_net_<step>.vtu (:40-41, 465-496).
 // Prints the centre deflection per step as CSV (the reference prints nothing per step).
 #include <cmath>
 #include <cstdio>
+#include <filesystem>
 #include <limits>
 #include <memory>
 
@@ -15,7 +17,7 @@ namespace {
 constexpr double kE = 7e8, kNu = 0.33, kRho0 = 2700;
 
 struct Options {
-  std::string joint = "welded", mesh;
+  std::string joint = "welded", mesh, vtu_dir;
   int steps = 50;
   double dt = 1e-3, W = 0.1, H = 0.1, center_force_z = -1000.0;
   bool verbose = false;
@@ -40,6 +42,8 @@ bool parse_args(int argc, char** argv, Options& o) {
       else if (starts_with(a, "--W=")) o.W = std::stod(val("--W="));
       else if (starts_with(a, "--H=")) o.H = std::stod(val("--H="));
       else if (starts_with(a, "--center_force_z=")) o.center_force_z = std::stod(val("--center_force_z="));
+      else if (a == "--vtu") o.vtu_dir = "output/ancf3243_net";
+      else if (starts_with(a, "--vtu=")) o.vtu_dir = val("--vtu=");
       else if (a == "--verbose") o.verbose = true;
       else {
         std::cerr << "Unknown argument: " << a << "\n";
@@ -140,9 +144,22 @@ int main(int argc, char** argv) {
 
   std::printf("step,centre_z,constraint_norm\n");
   tlfea::VectorXd x12, y12, z12, c;
+  auto write_vtu = [&](int step) {
+    if (opt.vtu_dir.empty() || step % 10 != 0) return;
+    char name[64];
+    std::snprintf(name, sizeof name, "/ancf3243_net_%06d.vtu", step);
+    ANCFCPUUtils::VisualizationUtils::ExportANCF3243ToVTU(x12, y12, z12, mesh.element_connectivity, opt.W, opt.H,
+                                                          opt.vtu_dir + name);
+  };
+  if (!opt.vtu_dir.empty()) {
+    std::filesystem::create_directories(opt.vtu_dir);
+    data.RetrievePositionToCPU(x12, y12, z12);
+    write_vtu(0);
+  }
   for (int step = 0; step < opt.steps; ++step) {
     solver.Solve();
     data.RetrievePositionToCPU(x12, y12, z12);
+    write_vtu(step + 1);
     data.CalcConstraintData();
     data.RetrieveConstraintDataToCPU(c);
     double cn = 0.0;
