@@ -348,3 +348,24 @@ def test_adamw_cooperative_sibling_semantics():
     assert out["coop"] == (3, 1, 3, 1), out       # converged at the first check, never re-entered
     assert out["nocoop"] == (3, 3, 3, 3), out     # flag cleared per outer iteration: one inner iteration each
     d.Destroy()
+
+
+def test_strip_constructor_and_print_dsdu_pre(capsys):
+    """GPU_ANCF3443_Data(num_beams) (ANCF3443Data.cuh:445-449) and PrintDsDuPre (ANCF3243Data.cu:326-360) of the
+    Python mirror: node count of the chain, text layout of the dump."""
+    kind, x, y, z, conn, (L, W, H), fixed, f_ext = PROBLEMS["shell3443"]()
+    n_beam = conn.shape[0]
+    d = tl.GPU_ANCF3443_Data(n_beam)
+    assert (d.n_nodes, d.n_elem, d.get_n_coef()) == (4 + 2 * (n_beam - 1), n_beam, len(x))
+    d.Initialize()
+    d.Setup(L, W, H, Q.gauss_xi_m_7, Q.gauss_eta_m_7, Q.gauss_zeta_m_3, Q.gauss_xi_4, Q.gauss_eta_4, Q.gauss_zeta_3,
+            Q.weight_xi_m_7, Q.weight_eta_m_7, Q.weight_zeta_m_3, Q.weight_xi_4, Q.weight_eta_4, Q.weight_zeta_3, x, y, z,
+            conn)
+    d.CalcDsDuPre()
+    d.PrintDsDuPre()
+    out = capsys.readouterr().out
+    assert out.count("=== Elem ") == n_beam * 48 and "Shape 15: " in out and "detJ_ref=" in out
+    g = d.RetrieveDnDuPreToCPU()
+    first = [float(v) for v in out.split("Shape 0: ")[1].splitlines()[0].split()]
+    assert np.allclose(first, g[0, 0, 0], atol=5e-7)
+    d.Destroy()

@@ -251,6 +251,16 @@ class _GPU_ANCF_Data(GPU_FEAT10_Data):
         check(self._lib.tlfea_ancf_create(self.KIND, self.n_nodes, self.n_elem, C.byref(self._h)))
         self._initialized = True
 
+    def PrintDsDuPre(self):
+        """Text dump of the reference gradients per (element, point) (ANCF3243Data.cu:326-360)."""
+        g, dj = self.RetrieveDnDuPreToCPU(), self.RetrieveDetJToCPU()
+        for e in range(self.n_elem):
+            for q in range(self.Q):
+                print(f"\n=== Elem {e} Quadrature Point {q} detJ_ref={dj[e, q]:g} ===")
+                print("        dN/dx       dN/dy       dN/dz")
+                for i in range(self.S):
+                    print(f"Shape {i}: " + " ".join(f"{g[e, q, i, j]:10.6f}" for j in range(3)) + " ")
+
     def _setup(self, length, width, height, mass_rule, force_rule, h_x12, h_y12, h_z12, connectivity):
         E = self.n_elem
         L, W, H = (np.ascontiguousarray(np.broadcast_to(np.asarray(a, dtype=np.float64), (E,))) for a in
@@ -290,6 +300,13 @@ class GPU_ANCF3243_Data(_GPU_ANCF_Data):
 
 class GPU_ANCF3443_Data(_GPU_ANCF_Data):
     TYPE, KIND, NN, S, Q = "TYPE_3443", 3443, 4, 16, 48
+
+    def __init__(self, num_nodes, num_elements=None):
+        """(num_nodes, num_elements), or the strip constructor (num_beams): every new shell of the chain brings two
+        new nodes (ANCF3443Data.cuh:445-457)."""
+        if num_elements is None:
+            num_elements, num_nodes = int(num_nodes), 4 + 2 * (int(num_nodes) - 1)
+        super().__init__(num_nodes, num_elements)
 
     def Setup(self, length, width, height, gauss_xi_m, gauss_eta_m, gauss_zeta_m, gauss_xi, gauss_eta, gauss_zeta,
               weight_xi_m, weight_eta_m, weight_zeta_m, weight_xi, weight_eta, weight_zeta, h_x12, h_y12, h_z12,
