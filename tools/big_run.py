@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""One GPU, BASELINE config E's mesh in one piece (180 x 120 x 60 cells x 6 = 7 776 000 T10 elements, 31.6 M DOF; the
+config is meant for 8 GPUs): set-up times, device memory, Newton iterations.  python tools/big_run.py [nx ny nz]"""
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402  (device memory query only)
+
+tl = importlib.import_module("total-lagrangian-fea_amd")
+wl = importlib.import_module("total-lagrangian-fea_amd.workloads")
+
+cells = tuple(int(v) for v in sys.argv[1:4]) if len(sys.argv) >= 4 else (180, 120, 60)
+t0 = time.time()
+# same element size as config C (1/30): a 6 x 4 x 2 bar at the default cells, clamped at x = 0, loaded at x = L
+wl.CONFIGS["C"] = dict(wl.CONFIGS["C"], cells=cells, size=(cells[0] / 30.0, cells[1] / 30.0, cells[2] / 30.0))
+w = wl.build("C")
+t_mesh = time.time() - t0
+print(f"mesh: {w['conn'].shape[0]} elements, {w['X'].shape[0]} nodes in {t_mesh:.1f} s", flush=True)
+t0 = time.time()
+d, s = wl.make_engine(tl, w)
+s.SetLinSolveOpts(tl.LinSolveOpts(1e-12, 5000, 25))
+t_setup = time.time() - t0
+print(f"engine set-up (upload, reference gradients, mass, sparsity, p-multigrid maps): {t_setup:.1f} s", flush=True)
+d.UpdatePositions(w["x0"][:, 0], w["x0"][:, 1], w["x0"][:, 2])
+out = []
+for i in range(3):
+    if i == 0:
+        s.BeginStep()
+    t1 = time.time()
+    ng, it = s.NewtonIteration()
+    out.append((round((time.time() - t1) * 1e3, 1), int(it), float(ng)))
+    print("Newton iteration", i, out[-1], flush=True)
+free, total = torch.cuda.mem_get_info()
+E = w["conn"].shape[0]
+best = min(o[0] for o in out[1:])
+print(json.dumps(dict(elements=E, nodes=int(w["X"].shape[0]), dof=3 * int(w["X"].shape[0]), mesh_s=round(t_mesh, 1),
+                      setup_s=round(t_setup, 1), newton_ms=[o[0] for o in out], cg_iterations=[o[1] for o in out],
+                      element_updates_per_s=round(E / (best * 1e-3), 1), device_GB_used=round((total - free) / 2**30, 1),
+                      pmg=s.GetPmgInfo())), flush=True)
