@@ -24,12 +24,14 @@ t_mesh = time.time() - t0
 print(f"mesh: {w['conn'].shape[0]} elements, {w['X'].shape[0]} nodes in {t_mesh:.1f} s", flush=True)
 t0 = time.time()
 d, s = wl.make_engine(tl, w)
-s.SetLinSolveOpts(tl.LinSolveOpts(1e-12, 5000, 25))
+s.SetLinSolveOpts(tl.LinSolveOpts(1e-12, 5000, 25, 0, 0.0, int(os.environ.get("BIG_BITS", "0")), int(os.environ.get("BIG_PRECOND", "0"))))
+if os.environ.get("BIG_VERBOSE"):
+    s.SetVerbose(1)
 t_setup = time.time() - t0
 print(f"engine set-up (upload, reference gradients, mass, sparsity, p-multigrid maps): {t_setup:.1f} s", flush=True)
 d.UpdatePositions(w["x0"][:, 0], w["x0"][:, 1], w["x0"][:, 2])
 out = []
-for i in range(3):
+for i in range(int(os.environ.get("BIG_ITERS", "3"))):
     if i == 0:
         s.BeginStep()
     t1 = time.time()
@@ -38,7 +40,7 @@ for i in range(3):
     print("Newton iteration", i, out[-1], flush=True)
 free, total = torch.cuda.mem_get_info()
 E = w["conn"].shape[0]
-best = min(o[0] for o in out[1:])
+best = min(o[0] for o in out[1:]) if len(out) > 1 else out[0][0]
 print(json.dumps(dict(elements=E, nodes=int(w["X"].shape[0]), dof=3 * int(w["X"].shape[0]), mesh_s=round(t_mesh, 1),
                       setup_s=round(t_setup, 1), newton_ms=[o[0] for o in out], cg_iterations=[o[1] for o in out],
                       element_updates_per_s=round(E / (best * 1e-3), 1), device_GB_used=round((total - free) / 2**30, 1),

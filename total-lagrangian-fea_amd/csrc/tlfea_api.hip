@@ -881,6 +881,10 @@ struct tlfea_newton_s {
     float* d_f32c = nullptr;   // coarse d, z^, res^ ping-pong pairs (6 x 3Nc) + (S D S)^-1 (9 Nc)
     double* d_coef = nullptr;  // [0..7] fine smoother, [8..] coarse polynomial
     double lam_c = 0.0;
+    // the coarse polynomial's degree is a size-based guess (fitted on configs B, C); when a solve stalls because the
+    // vertex-level operator is worse conditioned than the guess covers (a 5 x 3.3 x 1.7 bar of 4.5 M elements needs
+    // degree ~50 where the guess says 39), the solver raises it for this and all later solves
+    double kc_boost = 1.0;
     Incidence inc() const { return Incidence{nullptr, nullptr, nullptr, d_c_off, d_c_cols, d_c_diagpos}; }
     // third level: rigid-body-mode aggregates of the vertex level (pmg_host.h agg_build); N3 = 2 Na nodes
     struct Agg {
@@ -1611,6 +1615,10 @@ static double pmg_kappa_coarse(int kc) {
   static const double forced = std::getenv("TLFEA_PMG_KAPPA_C") ? std::atof(std::getenv("TLFEA_PMG_KAPPA_C")) : 0.0;
   return forced > 1.0 ? forced : 1.5 * kc * kc;
 }
+static int pmg_coarse_degree_eff(tlfea_newton_t s) {
+  const int base = pmg_coarse_degree(s->pmg.Nc);
+  return std::min(kPmgMaxCoarseDeg, (int)std::lround(base * s->pmg.kc_boost));
+}
 static const double kPmgKappaS = std::getenv("TLFEA_PMG_KAPPA_S") ? std::atof(std::getenv("TLFEA_PMG_KAPPA_S")) : 8.0;
 // Third level (rigid-body-mode aggregates below the vertex level): opt-in with TLFEA_PMG_LEVELS=3.  Measured at config C
 // it makes a CG iteration 10-12 % cheaper (4 vertex-level steps + a degree-20..32 polynomial on ~20 000 level-3 nodes
@@ -1835,7 +1843,7 @@ static int pmg_coefficients(tlfea_newton_t s) {
     HIP_TRY(hipMemcpyAsync(m.d_coef, h, (size_t)(16 + 2 * k3) * sizeof(double), hipMemcpyHostToDevice, s->stream));
     return 0;
   }
-  const int kc = pmg_coarse_degree(m.Nc);
+  const int kc = pmg_coarse_degree_eff(s);
   {
     const double b = s->lam_safety * m.lam_c, a = b / pmg_kappa_coarse(kc);
     const double theta = 0.5 * (b + a), delta = 0.5 * (b - a), sigma = theta / delta;
@@ -1901,7 +1909,7 @@ static int pmg_apply(tlfea_newton_t s, const double* d_r, double* d_z, double* r
     TLFEA_L2(c_d2, cf + 10, c_d, c_z2, c_z, c_r2, c_r);   // second term; the vertex-level result is in c_z
 #undef TLFEA_L2
   } else {
-    const int kc = pmg_coarse_degree(Nc);
+    const int kc = pmg_coarse_degree_eff(s);
     for (int k = 1; k < kc; k++) {
       launch_cheb32(s->stream, Nc, m.nnz_c, inc_c, m.d_B8c, m.d_B1c, bits, Dinv_fc, m.d_sc_c, c_d, cf + 8 + 2 * k, c_d2, c_z,
                     c_z2, c_r, c_r2, d_r, d_z, rz_part, false);
@@ -1994,7 +2002,7 @@ static void cg_graphs_destroy(tlfea_newton_t s) {
 // is what an iteration costs otherwise.  Single-GPU path only (the multi-GPU path calls back into the host
 // between kernels).
 static int cg_graphs_prepare(tlfea_newton_t s, double* d_x, bool fused, int deg, int bits) {
-  const long key[6] = {deg + 1000 * precond_eff(s), bits, fused ? 1 : 0, (long)(size_t)d_x, (long)(size_t)s->d_B8,
+  const long key[6] = {deg + 1000 * precond_eff(s) + 100000L * (s->pmg.ok ? pmg_coarse_degree_eff(s) : 0), bits, fused ? 1 : 0, (long)(size_t)d_x, (long)(size_t)s->d_B8,
                        (long)(size_t)s->pmg.d_B8c};
   if (s->cg_graph[0] && std::equal(key, key + 6, s->cg_graph_key)) return 0;
   cg_graphs_destroy(s);
@@ -2068,6 +2076,11 @@ static int pcg(tlfea_newton_t s, const double* d_b, double* d_x, int* iters_out,
     if (graphs) TRY(cg_graphs_prepare(s, d_x, fused, deg, bits));
     double indefinite = 0.0;
     HIP_TRY(hipMemsetAsync(s->d_scal + 3, 0, sizeof(double), s->stream));
+    // p-multigrid converges in 30-45 iterations when its coarse polynomial covers the vertex-level spectrum; far more
+    // means the size-based degree is too low for this mesh: raise it (kept for later solves) and start over
+    const int kStallIters = 80;
+    bool stalled = false;
+    int stall_check = (precond_eff(s) == 2 && s->pmg.ok && pmg_coarse_degree_eff(s) < kPmgMaxCoarseDeg) ? kStallIters : 0;
     for (int attempt = 0;; attempt++) {
       while (it < s->lin.max_iter) {
         // r.z slots of iteration `it` live in part(it & 1), the previous ones in the other pair
@@ -2076,21 +2089,41 @@ static int pcg(tlfea_newton_t s, const double* d_b, double* d_x, int* iters_out,
         else
           TRY(enqueue_cg_iteration(s, d_x, it == 0, it & 1, fused, deg));
         it++;
-        if ((it >= first_check && (it - first_check) % check_every == 0) || it == s->lin.max_iter) {
+        if ((it >= first_check && (it - first_check) % check_every == 0) || it == s->lin.max_iter || it == stall_check) {
           launch_sum_parts(s->stream, part(s, 3), s->d_scal + 2);
           TRY(fetch_scalar2(s, s->d_scal + 2, &rr, &indefinite));  // ||r||^2 and the r.z < 0 flag
           if (!(rr > target)) break;                       // also leaves on NaN
           if (rr > 1e8 * bb || indefinite != 0.0) break;   // the preconditioner is not positive definite
+          if (it >= stall_check && stall_check > 0) {      // p-multigrid far beyond its usual 30-45 iterations
+            stalled = true;
+            break;
+          }
         }
       }
       // A Chebyshev polynomial is positive only up to the upper end of its interval: if the power iteration
       // underestimated lambda_max by more than the safety margin, CG breaks down (NaN or growth).  Widen and redo.
       const bool broke = (rr != rr) || rr > 1e8 * bb || (indefinite != 0.0 && rr > target);
-      if (!broke || deg <= 1 || attempt >= 3) break;
-      s->lam_safety *= 1.5;  // kept for the following solves: the estimate is systematically low on this mesh
-      if (s->verbose) std::printf("PCG breakdown: Chebyshev interval widened to %.3g x lambda_max estimate\n", s->lam_safety);
-      TRY(cheb_upload_coefficients(s));
-      if (precond_eff(s) == 2) TRY(pmg_coefficients(s));
+      if (stalled && !broke && (attempt >= 3 || pmg_coarse_degree_eff(s) >= kPmgMaxCoarseDeg)) {
+        stalled = false;  // nothing left to raise: keep iterating with what there is
+        stall_check = 0;
+        continue;
+      }
+      if ((!broke && !stalled) || deg <= 1 || attempt >= 3) break;
+      if (stalled && !broke) {
+        s->pmg.kc_boost *= 1.45;
+        if (s->verbose)
+          std::printf("p-multigrid: %d CG iterations without convergence, coarse polynomial degree raised to %d\n", it,
+                      pmg_coarse_degree_eff(s));
+        stalled = false;
+        stall_check = pmg_coarse_degree_eff(s) < kPmgMaxCoarseDeg ? kStallIters : 0;
+        TRY(pmg_coefficients(s));
+        if (graphs) TRY(cg_graphs_prepare(s, d_x, fused, deg, bits));
+      } else {
+        s->lam_safety *= 1.5;  // kept for the following solves: the estimate is systematically low on this mesh
+        if (s->verbose) std::printf("PCG breakdown: Chebyshev interval widened to %.3g x lambda_max estimate\n", s->lam_safety);
+        TRY(cheb_upload_coefficients(s));
+        if (precond_eff(s) == 2) TRY(pmg_coefficients(s));
+      }
       launch_pcg_init(s->stream, N, d_b, s->d_Dinv, w, d_x, s->d_r, s->d_zv, part(s, 0), part(s, 4));
       TRY(parts_sum(s, part(s, 0), part(s, 4)));
       HIP_TRY(hipMemsetAsync(s->d_scal + 3, 0, sizeof(double), s->stream));
@@ -2171,7 +2204,7 @@ extern "C" int tlfea_newton_pmg3_retrieve(tlfea_newton_t s, int* agg, double* rv
   return 0;
 }
 
-extern "C" int tlfea_newton_pmg_coarse_degree(tlfea_newton_t s) { return s && s->pmg.ok ? pmg_coarse_degree(s->pmg.Nc) : 0; }
+extern "C" int tlfea_newton_pmg_coarse_degree(tlfea_newton_t s) { return s && s->pmg.ok ? pmg_coarse_degree_eff(s) : 0; }
 extern "C" int tlfea_newton_get_precond(tlfea_newton_t s) {  // 1 Chebyshev polynomial, 2 p-multigrid (what a solve would use now)
   if (!s) return -1;
   return cheb_degree_eff(s) > 1 ? precond_eff(s) : 0;
@@ -2237,7 +2270,7 @@ extern "C" int tlfea_newton_time_kernels(tlfea_newton_t s, int reps, double* out
         auto& m = s->pmg;
         const size_t n = 3 * (size_t)N, nc = 3 * (size_t)m.Nc;
         float *f = s->d_f32, *g = m.d_f32c;
-        const int kc = pmg_coarse_degree(m.Nc), bits = cheb_bits_eff(s);
+        const int kc = pmg_coarse_degree_eff(s), bits = cheb_bits_eff(s);
         auto fine = [&](int a) {
           const int b = 1 - a;
           launch_cheb32(s->stream, N, d->nnz_coef, d->inc(), s->d_B8, s->d_B1, bits, f + 6 * n, s->d_sc, f + a * n,
@@ -2280,7 +2313,7 @@ extern "C" int tlfea_newton_time_kernels(tlfea_newton_t s, int reps, double* out
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, s->ev[6], s->ev[7]));
     out_ms4[k] = ms / reps;
-    if (k == 6) out_ms4[k] /= (double)(pmg_coarse_degree(s->pmg.Nc) + 2);  // per launch of the cycle pattern
+    if (k == 6) out_ms4[k] /= (double)(pmg_coarse_degree_eff(s) + 2);  // per launch of the cycle pattern
   }
   HIP_TRY(hipGetLastError());
   return 0;
