@@ -2078,7 +2078,7 @@ static int pcg(tlfea_newton_t s, const double* d_b, double* d_x, int* iters_out,
     HIP_TRY(hipMemsetAsync(s->d_scal + 3, 0, sizeof(double), s->stream));
     // p-multigrid converges in 30-45 iterations when its coarse polynomial covers the vertex-level spectrum; far more
     // means the size-based degree is too low for this mesh: raise it (kept for later solves) and start over
-    const int kStallIters = 80;
+    const int kStallIters = 56;
     bool stalled = false;
     int stall_check = (precond_eff(s) == 2 && s->pmg.ok && pmg_coarse_degree_eff(s) < kPmgMaxCoarseDeg) ? kStallIters : 0;
     for (int attempt = 0;; attempt++) {
