@@ -1,6 +1,7 @@
 """GPU parity tests: every stage of the T10 hot path through the C-ABI (libtlfea_hip.so) against the CPU
 oracle on the same inputs.  Bit-exact for connectivity / sparsity indices; fp64 tolerances written per test
 (north_star: nodal displacement within 1e-10 relative of the CPU reference)."""
+import importlib
 import os
 
 import numpy as np
@@ -502,5 +503,34 @@ def test_device_side_force_hook_between_steps():
         assert disp_err_ok(xg, np.stack([o.x, o.y, o.z], axis=1), X)
         assert relerr(v_dev.cpu().numpy(), o.v) < 1e-8
     assert np.array_equal(d.RetrieveExternalForceToCPU(), o.f_ext)
+    del s
+    d.Destroy()
+
+
+def test_pmg_coarse_degree_adapts_on_a_thin_cantilever():
+    """The coarse polynomial's degree is a size-based guess; a 2 x 0.13 x 0.13 cantilever (60 x 4 x 4 cells) has a far
+    worse conditioned vertex-level operator than a cube with as many nodes.  A solve that passes 56 iterations raises
+    the degree (kept for later solves) and starts over; the next solve is inside the usual range, same solution as
+    with the Chebyshev preconditioner."""
+    wl = importlib.import_module("total-lagrangian-fea_amd.workloads")
+    cells = (60, 4, 4)
+    saved = dict(wl.CONFIGS["C"])
+    try:
+        wl.CONFIGS["C"] = dict(saved, cells=cells, size=tuple(c / 30.0 for c in cells))
+        w = wl.build("C")
+    finally:
+        wl.CONFIGS["C"] = saved
+    d, s = wl.make_engine(tl, w)
+    s.AssembleHessian()   # reference configuration
+    b = np.random.default_rng(1).normal(size=3 * w["X"].shape[0])
+    s.SetLinSolveOpts(tl.LinSolveOpts(1e-12, 6000, 5, 0, 0.0, 0, 2))
+    deg0 = s.GetPmgInfo()[2]
+    x1, it1, rel1 = s.LinearSolve(b)
+    deg1 = s.GetPmgInfo()[2]
+    x2, it2, rel2 = s.LinearSolve(b)
+    assert deg1 > deg0 and it2 < 56 and rel1 < 1e-12 and rel2 < 1e-12, (deg0, deg1, it1, it2)
+    s.SetLinSolveOpts(tl.LinSolveOpts(1e-12, 6000, 5, 0, 0.0, 0, 1))
+    xc, itc, relc = s.LinearSolve(b)
+    assert relerr(x2, xc) < 1e-7 and relerr(x1, x2) < 1e-7
     del s
     d.Destroy()
