@@ -9,8 +9,12 @@ value = elements * steps / seconds (whole job, max over ranks).  The JSON line a
   roofline_all : the same for every hot kernel
   cpu_baseline : the CPU oracle (C restatement of the reference, OpenMP) on the same workload, rank 0, N=1 only.
 
-Launch:  python bench.py [--gpus N --steps K --warmup W --config B|C]
+Launch:  python bench.py [--gpus N --steps K --warmup W --config C|B]
          python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (one rank per GPU)
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself (a child
+`python -m torch.distributed.run`, spawned before this process imports torch or touches the GPU) and relays rank 0's line.
+Default workload = config C (972 000 T10 elements, the largest single-GPU T10 configuration of BASELINE.json); with N
+GPUs every rank owns one config-C slab of a bar N times as long (N = 8: config E).
 """
 import argparse
 import importlib
@@ -38,6 +42,9 @@ def alg_bytes(E, N, nnz_coef, S=10, Q=5, cheb_bits=64, cheb_vec_bits=64):
         "tangent_blocks": E * elem_in + N * 24 + E * npair * 72,
         # block buffer in, scatter map in, mass in, H (9 doubles per coefficient pair) out once
         "assemble_rows": E * npair * 72 + E * 4 * S * S + nnz_coef * 8 + nnz_coef * 72,
+        # fused tangent + assembly (T10, SVK): grad N + det J + per-point F in (each once: the re-reads by the owners of
+        # an element's other rows are L2 traffic), instance map (code + S packed words), mass in, H out once
+        "assemble_direct": E * (24 * S * Q + 8 * Q + 72 * Q) + E * S * (4 + 4 * S) + nnz_coef * 8 + nnz_coef * 72,
         # H values + node-level columns + z,p_old in, p_new,q out
         "spmv": nnz_coef * 72 + nnz_coef * 4 + N * 96,
         # Chebyshev step: matrix (9 entries per block at cheb_bits: H itself or its scaled fp32/fp16 copy) + columns +
@@ -51,7 +58,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=6)
-    ap.add_argument("--config", default="B")
+    ap.add_argument("--config", default="C",
+                    help="C (default): T10 bar, 972 000 elements per GPU; B: T10 cube, 10 368 elements; D/A: ANCF")
     ap.add_argument("--rel-tol", type=float, default=1e-12)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--max-pcg", type=int, default=50000, help="cap on PCG iterations (kernel experiments only)")
@@ -71,6 +79,20 @@ def main():
     ap.add_argument("--cheb-bits", type=int, default=0, choices=(0, 16, 32, 64),
                     help="matrix precision streamed by the Chebyshev steps (0 = auto = fp16 scaled copy)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # Self-launch: one fresh child process per GPU through torch.distributed.run.  Nothing in THIS process has
+        # imported torch or touched the GPU yet, and it never will: it only relays the children's output.
+        import socket
+        import subprocess
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+        env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))
+        raise SystemExit(subprocess.run(cmd, env=env).returncode)
 
     import torch
     import torch.distributed as dist
@@ -111,7 +133,9 @@ def main():
         part = par.slab_partition_structured(w["X"], lx * rank, lx * (rank + 1), rank, world)
         w["f_ext"] = (w["f_ext"].reshape(-1, 3) * part.node_weight[:, None]).reshape(-1)  # this rank's share
     d, s = wl.make_engine(tl, w)
-    s.SetLinSolveOpts(tl.LinSolveOpts(args.rel_tol, args.max_pcg, 25, args.cheb_deg, args.cheb_kappa, args.cheb_bits, args.precond))
+    # a capped iteration count (--max-pcg, kernel experiments) accepts iterates above rel_tol; the default fails loudly
+    s.SetLinSolveOpts(tl.LinSolveOpts(args.rel_tol, args.max_pcg, 25, args.cheb_deg, args.cheb_kappa, args.cheb_bits,
+                                      args.precond, 0, int(args.max_pcg != 50000)))
     if world > 1:
         native = args.native_rccl or bool(os.environ.get("TLFEA_BENCH_NATIVE_RCCL"))
         comm = par.rccl_communicator(dist, rank, world) if (native and backend == "nccl") else None
@@ -157,6 +181,7 @@ def main():
     pcg_its = run(args.steps, args.warmup)
     barrier()
     dt = time.perf_counter() - t0
+    lin_status = s.GetLinSolveStatus()
     if world > 1:
         t = torch.tensor([dt], device="cuda" if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -175,9 +200,17 @@ def main():
     s.SetProfiling(False)
     deg_eff, bits_eff, vec_bits = s.GetLinSolveInfo()
     ab = alg_bytes(E, N, nnz_coef, d.S, d.Q, bits_eff, vec_bits)
+    fused = s.GetAssemblyMode() == 2   # one fused tangent + assembly launch instead of tangent_blocks + assemble_rows
+    if fused:
+        ab["residual"] += E * 72 * d.Q   # the residual launch also writes the per-point F the fused assembly stages
     # mean launch duration: `reps` back-to-back launches per kernel between one hipEvent pair on the launch stream
     # (kernel time + same-stream boundary; agrees with rocprofv3 --kernel-trace, profiles/*kernel_stats.csv)
     kt = s.TimeKernels(reps=40 if E < 200000 else 10)
+    if fused:
+        kt["assemble_direct"] = kt.pop("assemble_rows")
+        st = dict(st, assemble_direct=st["assemble_rows"])
+        st.pop("assemble_rows")
+        st["tangent_blocks"] = (0.0, 0)
     roof_all = {}
     n_outer = st["spmv"][1] // max(1, deg_eff)       # stage counter tallies deg launches per outer iteration
     pmg = s.GetPmgInfo()                              # (coarse nodes, coarse blocks, coarse polynomial degree) | None
@@ -193,7 +226,8 @@ def main():
                   cheb_step_coarse=(0.0, n_outer * ncs), poly_step=(0.0, n_outer * (nf + ncs)))
     else:
         st = dict(st, spmv=(st["spmv"][0], n_outer), cheb_step=(0.0, n_outer * (deg_eff - 1)))
-    for k in ("residual", "tangent_blocks", "assemble_rows", "spmv", "cheb_step", "cheb_step_coarse", "poly_step"):
+    for k in ("residual", "tangent_blocks", "assemble_rows", "assemble_direct", "spmv", "cheb_step", "cheb_step_coarse",
+              "poly_step"):
         if k not in st:
             continue
         ms, n = st[k]
@@ -217,9 +251,10 @@ def main():
     dominant = max((k for k in roof_all if not (pmg and k in ("cheb_step", "cheb_step_coarse"))),
                    key=lambda k: roof_all[k]["total_ms"])
     roofline = dict(roof_all[dominant], kernel=dominant)
-    elem_ms = sum(st[k][0] for k in ("residual", "grad", "tangent_blocks", "assemble_rows")) / nprof
-    stage_share = {k: round(st[k][0] / nprof, 4) for k in ("residual", "grad", "tangent_blocks", "assemble_rows",
-                                                           "pcg", "update")}
+    elem_keys = ("residual", "grad", "assemble_direct") if fused else ("residual", "grad", "tangent_blocks", "assemble_rows")
+    elem_ms = sum(st[k][0] for k in elem_keys) / nprof
+    b_alg = 4 * d.S + 24 * d.S * d.Q + 8 * d.Q + 24 * d.S + 72.0 * nnz_coef / E + 24.0 * N / E
+    stage_share = {k: round(st[k][0] / nprof, 4) for k in elem_keys + ("pcg", "update")}
 
     out = {
         "metric": "T10-tet element-updates/sec per Newton step", "value": round(value, 1), "unit": "element-updates/s",
@@ -229,6 +264,7 @@ def main():
                                f"implicit Newton iteration incl. PCG solve (rel_tol {args.rel_tol:g})",
                    "elements_per_gpu": E, "nodes_per_gpu": N, "hessian_nnz": 9 * nnz_coef,
                    "pcg_outer_iters_per_step": round(float(np.mean(pcg_its)), 1),
+                   "last_solve_rel_residual": float(lin_status["rel_res"]), "last_solve_converged": lin_status["converged"],
                    "preconditioner": ("block-Jacobi (3x3)" if deg_eff <= 1 else
                                       (f"two-level p-multigrid V-cycle (T10 -> vertex mesh, {pmg[0]} coarse nodes, Galerkin "
                                        f"coarse operator, 2-term Chebyshev smoothers, degree-{pmg[2]} coarse polynomial), "
@@ -237,7 +273,12 @@ def main():
                                       f"with fp{vec_bits} work vectors; "
                                       "outer CG, residual and convergence test in fp64 on H")},
         "element_stage": {"ms_per_step": round(elem_ms, 4), "value": round(E / (elem_ms * 1e-3), 1),
-                          "note": "residual+gradient+tangent+assembly only (no linear solve), profiling pass"},
+                          # connectivity + grad N + det J + x gather + H written once + f_int
+                          "alg_bytes_per_element": round(b_alg, 1),
+                          "roofline_frac": round(E * b_alg / (elem_ms * 1e-3) / (HBM_PEAK_GBS * 1e9), 4),
+                          "kernels": list(elem_keys),
+                          "note": "residual+gradient+tangent+assembly only (no linear solve), profiling pass; "
+                                  "roofline_frac = E * alg_bytes_per_element / time / 8 TB/s"},
         "stage_ms_per_step": stage_share,
         "prewarm": {"seconds": args.prewarm_s, "newton_iterations": n_prewarm,
                     "note": "untimed device warm-up before the W warm-up steps; state reset afterwards"},
@@ -293,9 +334,22 @@ def load_pmc_traffic():
 
 def cpu_baseline(w, args):
     """The CPU oracle (C restatement of the reference, OpenMP atomics for the scatter, Jacobi-PCG twin of the
-    device solver) on a bounded sample: Newton iterations of the same workload on the host cores."""
+    device solver) on a BOUNDED sample of the workload: Newton iterations on the host cores for ~10-30 s.
+    Large workloads (config C: one iteration of all 972 000 elements takes ~1 min on 16 cores) are sampled by a
+    thinner x-slab of the same bar -- same cell size, cross-section, material, clamp and load -- of <= ~30 000 elements."""
+    from importlib import import_module
+
     from oracle import orc
 
+    wl = import_module("total-lagrangian-fea_amd.workloads")
+    sample = "the whole workload"
+    cfg = wl.CONFIGS[args.config]
+    if w["conn"].shape[0] > 40000 and "cells" in cfg:
+        nx, ny, nz = cfg["cells"]
+        nxs = max(2, min(nx, 30000 // (6 * ny * nz)))
+        w = wl.build(args.config, cells=(nxs, ny, nz))
+        sample = (f"x-slab {nxs}x{ny}x{nz} cells of the {nx}x{ny}x{nz} bar (same cell size, cross-section, material, "
+                  f"clamp at x=0, load on the slab's end face)")
     m = w["material"]
     mat = (orc.svk(m["E"], m["nu"], rho0=m["rho0"]) if m["kind"] == "svk"
            else orc.mooney_rivlin(m["mu10"], m["mu01"], m["kappa"], rho0=m["rho0"]))
@@ -305,7 +359,6 @@ def cpu_baseline(w, args):
         cores = os.cpu_count() or 1
     cores = max(1, min(cores, 16, int(os.environ.get("OMP_NUM_THREADS", "16"))))  # the GPU box's CPU share
     X, conn = w["X"], w["conn"]
-    # bounded sample: whole workload when small, else its first ~10k elements' worth of slab
     o = orc.T10Oracle(X, conn, mat, fixed=w["fixed"], f_ext=w["f_ext"])
     o.calc_dndu_pre()
     o.calc_mass()
@@ -336,8 +389,9 @@ def cpu_baseline(w, args):
             o.v[:] = 0.0
             o.x, o.y, o.z = (np.ascontiguousarray(w["x0"][:, i]) for i in range(3))
     return {"value": round(conn.shape[0] * n_it / el, 1), "unit": "element-updates/s", "cores": cores,
-            "kind": "port", "element_stage_value": round(conn.shape[0] * n_it / t_elem, 1), "sample": f"{n_it} Newton iteration(s) of the same workload ({conn.shape[0]} elements, "
-                                      f"PCG rel_tol {args.rel_tol:g}, {its} iterations last solve) in {el:.1f} s"}
+            "kind": "port", "element_stage_value": round(conn.shape[0] * n_it / t_elem, 1),
+            "sample": f"{n_it} Newton iteration(s) of {sample} ({conn.shape[0]} elements, PCG rel_tol {args.rel_tol:g}, "
+                      f"{its} iterations last solve) in {el:.1f} s"}
 
 
 if __name__ == "__main__":

@@ -56,6 +56,11 @@ typedef struct {
   int precond;       /* 0 (default) = auto, 1 = Chebyshev polynomial of block-Jacobi, 2 = two-level p-multigrid (T10 on one
                         GPU: quadratic tets -> their vertex mesh, Galerkin coarse operator, polynomial smoothers and
                         coarse solve; auto picks it wherever it exists) */
+  int method;        /* 0 (default) = preconditioned CG; 1 = sparse direct (tlfea_newton_set_direct_solver, where built) */
+  int on_unconverged;/* a CG solve that ends above rel_tol (max_iter reached, or breakdown after the interval widenings):
+                        0 (default) = the call fails, nothing is applied to v and x (the reference aborts when cuDSS
+                        fails, SyncedNewton.cu:995-1029); 1 = accept the iterate (experiments with a capped iteration
+                        count) -- tlfea_newton_get_linsolve_status reports it */
 } tlfea_linsolve_opts;
 
 const char *tlfea_last_error(void);
@@ -176,6 +181,10 @@ int tlfea_newton_set_linsolve_opts(tlfea_newton_t s, const tlfea_linsolve_opts *
 int tlfea_newton_get_linsolve_info(tlfea_newton_t s, int *cheb_degree, int *cheb_bits, int *cheb_vector_bits);
 /* preconditioner a solve would use now: 0 block-Jacobi, 1 Chebyshev polynomial, 2 p-multigrid */
 int tlfea_newton_get_precond(tlfea_newton_t s);
+/* how compute_hessian_assemble_csr (FEAT10DataFunc.cuh:513-791) + the CSR scatter (SyncedNewton.cu:214-341) run now:
+ * 1 = tangent blocks into an element-major buffer + row-owner gather (two launches; Mooney-Rivlin, ANCF kinds),
+ * 2 = fused row-owner tangent + assembly (one launch, no block buffer; T10 with St.Venant-Kirchhoff) */
+int tlfea_newton_get_assembly_mode(tlfea_newton_t s);
 /* degree of the coarse-level polynomial of the p-multigrid cycle (grows with the coarse mesh); 0 without p-multigrid */
 /* third level of the cycle (rigid-body-mode aggregates of the vertex level; opt-in, TLFEA_PMG_LEVELS=3): number of
  * aggregates (0: two levels), 3x3 blocks of H3 (2 nodes per aggregate: translation, rotation), polynomial degree there;
@@ -199,7 +208,8 @@ int tlfea_newton_assemble_hessian(tlfea_newton_t s);
 /* Solve H x = b for host vectors (b,x length 3N) with the current H; iterations returned. */
 int tlfea_newton_linear_solve(tlfea_newton_t s, const double *b, double *x, int *iters, double *rel_res);
 /* mean duration (ms) of the hot kernels over `reps` back-to-back launches each (hipEvent pair per kernel on the
- * launch stream): [0] residual, [1] tangent blocks, [2] row assembly, [3] CG SpMV (fp64), [4] fine-level polynomial /
+ * launch stream): [0] residual, [1] tangent blocks (0 in assembly mode 2), [2] row assembly (mode 2: the fused
+ * tangent + assembly launch), [3] CG SpMV (fp64), [4] fine-level polynomial /
  * smoother step, [5] coarse-level polynomial step of the p-multigrid cycle, [6] the same kernel averaged over the
  * launch pattern of one V-cycle (3 fine + kc-1 coarse launches; [5], [6] are 0 without p-multigrid).  State of the
  * Newton iteration is unchanged (only linear-solver work vectors are touched). */
@@ -217,6 +227,12 @@ int tlfea_newton_retrieve_lambda(tlfea_newton_t s, double *lam /*n_constraints*/
 /* stats of the last tlfea_newton_solve(): [0] outer iterations, [1] Newton solves, [2] last ||g||,
  * [3] last ||c||, [4] total PCG iterations, [5] device ms of the step (hipEvent) */
 int tlfea_newton_get_stats(tlfea_newton_t s, double *stats6);
+/* number of multipliers the solver holds now (follows the data object's count at the start of every solve: an
+ * UpdateNodalFixed with another size restarts them from zero) */
+int tlfea_newton_n_constraints(tlfea_newton_t s);
+/* linear solves since the last tlfea_newton_solve() / tlfea_newton_iteration() began: out4 = [0] ||r||/||b|| of the last
+ * one, [1] 1 if it met rel_tol, [2] the worst ||r||/||b|| of them, [3] 1 if all of them met rel_tol */
+int tlfea_newton_get_linsolve_status(tlfea_newton_t s, double *out4);
 /* per-stage device time (ms, hipEvent pairs on the launch stream; profiling mode) and launch counts since
  * the last reset: [0] residual kernel, [1] gather+grad+norm, [2] tangent-block kernel, [3] row-assembly
  * kernel, [4] whole PCG solve, [5] update kernel, [6] SpMV kernel alone, [7] unused */

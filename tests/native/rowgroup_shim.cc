@@ -1,0 +1,22 @@
+// Test shim: exposes the host set-up of the fused assembly kernel (csrc/rowgroup_host.h, integer work only) to ctypes,
+// so that the CPU suite can check its invariants without a GPU.  Built by tests/test_rowgroups.py with g++.
+#include "../../total-lagrangian-fea_amd/csrc/rowgroup_host.h"
+
+static tlfea::RowGroupsHost g_rg;
+
+extern "C" int rg_build(int N, int E, int S, const int* conn, const int* off, const int* cols, const int* n2e_off,
+                        const int* n2e, const double* x, const double* y, const double* z, int* sizes) {
+  if (!tlfea::build_row_groups(N, E, S, conn, off, cols, n2e_off, n2e, x, y, z, g_rg)) return 1;
+  sizes[0] = g_rg.G();
+  sizes[1] = (int)g_rg.gi_code.size();
+  sizes[2] = g_rg.acc_max;
+  return 0;
+}
+extern "C" void rg_fetch(int* g_inst_off, int* g_row_off, int* gr_row, int* gr_acc, int* gi_code, int* gi_pack) {
+  std::copy(g_rg.g_inst_off.begin(), g_rg.g_inst_off.end(), g_inst_off);
+  std::copy(g_rg.g_row_off.begin(), g_rg.g_row_off.end(), g_row_off);
+  std::copy(g_rg.gr_row.begin(), g_rg.gr_row.end(), gr_row);
+  std::copy(g_rg.gr_acc.begin(), g_rg.gr_acc.end(), gr_acc);
+  std::copy(g_rg.gi_code.begin(), g_rg.gi_code.end(), gi_code);
+  std::copy(g_rg.gi_pack.begin(), g_rg.gi_pack.end(), gi_pack);
+}

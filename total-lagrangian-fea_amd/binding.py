@@ -44,7 +44,8 @@ class VbdParamsC(C.Structure):  # tlfea_vbd_params == SyncedVBDParams (SyncedVBD
 
 class LinSolveOptsC(C.Structure):
     _fields_ = [("rel_tol", C.c_double), ("max_iter", C.c_int), ("check_every", C.c_int), ("cheb_degree", C.c_int),
-                ("cheb_kappa", C.c_double), ("cheb_bits", C.c_int), ("precond", C.c_int)]
+                ("cheb_kappa", C.c_double), ("cheb_bits", C.c_int), ("precond", C.c_int), ("method", C.c_int),
+                ("on_unconverged", C.c_int)]
 
 
 def exported_symbols():

@@ -248,7 +248,7 @@ template <int S, int Q, bool STORE>
 __global__ __launch_bounds__(128) void residual_kernel(ElemView m, Material mat, const double* __restrict__ v,
                                                       double* __restrict__ fbuf, double* __restrict__ Fo,
                                                       double* __restrict__ Po, double* __restrict__ Fdo,
-                                                      double* __restrict__ Pvo) {
+                                                      double* __restrict__ Pvo, double* __restrict__ Fq) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= m.E) return;
   const bool damp = (v != nullptr) && (mat.eta != 0.0 || mat.lamd != 0.0);  // FEAT10DataFunc.cuh:137
@@ -279,6 +279,13 @@ __global__ __launch_bounds__(128) void residual_kernel(ElemView m, Material mat,
       for (int i = 0; i < 3; i++)
 #pragma unroll
         for (int j = 0; j < 3; j++) F[i][j] += xn[a][i] * hq[a][j];
+    if (Fq) {  // row-major F per (point, element): what the fused assembly stages instead of rebuilding F
+      double* fo = Fq + ((size_t)q * m.E + e) * 9;
+#pragma unroll
+      for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) fo[i * 3 + j] = F[i][j];
+    }
     double P[3][3];
     elastic_P(F, mat, P);
     double Fd[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, Pv[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
@@ -352,20 +359,20 @@ __global__ __launch_bounds__(128) void residual_kernel(ElemView m, Material mat,
 
 template <int S, int Q>
 static void launch_residual_t(hipStream_t s, const ElemView& m, const Material& mat, const double* v, double* fbuf,
-                              double* F, double* P, double* Fdot, double* Pvis) {
+                              double* F, double* P, double* Fdot, double* Pvis, double* Fq) {
   const dim3 grid((m.E + 127) / 128), block(128);
   if (F)
-    hipLaunchKernelGGL((residual_kernel<S, Q, true>), grid, block, 0, s, m, mat, v, fbuf, F, P, Fdot, Pvis);
+    hipLaunchKernelGGL((residual_kernel<S, Q, true>), grid, block, 0, s, m, mat, v, fbuf, F, P, Fdot, Pvis, Fq);
   else
     hipLaunchKernelGGL((residual_kernel<S, Q, false>), grid, block, 0, s, m, mat, v, fbuf, nullptr, nullptr, nullptr,
-                       nullptr);
+                       nullptr, Fq);
 }
 
 void launch_residual(hipStream_t s, const ElemView& m, const Material& mat, const double* v, double* fbuf, double* F,
-                     double* P, double* Fdot, double* Pvis) {
-  if (m.S == 10) launch_residual_t<10, 5>(s, m, mat, v, fbuf, F, P, Fdot, Pvis);
-  else if (m.S == 8) launch_residual_t<8, 12>(s, m, mat, v, fbuf, F, P, Fdot, Pvis);
-  else launch_residual_t<16, 48>(s, m, mat, v, fbuf, F, P, Fdot, Pvis);
+                     double* P, double* Fdot, double* Pvis, double* Fq) {
+  if (m.S == 10) launch_residual_t<10, 5>(s, m, mat, v, fbuf, F, P, Fdot, Pvis, Fq);
+  else if (m.S == 8) launch_residual_t<8, 12>(s, m, mat, v, fbuf, F, P, Fdot, Pvis, Fq);
+  else launch_residual_t<16, 48>(s, m, mat, v, fbuf, F, P, Fdot, Pvis, Fq);
 }
 
 // f_int[3i+d] = sum over the node's elements of their force rows (fixed order: ascending element id)
@@ -930,6 +937,195 @@ void launch_assemble_rows(hipStream_t s, int N, int S, int maxdeg, const Inciden
   else
     hipLaunchKernelGGL((assemble_rows_kernel<16>), dim3(N), dim3(64), lds, s, N, inc, Kbuf, mval, inv_h, fixed_slot, nw,
                        penalty, Hval);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fused tangent + assembly, T10 <10,5>, St.Venant-Kirchhoff (+ Kelvin-Voigt): compute_hessian_assemble_csr
+// (FEAT10DataFunc.cuh:513-791) + assemble_sparse_hessian_{mass,tangent,constraints} (SyncedNewton.cu:214-341) in ONE
+// launch with no element-block buffer in HBM.  Owner computes: a wavefront owns a GROUP of node rows of H (RowGroups;
+// rows in Morton order, groups dealt to the XCDs in contiguous ranges so that the grad-N re-reads of neighbouring
+// rows hit that XCD's L2) and recomputes, for every (row i, incident element e) INSTANCE, the ten 3x3 blocks
+// K_e(i, j), j = 0..9 -- 100 blocks per element over all its rows instead of the 55 of the symmetric element-wise
+// form, in exchange for 7.9 kB per element of block-buffer traffic and a second kernel.
+//   pass   = 6 instances x 10 column nodes = 60 lanes, lane (k, j) sums its block over the 5 points in 9 registers
+//   staged = per (instance, point) one 26-double record {h_i, F h_i, F, B1 F F^T, A1, B1, C0, C1} in LDS (F comes from
+//            the residual launch that precedes every assembly: Fq); h_j goes from memory straight to registers
+//   sum    = ds_add_f64 into the group's row accumulators in LDS (H layout), rows stream out once at the end
+// The LDS adds of one wave execute in program order, lanes of one instruction in the hardware's fixed conflict
+// order, so the sum order is fixed: bitwise reproducible like the two-kernel path (tests check it).
+// ------------------------------------------------------------------------------------------------
+namespace {
+constexpr int kAdInst = 6;                            // instances per pass
+constexpr int kAdRec = 26;                            // doubles per staged record
+constexpr int kAdRecTotal = kAdInst * kNQ * kAdRec;   // 780 doubles = 6.1 KiB
+}  // namespace
+
+__global__ __launch_bounds__(64) void assemble_direct_kernel(ElemView m, Material mat, double h, RowGroups rg,
+                                                            Incidence inc, const double* __restrict__ Fq,
+                                                            const double* __restrict__ mval, double inv_h,
+                                                            const int* __restrict__ fixed_slot,
+                                                            const double* __restrict__ nw, double penalty,
+                                                            double* __restrict__ Hval) {
+  extern __shared__ __attribute__((aligned(16))) double lds_ad[];
+  double* rec = lds_ad;                // [kAdInst][kNQ][kAdRec]
+  double* acc = lds_ad + kAdRecTotal;  // the group's rows, each in H's layout [d][3 deg]
+  // blocks b, b + 8, ... share an XCD (round-robin dispatch): XCD x works through groups [x per, (x+1) per)
+  const int per = gridDim.x >> 3;
+  const int g = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  if (g >= rg.G) return;
+  const int lane = threadIdx.x;
+  const int row0 = rg.g_row_off[g], row1 = rg.g_row_off[g + 1];
+  const int inst0 = rg.g_inst_off[g], inst1 = rg.g_inst_off[g + 1];
+  {
+    const int il = rg.gr_row[row1 - 1];
+    const int acc_n = rg.gr_acc[row1 - 1] + 9 * (inc.off[il + 1] - inc.off[il]);
+    for (int t = lane; t < acc_n; t += 64) acc[t] = 0.0;
+  }
+  __syncthreads();
+  for (int r = row0; r < row1; r++) {  // M/h on the xyz-diagonal of every block (SyncedNewton.cu:214-259)
+    const int i = rg.gr_row[r], a0 = rg.gr_acc[r], off0 = inc.off[i], deg = inc.off[i + 1] - off0, row = 3 * deg;
+    for (int k = lane; k < deg; k += 64) {
+      const double mh = mval[off0 + k] * inv_h;
+      acc[a0 + 3 * k] = mh;
+      acc[a0 + row + 3 * k + 1] = mh;
+      acc[a0 + 2 * row + 3 * k + 2] = mh;
+    }
+  }
+  __syncthreads();
+  if (fixed_slot && lane < 3)  // h^2 rho J^T J: one 1.0 per pinned DOF (SyncedNewton.cu:292-341)
+    for (int r = row0; r < row1; r++) {
+      const int i = rg.gr_row[r];
+      if (fixed_slot[i] >= 0) {
+        const int deg = inc.off[i + 1] - inc.off[i];
+        acc[rg.gr_acc[r] + lane * 3 * deg + 3 * inc.diagpos[i] + lane] += (nw ? nw[i] : 1.0) * penalty;
+      }
+    }
+
+  const int k = lane / kNN, j = lane - kNN * k;  // lanes 60..63: k == 6, idle
+  const int E = m.E;
+#pragma unroll 1
+  for (int p0 = inst0; p0 < inst1; p0 += kAdInst) {
+    __syncthreads();  // the previous pass has consumed its records (and orders the accumulator set-up)
+    {                 // ---- stage the 30 (instance, point) records: lanes 0..29 the kinematic half, 32..61 the material half
+      const int t = lane & 31;
+      if (t < kAdInst * kNQ) {
+        const int ks = t / kNQ, q = t - kNQ * ks;
+        const int code = rg.gi_code[min(p0 + ks, inst1 - 1)];
+        const int e = code / kNN, il = code - kNN * e;
+        const double* Fp = Fq + ((size_t)q * E + e) * 9;
+        double F[9];
+#pragma unroll
+        for (int c = 0; c < 9; c++) F[c] = Fp[c];
+        double* R = rec + (ks * kNQ + q) * kAdRec;
+        if (lane < 32) {
+          const double* gN = m.gradN + ((size_t)e * kNQ + q) * (3 * kNN);
+          const double h0 = gN[il], h1 = gN[kNN + il], h2 = gN[2 * kNN + il];
+          double2* R2 = reinterpret_cast<double2*>(R);
+          R2[0] = make_double2(h0, h1);
+          R2[1] = make_double2(h2, F[0] * h0 + F[1] * h1 + F[2] * h2);
+          R2[2] = make_double2(F[3] * h0 + F[4] * h1 + F[5] * h2, F[6] * h0 + F[7] * h1 + F[8] * h2);
+          R2[3] = make_double2(F[0], F[1]);
+          R2[4] = make_double2(F[2], F[3]);
+          R2[5] = make_double2(F[4], F[5]);
+          R2[6] = make_double2(F[6], F[7]);
+          R2[7] = make_double2(F[8], 0.0);
+        } else {
+          const double T00 = F[0] * F[0] + F[1] * F[1] + F[2] * F[2], T01 = F[0] * F[3] + F[1] * F[4] + F[2] * F[5],
+                       T02 = F[0] * F[6] + F[1] * F[7] + F[2] * F[8], T11 = F[3] * F[3] + F[4] * F[4] + F[5] * F[5],
+                       T12 = F[3] * F[6] + F[4] * F[7] + F[5] * F[8], T22 = F[6] * F[6] + F[7] * F[7] + F[8] * F[8];
+          const double trE = 0.5 * (T00 + T11 + T22 - 3.0);
+          const double dV = m.detJ[(size_t)e * kNQ + q] * m.qw[q];
+          // h*K (SVK.cuh:35-55) + C_vis (FEAT10DataFunc.cuh:695-762) share their rank-1 structure:
+          const double A1 = dV * (h * mat.lambda + mat.lamd);      // * Fh_i (x) Fh_j
+          const double B1 = dV * (h * mat.mu + mat.eta);           // * Fh_j (x) Fh_i  and  * (h_i.h_j) FF^T
+          const double C0 = dV * h * (mat.lambda * trE - mat.mu);  // * (h_i.h_j) I
+          const double C1 = dV * h * mat.mu;                       // * (Fh_i.Fh_j) I
+          double2* R2 = reinterpret_cast<double2*>(R + 16);
+          R2[0] = make_double2(B1 * T00, B1 * T01);
+          R2[1] = make_double2(B1 * T02, B1 * T11);
+          R2[2] = make_double2(B1 * T12, B1 * T22);
+          R2[3] = make_double2(A1, B1);
+          R2[4] = make_double2(C0, C1);
+        }
+      }
+    }
+    // ---- this lane's item: block (instance k, column node j)
+    const bool act = (k < kAdInst) && (p0 + k < inst1);
+    const int ii = act ? p0 + k : inst1 - 1;
+    const int code = rg.gi_code[ii];
+    const int e = code / kNN;
+    const int pk = rg.gi_pack[(size_t)ii * kNN + j];
+    const double* gN = m.gradN + (size_t)e * (kNQ * 3 * kNN) + j;
+    double hj[kNQ][3];
+#pragma unroll
+    for (int q = 0; q < kNQ; q++)
+#pragma unroll
+      for (int d = 0; d < 3; d++) hj[q][d] = gN[q * 3 * kNN + d * kNN];
+    __syncthreads();
+    double a00 = 0, a01 = 0, a02 = 0, a10 = 0, a11 = 0, a12 = 0, a20 = 0, a21 = 0, a22 = 0, cds = 0;
+    const double2* Rk = reinterpret_cast<const double2*>(rec + (size_t)min(k, kAdInst - 1) * kNQ * kAdRec);
+#pragma unroll
+    for (int q = 0; q < kNQ; q++) {
+      const double2* R2 = Rk + q * (kAdRec / 2);
+      const double2 r0 = R2[0], r1 = R2[1], r2 = R2[2], r3 = R2[3], r4 = R2[4], r5 = R2[5], r6 = R2[6], r7 = R2[7],
+                    r8 = R2[8], r9 = R2[9], r10 = R2[10], r11 = R2[11], r12 = R2[12];
+      const double hj0 = hj[q][0], hj1 = hj[q][1], hj2 = hj[q][2];
+      const double fi0 = r1.y, fi1 = r2.x, fi2 = r2.y;
+      const double fj0 = r3.x * hj0 + r3.y * hj1 + r4.x * hj2;
+      const double fj1 = r4.y * hj0 + r5.x * hj1 + r5.y * hj2;
+      const double fj2 = r6.x * hj0 + r6.y * hj1 + r7.x * hj2;
+      const double sv = r0.x * hj0 + r0.y * hj1 + r1.x * hj2;  // h_i . h_j
+      const double tv = fi0 * fj0 + fi1 * fj1 + fi2 * fj2;     // F h_i . F h_j
+      const double A1 = r11.x, B1 = r11.y;
+      cds += r12.x * sv + r12.y * tv;
+      const double u0 = A1 * fi0, u1 = A1 * fi1, u2 = A1 * fi2;
+      const double w0 = B1 * fj0, w1 = B1 * fj1, w2 = B1 * fj2;
+      a00 += u0 * fj0 + w0 * fi0 + sv * r8.x;
+      a01 += u0 * fj1 + w0 * fi1 + sv * r8.y;
+      a02 += u0 * fj2 + w0 * fi2 + sv * r9.x;
+      a10 += u1 * fj0 + w1 * fi0 + sv * r8.y;
+      a11 += u1 * fj1 + w1 * fi1 + sv * r9.y;
+      a12 += u1 * fj2 + w1 * fi2 + sv * r10.x;
+      a20 += u2 * fj0 + w2 * fi0 + sv * r9.x;
+      a21 += u2 * fj1 + w2 * fi1 + sv * r10.x;
+      a22 += u2 * fj2 + w2 * fi2 + sv * r10.y;
+    }
+    if (act) {
+      double* ap = acc + (pk & 0xffff);
+      const int st = pk >> 16;
+#define TLFEA_LDS_ADD(p, v) (void)__hip_atomic_fetch_add((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+      TLFEA_LDS_ADD(ap + 0, a00 + cds);
+      TLFEA_LDS_ADD(ap + 1, a01);
+      TLFEA_LDS_ADD(ap + 2, a02);
+      TLFEA_LDS_ADD(ap + st + 0, a10);
+      TLFEA_LDS_ADD(ap + st + 1, a11 + cds);
+      TLFEA_LDS_ADD(ap + st + 2, a12);
+      TLFEA_LDS_ADD(ap + 2 * st + 0, a20);
+      TLFEA_LDS_ADD(ap + 2 * st + 1, a21);
+      TLFEA_LDS_ADD(ap + 2 * st + 2, a22 + cds);
+#undef TLFEA_LDS_ADD
+    }
+  }
+  __syncthreads();
+  for (int r = row0; r < row1; r++) {  // every row streams out once (no memset of H, no atomics on HBM)
+    const int i = rg.gr_row[r], a0 = rg.gr_acc[r], off0 = inc.off[i], n9 = 9 * (inc.off[i + 1] - off0);
+    double* out = Hval + (size_t)9 * off0;
+    for (int t = lane; t < n9; t += 64) out[t] = acc[a0 + t];
+  }
+}
+
+void launch_assemble_direct(hipStream_t s, const ElemView& m, const Material& mat, double h, const RowGroups& rg,
+                            const Incidence& inc, const double* Fq, const double* mval, const int* fixed_slot,
+                            const double* nw, double penalty, double* Hval) {
+  const size_t lds = (size_t)(kAdRecTotal + rg.acc_max) * sizeof(double);
+  static size_t lds_attr = 0;
+  if (lds > 64 * 1024 && lds > lds_attr) {
+    (void)hipFuncSetAttribute((const void*)assemble_direct_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    lds_attr = lds;
+  }
+  const int nb = ((rg.G + 7) / 8) * 8;
+  hipLaunchKernelGGL(assemble_direct_kernel, dim3(nb), dim3(64), lds, s, m, mat, h, rg, inc, Fq, mval, 1.0 / h,
+                     fixed_slot, nw, penalty, Hval);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -1,0 +1,122 @@
+// rowgroup_host.h -- host set-up of the fused tangent + assembly kernel (assemble_direct_kernel, elem_kernels.hip):
+// which node rows of H one wavefront owns, in which order, and where every (row, element, column node) block lands
+// in the wavefront's LDS accumulator.  Integer work only, once per mesh.
+//
+//   * rows are ordered along a Morton (Z-order) curve of the reference coordinates: consecutive groups are spatial
+//     neighbours, so the elements they re-read (every element is read by the owners of its S rows) are still in the
+//     XCD's L2 -- the kernel deals contiguous group ranges to the XCDs;
+//   * a group holds rows until their (row, element) instances exceed kInstBudget or their accumulators kAccBudget
+//     doubles; a row with many instances (a corner node of a tet mesh: ~24 elements) forms a group of its own;
+//   * per instance and column node j the packed word (accumulator offset of block column pos_j) | (3 deg << 16),
+//     16 bits each -- a mesh that does not fit (deg > 10 922 or an accumulator beyond 64 Ki doubles) reports failure and
+//     the solver keeps the two-kernel path.
+#pragma once
+#include <algorithm>
+#include <cstdint>
+#include <vector>
+
+namespace tlfea {
+
+struct RowGroupsHost {
+  std::vector<int> g_inst_off, g_row_off, gr_row, gr_acc, gi_code, gi_pack;
+  int acc_max = 0;
+  int G() const { return (int)g_inst_off.size() - 1; }
+};
+
+inline uint64_t morton_spread21(uint64_t v) {  // 21 bits -> every third bit
+  v &= 0x1fffffULL;
+  v = (v | (v << 32)) & 0x1f00000000ffffULL;
+  v = (v | (v << 16)) & 0x1f0000ff0000ffULL;
+  v = (v | (v << 8)) & 0x100f00f00f00f00fULL;
+  v = (v | (v << 4)) & 0x10c30c30c30c30c3ULL;
+  v = (v | (v << 2)) & 0x1249249249249249ULL;
+  return v;
+}
+
+// conn: column-major E x S (coefficient ids), off/cols: node adjacency (sorted columns), n2e_off/n2e: incidence
+// (e*S + local, ascending e per node), x/y/z: reference coordinates of the N rows.
+inline bool build_row_groups(int N, int E, int S, const int* conn, const int* off, const int* cols, const int* n2e_off,
+                             const int* n2e, const double* x, const double* y, const double* z, RowGroupsHost& out) {
+  constexpr int kInstBudget = 24, kAccBudget = 1024, kBigRow = 13;
+  if (N <= 0 || E <= 0) return false;
+  double lo[3] = {x[0], y[0], z[0]}, hi[3] = {x[0], y[0], z[0]};
+  for (int i = 1; i < N; i++) {
+    lo[0] = std::min(lo[0], x[i]); hi[0] = std::max(hi[0], x[i]);
+    lo[1] = std::min(lo[1], y[i]); hi[1] = std::max(hi[1], y[i]);
+    lo[2] = std::min(lo[2], z[i]); hi[2] = std::max(hi[2], z[i]);
+  }
+  // one scale for the three axes: cells of the curve stay cubes on an elongated body
+  const double ext = std::max({hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2], 1e-300});
+  const double sc = 2097151.0 / ext;
+  std::vector<std::pair<uint64_t, int>> key((size_t)N);
+#pragma omp parallel for schedule(static)
+  for (int i = 0; i < N; i++) {
+    const uint64_t a = (uint64_t)((x[i] - lo[0]) * sc), b = (uint64_t)((y[i] - lo[1]) * sc),
+                   c = (uint64_t)((z[i] - lo[2]) * sc);
+    key[i] = {morton_spread21(a) | (morton_spread21(b) << 1) | (morton_spread21(c) << 2), i};
+  }
+  std::sort(key.begin(), key.end());
+
+  out = RowGroupsHost();
+  out.gr_row.reserve((size_t)N);
+  out.gr_acc.reserve((size_t)N);
+  out.g_row_off.push_back(0);
+  out.g_inst_off.push_back(0);
+  std::vector<int> open_rows;  // the open group of small rows
+  int open_inst = 0, open_acc = 0, n_inst = 0;
+  auto emit = [&](const int* rows, int n) {
+    int a = 0;
+    for (int r = 0; r < n; r++) {
+      const int i = rows[r];
+      out.gr_row.push_back(i);
+      out.gr_acc.push_back(a);
+      a += 9 * (off[i + 1] - off[i]);
+      n_inst += n2e_off[i + 1] - n2e_off[i];
+    }
+    out.acc_max = std::max(out.acc_max, a);
+    out.g_row_off.push_back((int)out.gr_row.size());
+    out.g_inst_off.push_back(n_inst);
+  };
+  for (int t = 0; t < N; t++) {
+    const int i = key[t].second;
+    const int ni = n2e_off[i + 1] - n2e_off[i], ai = 9 * (off[i + 1] - off[i]);
+    if (ai >= 65536 || 3 * (off[i + 1] - off[i]) >= 32768) return false;
+    if (ni >= kBigRow || ai > kAccBudget / 2) {
+      emit(&i, 1);
+      continue;
+    }
+    if (!open_rows.empty() && (open_inst + ni > kInstBudget || open_acc + ai > kAccBudget)) {
+      emit(open_rows.data(), (int)open_rows.size());
+      open_rows.clear();
+      open_inst = open_acc = 0;
+    }
+    open_rows.push_back(i);
+    open_inst += ni;
+    open_acc += ai;
+  }
+  if (!open_rows.empty()) emit(open_rows.data(), (int)open_rows.size());
+  if (out.acc_max >= 65536) return false;
+
+  const int G = out.G();
+  out.gi_code.resize((size_t)n_inst);
+  out.gi_pack.resize((size_t)n_inst * S);
+#pragma omp parallel for schedule(dynamic, 256)
+  for (int g = 0; g < G; g++) {
+    size_t w = (size_t)out.g_inst_off[g];
+    for (int r = out.g_row_off[g]; r < out.g_row_off[g + 1]; r++) {
+      const int i = out.gr_row[r], a0 = out.gr_acc[r], deg = off[i + 1] - off[i];
+      const int* c = cols + off[i];
+      for (int k = n2e_off[i]; k < n2e_off[i + 1]; k++, w++) {
+        const int code = n2e[k], e = code / S;
+        out.gi_code[w] = code;
+        for (int j = 0; j < S; j++) {
+          const int pos = (int)(std::lower_bound(c, c + deg, conn[(size_t)j * E + e]) - c);
+          out.gi_pack[w * S + j] = (a0 + 3 * pos) | ((3 * deg) << 16);
+        }
+      }
+    }
+  }
+  return true;
+}
+
+}  // namespace tlfea

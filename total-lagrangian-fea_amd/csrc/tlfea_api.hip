@@ -17,6 +17,7 @@
 #include "ancf_host.h"
 #include "tlfea_internal.h"
 #include "pmg_host.h"
+#include "rowgroup_host.h"
 #include "vbd_host.h"
 
 using namespace tlfea;
@@ -90,10 +91,14 @@ struct tlfea_t10_s {  // any element type; the name is kept for the ABI's first 
   int nnz_mass = 0;
   // sparsity (host copies are kept: the solver and the retrieve calls need them)
   std::vector<int> h_conn, h_off, h_cols, h_n2e_off, h_n2e;
+  std::vector<double> h_X0;  // coordinates handed to Setup (x | y | z): the Morton order of the fused assembly's row groups
   int *d_off = nullptr, *d_cols = nullptr, *d_n2e_off = nullptr, *d_n2e = nullptr, *d_n2e_pos = nullptr,
       *d_diagpos = nullptr;
   double* d_mval = nullptr;
   int nnz_coef = 0, maxdeg = 0;
+  // bumped by every setter that changes what a captured launch has baked in (material scalars travel by value, the
+  // fixed-node buffers are re-allocated by UpdateNodalFixed): cached hipGraphs carry the value they were captured at
+  long gen = 0;
   bool is_setup = false, is_constraints_setup = false, is_csr_setup = false, is_j_csr_setup = false,
        is_cj_csr_setup = false, have_dndu = false;
 
@@ -196,6 +201,10 @@ extern "C" int tlfea_t10_setup(tlfea_t10_t h, const double* qx, const double* qy
   HIP_TRY(hipMemcpy(h->d_qz, qz, kNQ * sizeof(double), hipMemcpyHostToDevice));
   for (int q = 0; q < kNQ; q++) h->h_qw[q] = qw[q];
   h->h_conn.assign(conn, conn + E * kNN);
+  h->h_X0.resize(3 * N);
+  std::copy(x, x + N, h->h_X0.begin());
+  std::copy(y, y + N, h->h_X0.begin() + N);
+  std::copy(z, z + N, h->h_X0.begin() + 2 * N);
   HIP_TRY(hipMemset(h->d_gradN, 0, E * kNQ * 30 * sizeof(double)));
   HIP_TRY(hipMemset(h->d_gradN_t, 0, (size_t)h->Epad * kNQ * 30 * sizeof(double)));
   HIP_TRY(hipMemset(h->d_detJ, 0, E * kNQ * sizeof(double)));
@@ -211,17 +220,20 @@ extern "C" int tlfea_t10_setup(tlfea_t10_t h, const double* qx, const double* qy
 
 extern "C" int tlfea_t10_set_density(tlfea_t10_t h, double rho0) {
   NEED_SETUP(h, "setting density.");
+  h->gen++;
   h->mat.rho0 = rho0;
   return 0;
 }
 extern "C" int tlfea_t10_set_damping(tlfea_t10_t h, double eta, double lamd) {
   NEED_SETUP(h, "setting damping.");
+  h->gen++;
   h->mat.eta = eta;
   h->mat.lamd = lamd;
   return 0;
 }
 extern "C" int tlfea_t10_set_svk_select(tlfea_t10_t h) {
   NEED_SETUP(h, "setting material.");
+  h->gen++;
   h->mat.model = kSVK;
   h->mat.mu10 = h->mat.mu01 = h->mat.kappa = 0.0;
   return 0;
@@ -236,6 +248,7 @@ extern "C" int tlfea_t10_set_svk(tlfea_t10_t h, double E, double nu) {
 }
 extern "C" int tlfea_t10_set_mooney_rivlin(tlfea_t10_t h, double mu10, double mu01, double kappa) {
   NEED_SETUP(h, "setting material.");
+  h->gen++;
   h->mat.model = kMooneyRivlin;
   h->mat.mu10 = mu10;
   h->mat.mu01 = mu01;
@@ -252,6 +265,9 @@ extern "C" int tlfea_t10_set_external_force(tlfea_t10_t h, const double* f, int 
 static int upload_fixed(tlfea_t10_t h, const int* nodes, int n_fixed) {
   for (int k = 0; k < n_fixed; k++)
     if (nodes[k] < 0 || nodes[k] >= h->N) return fail("fixed node index out of range");
+  // a solver may still have launches in flight that read the old buffers (its own stream): drain before freeing
+  HIP_TRY(hipDeviceSynchronize());
+  h->gen++;
   if (h->d_cons) (void)hipFree(h->d_cons);
   if (h->d_fixed) (void)hipFree(h->d_fixed);
   if (h->d_fixed_slot) (void)hipFree(h->d_fixed_slot);
@@ -854,9 +870,12 @@ extern "C" double* tlfea_t10_constraint_device_ptr(tlfea_t10_t h) { return h->d_
 struct tlfea_newton_s {
   tlfea_t10_t d = nullptr;
   int N = 0, n_constraints = 0;
+  bool cons_enabled = false;     // constructed with n_constraints > 0: the reference gates every constraint term on it
   int n_constraints_global = 0;  // over all ranks (control flow must be identical on every rank)
   tlfea_newton_params prm{1e-4, 1e-4, 1e-4, 1e14, 5, 10, 1e-3};
-  tlfea_linsolve_opts lin{1e-12, 20000, 25, 0, 0.0, 0, 0};
+  tlfea_linsolve_opts lin{1e-12, 20000, 25, 0, 0.0, 0, 0, 0, 0};
+  double lin_last_rel = 0.0, lin_worst_rel = 0.0;  // ||r||/||b|| of the last linear solve / the worst since the step began
+  bool lin_last_ok = true, lin_all_ok = true;
   double lam_max = 0.0;       // estimate of lambda_max(D^-1 H) (power iteration, warm-started across solves)
   double lam_safety = 1.15;   // the polynomial's interval ends at lam_safety * lam_max (power iteration converges from below)
   double* d_eigv = nullptr;   // its vector
@@ -917,6 +936,14 @@ struct tlfea_newton_s {
   bool spmv_nt = false; // non-temporal loads of H in the SpMV (TLFEA_SPMV_NT): measured slower at config C  // per-stage hipEvent timing (adds a host sync per stage)
   double *d_xp = nullptr, *d_yp = nullptr, *d_zp = nullptr;
   double *d_H = nullptr, *d_Kbuf = nullptr, *d_Dinv = nullptr;
+  // fused tangent + assembly (T10, SVK): row groups (rowgroup_host.h) and the per-point F of the last residual launch.
+  // asm_mode (TLFEA_ASSEMBLE=kbuf|direct): 0 auto = fused where it applies, 1 always the two-kernel path via Kbuf
+  RowGroups rg{0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  int* d_rg[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  bool rg_ok = false;
+  bool fq_in_residual = true;  // first-order solvers (AdamW, Nesterov, VBD) never assemble: their residual skips Fq
+  int asm_mode = 0;
+  double* d_Fq = nullptr;
   double *d_p = nullptr, *d_p2 = nullptr, *d_q = nullptr, *d_zv = nullptr;
   double* d_parts = nullptr;  // 6 x kNPart: rz[2], pq, rr, bb, norm
   double* d_scal = nullptr;   // 4 scalars
@@ -949,9 +976,16 @@ struct tlfea_newton_s {
 
 extern "C" int tlfea_newton_create(tlfea_t10_t data, int n_constraints, tlfea_newton_t* out) {
   if (!data || !out) return fail("tlfea_newton_create: null argument");
+  // The reference sizes lambda from this count and indexes it with the data object's constraint ids: any other value
+  // than the data object's own count (or 0 = constraint terms off, SyncedNewton.cu "if (n_constraints_ > 0)") would
+  // read and write past the multipliers.
+  if (n_constraints != 0 && n_constraints != data->n_constraint)
+    return fail("solver n_constraints (" + std::to_string(n_constraints) + ") differs from the data object's (" +
+                std::to_string(data->n_constraint) + "): pass data.get_n_constraint()");
   auto* s = new tlfea_newton_s();
   s->d = data;
   s->N = data->N;
+  s->cons_enabled = n_constraints > 0;
   s->n_constraints = n_constraints;
   s->n_constraints_global = n_constraints;
   const size_t n = 3 * (size_t)s->N;
@@ -978,6 +1012,7 @@ extern "C" int tlfea_newton_create(tlfea_t10_t data, int n_constraints, tlfea_ne
   if (const char* e = std::getenv("TLFEA_SPMV_NT")) s->spmv_nt = std::atoi(e) != 0;
   if (const char* e = std::getenv("TLFEA_CHEB_BITS")) s->lin.cheb_bits = std::atoi(e);
   if (const char* e = std::getenv("TLFEA_PRECOND")) s->lin.precond = std::atoi(e);
+  if (const char* e = std::getenv("TLFEA_ASSEMBLE")) s->asm_mode = (std::string(e) == "kbuf") ? 1 : 0;
   *out = s;
   return tlfea_newton_setup(s);
 }
@@ -989,6 +1024,9 @@ extern "C" int tlfea_newton_destroy(tlfea_newton_t s) {
                   s->d_Kbuf, s->d_Dinv, s->d_p, s->d_p2, s->d_q, s->d_zv, s->d_parts, s->d_scal, s->d_if_node, s->d_if_slot, s->d_ibuf, s->d_w, s->d_nw, s->d_wc, s->d_D, s->d_B8, s->d_B1, s->d_sc, s->d_Dinv_s, s->d_cz, s->d_cz2, s->d_cres2, s->d_f32, s->d_own, s->d_sc_mask};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
+  for (int* p : s->d_rg)
+    if (p) (void)hipFree(p);
+  if (s->d_Fq) (void)hipFree(s->d_Fq);
   for (auto& e : s->ev)
     if (e) (void)hipEventDestroy(e);
   if (s->h_pin) (void)hipHostFree(s->h_pin);
@@ -1039,6 +1077,7 @@ extern "C" int tlfea_newton_set_linsolve_opts(tlfea_newton_t s, const tlfea_lins
   if (!(s->lin.cheb_kappa > 1.0)) s->lin.cheb_kappa = 0.0;  // auto
   if (s->lin.cheb_bits != 16 && s->lin.cheb_bits != 32 && s->lin.cheb_bits != 64) s->lin.cheb_bits = 0;
   if (s->lin.precond < 0 || s->lin.precond > 2) s->lin.precond = 0;
+  s->lin.on_unconverged = s->lin.on_unconverged ? 1 : 0;
   return 0;
 }
 extern "C" int tlfea_newton_set_fixed_sparsity_pattern(tlfea_newton_t s, int fixed) {
@@ -1081,7 +1120,22 @@ extern "C" int tlfea_newton_analyze_hessian_sparsity(tlfea_newton_t s) {
     }
   }
   TRY(dmalloc(&s->d_H, (size_t)s->h_nnz));
-  TRY(dmalloc(&s->d_Kbuf, (size_t)d->E * (d->S * (d->S + 1) / 2) * 9));
+  if (d->kind == kT10 && s->asm_mode != 1 && d->h_X0.size() == 3 * (size_t)N) {
+    // row groups of the fused tangent + assembly kernel (the element-block buffer Kbuf is then never allocated
+    // unless the material is switched to Mooney-Rivlin: ensure_kbuf)
+    RowGroupsHost rh;
+    if (build_row_groups(N, d->E, d->S, d->h_conn.data(), d->h_off.data(), d->h_cols.data(), d->h_n2e_off.data(),
+                         d->h_n2e.data(), d->h_X0.data(), d->h_X0.data() + N, d->h_X0.data() + 2 * (size_t)N, rh)) {
+      const std::vector<int>* src[6] = {&rh.g_inst_off, &rh.g_row_off, &rh.gr_row, &rh.gr_acc, &rh.gi_code, &rh.gi_pack};
+      for (int k = 0; k < 6; k++) {
+        TRY(dmalloc(&s->d_rg[k], src[k]->size()));
+        HIP_TRY(hipMemcpy(s->d_rg[k], src[k]->data(), src[k]->size() * sizeof(int), hipMemcpyHostToDevice));
+      }
+      s->rg = RowGroups{rh.G(), rh.acc_max, s->d_rg[0], s->d_rg[1], s->d_rg[2], s->d_rg[3], s->d_rg[4], s->d_rg[5]};
+      TRY(dmalloc(&s->d_Fq, (size_t)d->E * d->Q * 9));
+      s->rg_ok = true;
+    }
+  }
   s->sparsity_done = true;
   if (s->verbose)
     std::printf("Sparse Hessian: %d x %d, nnz = %d\n", 3 * N, 3 * N, s->h_nnz);
@@ -1345,21 +1399,51 @@ struct StageTimer {  // hipEvent pair on the launch stream around one stage (pro
   }
 };
 
+// UpdateNodalFixed may have changed the size of the fixed set since the solver was built: the multipliers follow it
+// (restarting from zero) before anything indexes them with the new constraint ids.
+static int sync_constraints(tlfea_newton_t s) {
+  tlfea_t10_t d = s->d;
+  if (!s->cons_enabled || d->n_constraint == s->n_constraints) return 0;
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  if (s->d_lam) (void)hipFree(s->d_lam);
+  s->n_constraints = d->n_constraint;
+  if (!s->ar) s->n_constraints_global = s->n_constraints;
+  TRY(dmalloc(&s->d_lam, (size_t)std::max(1, s->n_constraints)));
+  HIP_TRY(hipMemset(s->d_lam, 0, (size_t)std::max(1, s->n_constraints) * sizeof(double)));
+  return 0;
+}
+static bool pinned_on(tlfea_newton_t s) {
+  return s->n_constraints > 0 && s->d->is_constraints_setup && s->d->cons_mode == 1;
+}
+static bool lincons_on(tlfea_newton_t s) { return s->n_constraints > 0 && s->d->cons_mode == 2 && s->d->n_constraint > 0; }
+
+// the fused tangent + assembly kernel covers T10 with St.Venant-Kirchhoff (+ Kelvin-Voigt); Mooney-Rivlin and the
+// ANCF kinds keep the element-block buffer (tangent_blocks + assemble_rows)
+static bool use_direct(tlfea_newton_t s) {
+  return s->rg_ok && s->asm_mode != 1 && s->d->kind == kT10 && s->d->mat.model == kSVK;
+}
+static int ensure_kbuf(tlfea_newton_t s) {
+  if (s->d_Kbuf) return 0;
+  tlfea_t10_t d = s->d;
+  return dmalloc(&s->d_Kbuf, (size_t)d->E * (d->S * (d->S + 1) / 2) * 9);
+}
+
 static int eval_gradient(tlfea_newton_t s, double* norm_g) {
   tlfea_t10_t d = s->d;
   const tlfea_newton_params& p = s->prm;
   {
     StageTimer t(s, 0);
-    launch_residual(s->stream, d->view(), d->mat, s->d_v, d->d_fbuf, nullptr, nullptr, nullptr, nullptr);
+    launch_residual(s->stream, d->view(), d->mat, s->d_v, d->d_fbuf, nullptr, nullptr, nullptr, nullptr,
+                    (use_direct(s) && s->fq_in_residual) ? s->d_Fq : nullptr);
     t.stop();
   }
   {
     StageTimer t(s, 1);
-    const bool pinned = d->is_constraints_setup && d->cons_mode == 1;
+    const bool pinned = pinned_on(s);
     launch_grad(s->stream, s->N, d->inc(), d->d_fbuf, d->d_mval, s->d_v, s->d_vprev, d->d_fext, d->d_x, d->d_y, d->d_z,
                 d->d_xt, d->d_yt, d->d_zt, pinned ? d->d_fixed_slot : nullptr, s->d_lam, s->d_nw, p.time_step, p.rho,
                 d->d_fint, d->d_cons, s->d_g);
-    if (d->cons_mode == 2 && d->n_constraint > 0) {
+    if (lincons_on(s)) {
       // general linear rows: c = J x - rhs, then g += h J^T (lambda + rho c)   (SyncedNewton.cu:377-404)
       launch_lin_constraint(s->stream, d->n_constraint, d->d_joff, d->d_jcol, d->d_jval, d->d_rhs, d->d_x, d->d_y, d->d_z,
                             d->d_cons);
@@ -1376,9 +1460,26 @@ static int eval_gradient(tlfea_newton_t s, double* norm_g) {
   return 0;
 }
 
-static int assemble(tlfea_newton_t s) {
+// fq_fresh: the per-point F buffer holds the F of the CURRENT coordinates (true right after eval_gradient, which is
+// how the Newton loop calls it); a stand-alone assembly refreshes it with a residual launch first
+static int assemble(tlfea_newton_t s, bool fq_fresh = true) {
   tlfea_t10_t d = s->d;
   const tlfea_newton_params& p = s->prm;
+  const bool pinned = pinned_on(s);
+  if (use_direct(s)) {
+    StageTimer t(s, 3);
+    if (!fq_fresh)
+      launch_residual(s->stream, d->view(), d->mat, s->d_v, d->d_fbuf, nullptr, nullptr, nullptr, nullptr, s->d_Fq);
+    launch_assemble_direct(s->stream, d->view(), d->mat, p.time_step, s->rg, d->inc(), s->d_Fq, d->d_mval,
+                           pinned ? d->d_fixed_slot : nullptr, s->d_nw, p.time_step * p.time_step * p.rho, s->d_H);
+    if (lincons_on(s))  // + h^2 rho J^T J  (SyncedNewton.cu:292-341)
+      launch_lin_constraint_hessian(s->stream, 3 * s->N, d->d_jtoff, d->d_jtcol, d->d_jtval, d->d_joff, d->d_jcol,
+                                    d->d_jval, d->d_off, d->d_cols, p.time_step * p.time_step * p.rho, s->d_H);
+    HIP_TRY(hipGetLastError());
+    t.stop();
+    return 0;
+  }
+  TRY(ensure_kbuf(s));
   {
     StageTimer t(s, 2);
     launch_tangent_blocks(s->stream, d->view(), d->mat, p.time_step, s->d_Kbuf);
@@ -1386,10 +1487,9 @@ static int assemble(tlfea_newton_t s) {
   }
   {
     StageTimer t(s, 3);
-    const bool pinned = d->is_constraints_setup && d->cons_mode == 1;
     launch_assemble_rows(s->stream, s->N, d->S, d->maxdeg, d->inc(), s->d_Kbuf, d->d_mval, 1.0 / p.time_step,
                          pinned ? d->d_fixed_slot : nullptr, s->d_nw, p.time_step * p.time_step * p.rho, s->d_H);
-    if (d->cons_mode == 2 && d->n_constraint > 0)  // + h^2 rho J^T J  (SyncedNewton.cu:292-341)
+    if (lincons_on(s))  // + h^2 rho J^T J  (SyncedNewton.cu:292-341)
       launch_lin_constraint_hessian(s->stream, 3 * s->N, d->d_jtoff, d->d_jtcol, d->d_jtval, d->d_joff, d->d_jcol,
                                     d->d_jval, d->d_off, d->d_cols, p.time_step * p.time_step * p.rho, s->d_H);
     HIP_TRY(hipGetLastError());
@@ -2139,9 +2239,22 @@ static int pcg(tlfea_newton_t s, const double* d_b, double* d_x, int* iters_out,
   }
   HIP_TRY(hipGetLastError());
   t.stop();
+  const double rel = bb > 0.0 ? std::sqrt(rr / bb) : 0.0;
   if (iters_out) *iters_out = it;
-  if (rel_out) *rel_out = bb > 0.0 ? std::sqrt(rr / bb) : 0.0;
+  if (rel_out) *rel_out = rel;
+  s->lin_last_rel = rel;
+  s->lin_last_ok = rel == rel && rel <= s->lin.rel_tol;
+  s->lin_worst_rel = (rel != rel) ? rel : std::max(s->lin_worst_rel, rel);
+  s->lin_all_ok = s->lin_all_ok && s->lin_last_ok;
   if (rr != rr) return fail("PCG produced NaN (Hessian not SPD?)");
+  // The solve stands in for the reference's cuDSS factor + solve, which aborts on failure: an iterate that missed the
+  // tolerance (max_iter, or breakdown after the last interval widening) is not applied unless the caller asked for it.
+  if (!s->lin_last_ok && !s->lin.on_unconverged) {
+    char msg[256];
+    std::snprintf(msg, sizeof msg, "PCG did not converge: ||r||/||b|| = %.3e > rel_tol %.1e after %d iterations (max_iter %d)",
+                  rel, s->lin.rel_tol, it, s->lin.max_iter);
+    return fail(msg);
+  }
   return 0;
 }
 
@@ -2209,6 +2322,11 @@ extern "C" int tlfea_newton_get_precond(tlfea_newton_t s) {  // 1 Chebyshev poly
   if (!s) return -1;
   return cheb_degree_eff(s) > 1 ? precond_eff(s) : 0;
 }
+extern "C" int tlfea_newton_get_assembly_mode(tlfea_newton_t s) {
+  if (!s) return 0;
+  if (tlfea_newton_analyze_hessian_sparsity(s)) return 0;
+  return use_direct(s) ? 2 : 1;
+}
 extern "C" int tlfea_newton_get_linsolve_info(tlfea_newton_t s, int* cheb_degree, int* cheb_bits, int* cheb_vector_bits) {
   if (!s) return fail("null argument");
   if (cheb_degree) *cheb_degree = cheb_degree_eff(s);
@@ -2218,11 +2336,12 @@ extern "C" int tlfea_newton_get_linsolve_info(tlfea_newton_t s, int* cheb_degree
 }
 extern "C" int tlfea_newton_eval_gradient(tlfea_newton_t s, double* norm_g) {
   TRY(tlfea_newton_analyze_hessian_sparsity(s));
+  TRY(sync_constraints(s));
   return eval_gradient(s, norm_g);
 }
 extern "C" int tlfea_newton_assemble_hessian(tlfea_newton_t s) {
   TRY(tlfea_newton_analyze_hessian_sparsity(s));
-  TRY(assemble(s));
+  TRY(assemble(s, /*fq_fresh=*/false));
   HIP_TRY(hipStreamSynchronize(s->stream));
   return 0;
 }
@@ -2252,12 +2371,19 @@ extern "C" int tlfea_newton_time_kernels(tlfea_newton_t s, int reps, double* out
     HIP_TRY(hipEventRecord(s->ev[6], s->stream));
     for (int r = 0; r < reps; r++) {
       if (k == 0)
-        launch_residual(s->stream, d->view(), d->mat, s->d_v, d->d_fbuf, nullptr, nullptr, nullptr, nullptr);
-      else if (k == 1)
+        launch_residual(s->stream, d->view(), d->mat, s->d_v, d->d_fbuf, nullptr, nullptr, nullptr, nullptr,
+                        use_direct(s) ? s->d_Fq : nullptr);
+      else if (k == 1) {
+        if (use_direct(s)) break;  // no separate tangent launch on the fused path: out[1] = 0
+        TRY(ensure_kbuf(s));
         launch_tangent_blocks(s->stream, d->view(), d->mat, p.time_step, s->d_Kbuf);
+      } else if (k == 2 && use_direct(s))  // out[2] = the fused tangent + assembly launch
+        launch_assemble_direct(s->stream, d->view(), d->mat, p.time_step, s->rg, d->inc(), s->d_Fq, d->d_mval,
+                               pinned_on(s) ? d->d_fixed_slot : nullptr, s->d_nw,
+                               p.time_step * p.time_step * p.rho, s->d_H);
       else if (k == 2)
         launch_assemble_rows(s->stream, N, d->S, d->maxdeg, d->inc(), s->d_Kbuf, d->d_mval, 1.0 / p.time_step,
-                             (d->is_constraints_setup && d->cons_mode == 1) ? d->d_fixed_slot : nullptr, s->d_nw,
+                             pinned_on(s) ? d->d_fixed_slot : nullptr, s->d_nw,
                              p.time_step * p.time_step * p.rho, s->d_H);
       else if (k == 3)  // the CG iteration's launch (beta from the reduction slots as in the solver; p ping-pongs)
         launch_spmv_dir_dot(s->stream, N, d->inc(), s->d_H, s->d_zv, (r & 1) ? s->d_p2 : s->d_p, 0, part(s, 1), part(s, 0),
@@ -2352,6 +2478,9 @@ static int begin_step(tlfea_newton_t s) {  // cudss_solve_update_pos_prev (Synce
 
 extern "C" int tlfea_newton_iteration(tlfea_newton_t s, double* norm_g, int* iters) {
   TRY(tlfea_newton_analyze_hessian_sparsity(s));
+  TRY(sync_constraints(s));
+  s->lin_worst_rel = 0.0;
+  s->lin_all_ok = true;
   double ng = 0.0;
   TRY(eval_gradient(s, &ng));
   launch_axpy_neg(s->stream, 3 * s->N, s->d_g, s->d_b);  // b = -g
@@ -2371,6 +2500,9 @@ extern "C" int tlfea_newton_solve(tlfea_newton_t s) {
   tlfea_t10_t d = s->d;
   if (!d->have_dndu) return fail("CalcDnDuPre must be called before Solve");
   TRY(tlfea_newton_analyze_hessian_sparsity(s));
+  TRY(sync_constraints(s));
+  s->lin_worst_rel = 0.0;
+  s->lin_all_ok = true;
   const tlfea_newton_params& p = s->prm;
   const int n = 3 * s->N;
   hipEvent_t e0 = s->ev[2], e1 = s->ev[3];
@@ -2439,6 +2571,15 @@ extern "C" int tlfea_newton_get_stats(tlfea_newton_t s, double* st) {
   std::copy(s->stats, s->stats + 6, st);
   return 0;
 }
+extern "C" int tlfea_newton_n_constraints(tlfea_newton_t s) { return s ? s->n_constraints : -1; }
+extern "C" int tlfea_newton_get_linsolve_status(tlfea_newton_t s, double* out4) {
+  if (!s || !out4) return fail("null argument");
+  out4[0] = s->lin_last_rel;
+  out4[1] = s->lin_last_ok ? 1.0 : 0.0;
+  out4[2] = s->lin_worst_rel;
+  out4[3] = s->lin_all_ok ? 1.0 : 0.0;
+  return 0;
+}
 extern "C" int tlfea_newton_get_stage_ms(tlfea_newton_t s, double* ms, double* counts, int reset) {
   std::copy(s->stage_ms, s->stage_ms + 8, ms);
   if (counts) std::copy(s->stage_n, s->stage_n + 8, counts);
@@ -2477,6 +2618,7 @@ extern "C" int tlfea_adamw_create(tlfea_t10_t data, int n_constraints, tlfea_ada
   if (!data || !out) return fail("tlfea_adamw_create: null argument");
   auto* a = new tlfea_adamw_s();
   TRY(tlfea_newton_create(data, n_constraints, &a->core));
+  a->core->fq_in_residual = false;
   const size_t n = 3 * (size_t)a->core->N;
   TRY(dmalloc(&a->d_m, n));
   TRY(dmalloc(&a->d_va, n));
@@ -2534,6 +2676,7 @@ extern "C" int tlfea_adamw_solve(tlfea_adamw_t a) {
   const tlfea_adamw_params& p = a->prm;
   if (!d->is_csr_setup) return fail("SyncedAdamWNocoop: CalcMassMatrix() must precede Solve() (the gradient uses the mass CSR)");
   if (s->ar) return fail("SyncedAdamWNocoop: single-GPU path only");
+  TRY(sync_constraints(s));
   const int N = s->N, n = 3 * N;
   const double dt = p.time_step;
   // the core evaluates grad L with ITS parameters: time step and rho of this solver
@@ -2622,6 +2765,7 @@ extern "C" int tlfea_nesterov_create(tlfea_t10_t data, int n_constraints, tlfea_
   if (!data || !out) return fail("tlfea_nesterov_create: null argument");
   auto* a = new tlfea_nesterov_s();
   TRY(tlfea_newton_create(data, n_constraints, &a->core));
+  a->core->fq_in_residual = false;
   const size_t n = 3 * (size_t)a->core->N;
   TRY(dmalloc(&a->d_vk, n)); TRY(dmalloc(&a->d_vkm1, n)); TRY(dmalloc(&a->d_vnext, n));
   *out = a;
@@ -2665,6 +2809,7 @@ extern "C" int tlfea_nesterov_solve(tlfea_nesterov_t a) {
   const tlfea_nesterov_params& p = a->prm;
   if (!d->is_csr_setup) return fail("SyncedNesterov: CalcMassMatrix() must precede Solve() (the gradient uses the mass CSR)");
   if (s->ar) return fail("SyncedNesterov: single-GPU path only");
+  TRY(sync_constraints(s));
   if (d->cons_mode == 2) return fail("SyncedNesterov: fixed-coefficient constraints only (as the reference, :197-200)");
   const int N = s->N, n = 3 * N;
   const double dt = p.time_step;
@@ -2744,7 +2889,9 @@ struct tlfea_vbd_s {
   bool coloring_ready = false, mass_ready = false, fixed_ready = false;
   int colored_group_size = 0;
   hipGraphExec_t sweep_graph = nullptr;
-  double graph_key[5] = {0, 0, 0, 0, 0};  // h, rho, omega, hess_eps, pinned?: the values baked into the captured launches
+  // what the captured launches have baked in: h, rho, omega, hess_eps, pinned?, the data object's generation (material
+  // scalars by value, the fixed-slot buffer re-allocated by UpdateNodalFixed) and the multiplier buffer
+  double graph_key[7] = {0, 0, 0, 0, 0, -1, 0};
   double stats[6] = {0, 0, 0, 0, 0, 0};
   int verbose = 0;
 };
@@ -2758,6 +2905,7 @@ extern "C" int tlfea_vbd_create(tlfea_t10_t data, int n_constraints, tlfea_vbd_t
   if (!data || !out) return fail("tlfea_vbd_create: null argument");
   auto* a = new tlfea_vbd_s();
   TRY(tlfea_newton_create(data, n_constraints, &a->core));
+  a->core->fq_in_residual = false;
   *out = a;
   return 0;
 }
@@ -2885,13 +3033,14 @@ static void vbd_enqueue_sweep(tlfea_vbd_t a, hipStream_t st) {
 static int vbd_sweep(tlfea_vbd_t a) {
   tlfea_newton_t s = a->core;
   const tlfea_vbd_params& p = a->prm;
-  const double key[5] = {p.time_step, p.rho, p.omega, p.hess_eps, s->n_constraints > 0 ? 1.0 : 0.0};
+  const double key[7] = {p.time_step, p.rho, p.omega, p.hess_eps, s->n_constraints > 0 ? 1.0 : 0.0, (double)s->d->gen,
+                         (double)(uintptr_t)s->d_lam};
   const bool graphs = s->use_graphs && s->stream != nullptr;
   if (!graphs) {
     vbd_enqueue_sweep(a, s->stream);
     return 0;
   }
-  if (a->sweep_graph && !std::equal(key, key + 5, a->graph_key)) vbd_drop_graph(a);
+  if (a->sweep_graph && !std::equal(key, key + 7, a->graph_key)) vbd_drop_graph(a);
   if (!a->sweep_graph) {
     hipGraph_t graph = nullptr;
     HIP_TRY(hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
@@ -2899,7 +3048,7 @@ static int vbd_sweep(tlfea_vbd_t a) {
     HIP_TRY(hipStreamEndCapture(s->stream, &graph));
     HIP_TRY(hipGraphInstantiate(&a->sweep_graph, graph, nullptr, nullptr, 0));
     HIP_TRY(hipGraphDestroy(graph));
-    std::copy(key, key + 5, a->graph_key);
+    std::copy(key, key + 7, a->graph_key);
   }
   HIP_TRY(hipGraphLaunch(a->sweep_graph, s->stream));
   return 0;
@@ -2911,6 +3060,7 @@ extern "C" int tlfea_vbd_solve(tlfea_vbd_t a) {
   tlfea_t10_t d = s->d;
   const tlfea_vbd_params& p = a->prm;
   if (s->ar) return fail("SyncedVBDSolver: single-GPU path only");
+  TRY(sync_constraints(s));
   if (!a->mass_ready && !d->is_csr_setup) TRY(tlfea_vbd_initialize_mass_diag_blocks(a));
   TRY(tlfea_vbd_initialize_coloring(a));
   if (!a->fixed_ready) TRY(tlfea_vbd_initialize_fixed_map(a));

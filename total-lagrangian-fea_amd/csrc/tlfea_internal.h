@@ -53,12 +53,31 @@ struct Incidence {
   const int* diagpos;   // [N]     position of i in row i
 };
 
+// Row groups of the fused tangent + assembly kernel (T10, SVK): a wavefront owns a few node rows of H (3 CSR rows
+// each) and works through their (row, incident element) instances, 6 at a time.  Built once per mesh on the host
+// (rowgroup_host.h): rows in Morton order of the reference coordinates, so that consecutive groups share elements.
+struct RowGroups {
+  int G;                  // number of groups
+  int acc_max;            // doubles of LDS accumulator the largest group needs
+  const int* g_inst_off;  // [G+1] instances of group g: g_inst_off[g] .. g_inst_off[g+1]
+  const int* g_row_off;   // [G+1] rows of group g (indices into gr_row / gr_acc)
+  const int* gr_row;      // [N]   node id of each group row
+  const int* gr_acc;      // [N]   offset (doubles) of the row's 9*deg accumulator inside the group's LDS block
+  const int* gi_code;     // [S*E] element * S + local node, group order (ascending element inside a row)
+  const int* gi_pack;     // [S*E][S] per (instance, column node j): (gr_acc + 3*pos_j) | (3*deg << 16)
+};
+
 // ---- launch wrappers (defined in the .hip files) -------------------------------------------
 void launch_dndu_pre(hipStream_t s, int E, int Epad, const int* conn, const double* x, const double* y,
                      const double* z, const double* qx, const double* qy, const double* qz,
                      double* gradN, double* gradN_t, double* detJ);
 void launch_residual(hipStream_t s, const ElemView& m, const Material& mat, const double* v /*or null*/,
-                     double* fbuf /*[E][30]*/, double* F, double* P, double* Fdot, double* Pvis);
+                     double* fbuf /*[E][30]*/, double* F, double* P, double* Fdot, double* Pvis,
+                     double* Fq = nullptr /*[Q][E][9] row-major F per point, for the fused assembly*/);
+// fused tangent + row assembly (T10, SVK): H rows straight from grad N and the F of the last residual launch
+void launch_assemble_direct(hipStream_t s, const ElemView& m, const Material& mat, double h, const RowGroups& rg,
+                            const Incidence& inc, const double* Fq, const double* mval, const int* fixed_slot,
+                            const double* nw, double penalty, double* Hval);
 void launch_tangent_blocks(hipStream_t s, const ElemView& m, const Material& mat, double h,
                            double* Kbuf /*[E][55][9]*/);
 void launch_assemble_rows(hipStream_t s, int N, int S, int maxdeg, const Incidence& inc, const double* Kbuf,

@@ -28,6 +28,8 @@ class LinSolveOpts:
     cheb_kappa: float = 0.0   # polynomial interval [lmax/kappa, lmax] of D^-1 H (0 = auto, by degree)
     cheb_bits: int = 0        # matrix precision of the polynomial's steps: 64 | 32 | 16 (0 = auto = 16)
     precond: int = 0          # 0 auto | 1 Chebyshev polynomial | 2 two-level p-multigrid (T10, one GPU)
+    method: int = 0           # 0 preconditioned CG | 1 sparse direct (where built)
+    on_unconverged: int = 0   # 0: a solve that misses rel_tol fails the call (nothing applied) | 1: accept the iterate
 
 
 class SyncedNewtonSolver:
@@ -57,7 +59,8 @@ class SyncedNewtonSolver:
         check(self._lib.tlfea_newton_set_parameters(self._h, C.byref(p)))
 
     def SetLinSolveOpts(self, o):
-        c = LinSolveOptsC(o.rel_tol, o.max_iter, o.check_every, o.cheb_degree, o.cheb_kappa, o.cheb_bits, o.precond)
+        c = LinSolveOptsC(o.rel_tol, o.max_iter, o.check_every, o.cheb_degree, o.cheb_kappa, o.cheb_bits, o.precond,
+                          o.method, o.on_unconverged)
         check(self._lib.tlfea_newton_set_linsolve_opts(self._h, C.byref(c)))
 
     def GetLinSolveInfo(self):
@@ -69,6 +72,10 @@ class SyncedNewtonSolver:
     def GetPreconditioner(self):
         """0 block-Jacobi, 1 Chebyshev polynomial, 2 two-level p-multigrid (what a solve would use now)"""
         return int(self._lib.tlfea_newton_get_precond(self._h))
+
+    def GetAssemblyMode(self):
+        """1: tangent blocks + row-owner gather (two launches), 2: fused row-owner tangent + assembly (T10, SVK)"""
+        return int(self._lib.tlfea_newton_get_assembly_mode(self._h))
 
     def RetrievePmgLevel(self):
         """(par0, par1, c_off, c_cols, Hc_values): parent map of the fine nodes, coarse node adjacency and the Galerkin
@@ -179,6 +186,7 @@ class SyncedNewtonSolver:
         check(self._lib.tlfea_newton_set_lambda(self._h, dp(lam)))
 
     def RetrieveLambdaToCPU(self):
+        self.n_constraints = int(self._lib.tlfea_newton_n_constraints(self._h))   # follows UpdateNodalFixed
         lam = np.zeros(self.n_constraints)
         check(self._lib.tlfea_newton_retrieve_lambda(self._h, dp(lam)))
         return lam
@@ -187,6 +195,13 @@ class SyncedNewtonSolver:
         st = np.zeros(6)
         check(self._lib.tlfea_newton_get_stats(self._h, dp(st)))
         return dict(outer=int(st[0]), newton=int(st[1]), norm_g=st[2], norm_c=st[3], pcg_iters=int(st[4]), ms=st[5])
+
+    def GetLinSolveStatus(self):
+        """Linear solves since the last Solve() / NewtonIteration() began: relative residual and tolerance flag of the
+        last one, worst relative residual, and whether all of them met rel_tol."""
+        st = np.zeros(4)
+        check(self._lib.tlfea_newton_get_linsolve_status(self._h, dp(st)))
+        return dict(rel_res=st[0], converged=bool(st[1]), worst_rel_res=st[2], all_converged=bool(st[3]))
 
     STAGES = ["residual", "grad", "tangent_blocks", "assemble_rows", "pcg", "update", "spmv", "_"]
 
