@@ -10,7 +10,15 @@ extern "C" int rg_build(int N, int E, int S, const int* conn, const int* off, co
   sizes[0] = g_rg.G();
   sizes[1] = (int)g_rg.gi_code.size();
   sizes[2] = g_rg.acc_max;
+  sizes[3] = (int)(g_rg.pt.size() / 4);
+  sizes[4] = g_rg.C();
   return 0;
+}
+extern "C" void rg_fetch_passes(int* pt, int* chunk_off, int* gr_info, int* gi_mb) {
+  std::copy(g_rg.pt.begin(), g_rg.pt.end(), pt);
+  std::copy(g_rg.chunk_off.begin(), g_rg.chunk_off.end(), chunk_off);
+  std::copy(g_rg.gr_info.begin(), g_rg.gr_info.end(), gr_info);
+  std::copy(g_rg.gi_mb.begin(), g_rg.gi_mb.end(), gi_mb);
 }
 extern "C" void rg_fetch(int* g_inst_off, int* g_row_off, int* gr_row, int* gr_acc, int* gi_code, int* gi_pack) {
   std::copy(g_rg.g_inst_off.begin(), g_rg.g_inst_off.end(), g_inst_off);

@@ -37,6 +37,15 @@ def shell_problem(n_elem=3, L=2.0, W=1.0, H=0.1):
     return 3443, x, y, z, conn, (L, W, H), fixed, f_ext
 
 
+def plate_problem():
+    """BASELINE config D's workload at test size (workloads.py "Ds": 16 x 12 ANCF-3443 plate, interior nodes shared by
+    FOUR shells -- the strips above only ever have two): one edge clamped with all four coefficient vectors, line load
+    on the opposite edge (lib_bin/beam_sag/test_ancf3443.cc:240-323 flow on a plate)."""
+    wl = __import__("importlib").import_module("total-lagrangian-fea_amd.workloads")
+    w = wl.build("Ds")
+    return 3443, w["x12"], w["y12"], w["z12"], w["conn"], w["dims"], w["fixed"], w["f_ext"]
+
+
 def make_pair(prob, mat_kw, with_constraints=True):
     kind, x, y, z, conn, (L, W, H), fixed, f_ext = prob
     if mat_kw["kind"] == "svk":
@@ -81,7 +90,7 @@ def make_pair(prob, mat_kw, with_constraints=True):
 SVK = dict(kind="svk", E=7e8, nu=0.33, rho0=2700.0, eta=0.0, lamd=0.0)
 SVK_D = dict(SVK, eta=1e5, lamd=1e5)  # test_ancf3243.cc:287-291
 MR_D = dict(kind="mr", mu10=4e7, mu01=1e7, kappa=5e8, rho0=920.0, eta=2e4, lamd=3e4)
-PROBLEMS = {"beam3243": beam_problem, "shell3443": shell_problem}
+PROBLEMS = {"beam3243": beam_problem, "shell3443": shell_problem, "plate3443": plate_problem}
 
 
 def perturb(o, d, sigma=1e-3, seed=5):
@@ -160,7 +169,7 @@ def test_calc_p(pname):
     d.Destroy()
 
 
-@pytest.mark.parametrize("pname,steps", [("beam3243", 3), ("shell3443", 2)])
+@pytest.mark.parametrize("pname,steps", [("beam3243", 3), ("shell3443", 2), ("plate3443", 1)])
 def test_newton_steps(pname, steps):
     """Driver parameters of lib_bin/beam_sag/test_ancf3243.cc:329 / test_ancf3443.cc:357: {1e-4,0,1e-6,1e14,5,10,dt},
     Kelvin-Voigt damping 1e5/1e5 (:287-291)."""
@@ -180,6 +189,42 @@ def test_newton_steps(pname, steps):
         xo = np.stack([o.x, o.y, o.z], axis=1)
         assert disp_err_ok(xg, xo, X0), (st_g, st_o)
         assert st_g["outer"] == st_o[0] and st_g["newton"] == st_o[1]
+    del s
+    d.Destroy()
+
+
+def test_full_size_config_d_properties():
+    """BASELINE config D (512 x 500 ANCF-3443 shells = 256 000 elements, 3.08 M DOF, 48 force points per element): the
+    oracle does not finish at this size in test time, so parity rests on size-independent properties -- the internal
+    forces of the position coefficients are self-equilibrated, H = H^T (x.Hy == y.Hx through the device SpMV), assembly is
+    bitwise reproducible, the PCG solution has the residual it claims, and a Newton iteration reduces the gradient."""
+    wl = __import__("importlib").import_module("total-lagrangian-fea_amd.workloads")
+    w = wl.build("D")
+    E, N = w["conn"].shape[0], len(w["x12"])
+    assert (E, N) == (256000, 4 * 257013)
+    d, s = wl.make_engine(tl, w)
+    d.UpdatePositions(w["x0"][:, 0], w["x0"][:, 1], w["x0"][:, 2])
+    d.CalcP()
+    d.CalcInternalForce()
+    f = d.RetrieveInternalForceToCPU().reshape(-1, 4, 3)
+    # a rigid translation moves only the position coefficients r (slot 0): their forces sum to zero
+    assert np.abs(f[:, 0, :].sum(axis=0)).max() < 1e-9 * np.abs(f).max()
+    s.AssembleHessian()
+    rng = np.random.default_rng(7)
+    x, y = rng.normal(size=3 * N), rng.normal(size=3 * N)
+    Hx, Hy = s.ApplyHessian(x), s.ApplyHessian(y)
+    assert abs(y @ Hx - x @ Hy) <= 1e-11 * (np.linalg.norm(Hx) * np.linalg.norm(y))
+    assert (x @ Hx) > 0 and (y @ Hy) > 0
+    s.AssembleHessian()
+    assert np.array_equal(Hx, s.ApplyHessian(x))                      # same bits after re-assembly
+    s.SetLinSolveOpts(tl.LinSolveOpts(1e-10, 3000, 25))
+    b = rng.normal(size=3 * N)
+    xs, iters, rel = s.LinearSolve(b)
+    assert rel <= 1e-10 and np.linalg.norm(s.ApplyHessian(xs) - b) / np.linalg.norm(b) < 1e-9
+    s.BeginStep()
+    g0, _ = s.NewtonIteration()
+    g1 = s.EvalGradient()
+    assert g1 < 0.5 * g0, (g0, g1)
     del s
     d.Destroy()
 

@@ -1,6 +1,8 @@
 """Host set-up of the fused tangent + assembly kernel (csrc/rowgroup_host.h): every row owned once, every (row, element)
 instance listed once in ascending element order, packed accumulator offsets consistent with the sorted column lists,
-accumulators of one group disjoint and within the 16-bit packing.  Integer work only -- runs without a GPU."""
+accumulators of one group disjoint and within the 16-bit packing; every block's mass carried by exactly one item; the
+pass table walks every instance once, group by group; chunks cut it at group boundaries.  Integer work only -- runs
+without a GPU."""
 import ctypes as C
 import os
 import subprocess
@@ -56,9 +58,9 @@ def test_row_groups_invariants(shim, mesh):
     off, cols, n2e_off, n2e = adjacency(conn, N)
     conn_cm = np.ascontiguousarray(conn.T)                       # column-major E x S, the engine's layout
     x, y, z = (np.ascontiguousarray(X[:, k]) for k in range(3))
-    sizes = np.zeros(3, dtype=np.int32)
+    sizes = np.zeros(5, dtype=np.int32)
     assert shim.rg_build(N, E, S, ip(conn_cm), ip(off), ip(cols), ip(n2e_off), ip(n2e), dp(x), dp(y), dp(z), ip(sizes)) == 0
-    G, n_inst, acc_max = map(int, sizes)
+    G, n_inst, acc_max, P, nchunks = map(int, sizes)
     assert n_inst == E * S
     g_inst_off, g_row_off = np.zeros(G + 1, np.int32), np.zeros(G + 1, np.int32)
     gr_row, gr_acc = np.zeros(N, np.int32), np.zeros(N, np.int32)
@@ -69,6 +71,14 @@ def test_row_groups_invariants(shim, mesh):
     assert np.array_equal(np.sort(gi_code), np.arange(E * S))    # every (element, local node) listed once
     deg = np.diff(off)
     gi_pack = gi_pack.reshape(n_inst, S)
+    pt, chunk_off = np.zeros(4 * P, np.int32), np.zeros(nchunks + 1, np.int32)
+    gr_info, gi_mb = np.zeros(4 * N, np.int32), np.zeros(n_inst, np.int32)
+    shim.rg_fetch_passes(ip(pt), ip(chunk_off), ip(gr_info), ip(gi_mb))
+    pt, gr_info = pt.reshape(P, 4), gr_info.reshape(N, 4)
+    mass_flag = gi_pack < 0                                      # bit 31: the item carries its block's M/h
+    gi_pack = gi_pack & 0x7FFFFFFF
+    carried = np.zeros(len(cols), dtype=np.int32)                # how many items carry the mass of each block
+    pi = 0                                                       # pass cursor
     for g in range(G):
         rows = gr_row[g_row_off[g]:g_row_off[g + 1]]
         acc = gr_acc[g_row_off[g]:g_row_off[g + 1]]
@@ -87,8 +97,34 @@ def test_row_groups_invariants(shim, mesh):
                 assert np.array_equal(c[pos], conn[e])
                 assert np.array_equal(gi_pack[w + k] & 0xFFFF, a0 + 3 * pos)
                 assert np.all(gi_pack[w + k] >> 16 == 3 * deg[i])
+                # mass value of the block: mval[gi_mb + acc offset / 3] == mval[off[i] + pos]
+                assert np.array_equal(gi_mb[w + k] + (gi_pack[w + k] & 0xFFFF) // 3, off[i] + pos)
+                np.add.at(carried, off[i] + pos[mass_flag[w + k]], 1)
+                if k == 0:
+                    assert np.all(mass_flag[w + k])             # the lowest element is the first contribution
             w += n
         assert w == g_inst_off[g + 1]
+        # row records and passes of the group
+        r0, nr = g_row_off[g], g_row_off[g + 1] - g_row_off[g]
+        for t, (i, a0) in enumerate(zip(rows, acc)):
+            c = cols[off[i]:off[i + 1]]
+            assert gr_info[r0 + t].tolist() == [a0 | (int(np.searchsorted(c, i)) << 16), off[i], deg[i], i]
+        i0, i1 = g_inst_off[g], g_inst_off[g + 1]
+        p0 = i0
+        while True:
+            inst0, meta, row0, acc_n = pt[pi]
+            cnt = min(6, i1 - p0)
+            assert inst0 == p0 and (meta & 7) == cnt and (meta >> 8) == nr and row0 == r0
+            assert bool(meta & 8) == (p0 == i0) and bool(meta & 16) == (p0 + 6 >= i1)
+            assert acc_n == acc[-1] + 9 * deg[rows[-1]]
+            pi += 1
+            p0 += 6
+            if p0 >= i1:
+                break
+    assert pi == P
+    assert np.all(carried == 1)                                  # every block's M/h enters H exactly once
+    assert chunk_off[0] == 0 and chunk_off[-1] == P and np.all(np.diff(chunk_off) > 0)
+    assert np.all(pt[chunk_off[:-1], 1] & 8) and np.all(pt[chunk_off[1:] - 1, 1] & 16)   # chunks hold whole groups
     # locality: consecutive groups are spatial neighbours (Morton order) -- the median distance between the first rows of
     # consecutive groups is a few element sizes, far below the body's extent
     first = X[gr_row[g_row_off[:-1]]]

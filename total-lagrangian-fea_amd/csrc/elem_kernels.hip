@@ -942,15 +942,20 @@ void launch_assemble_rows(hipStream_t s, int N, int S, int maxdeg, const Inciden
 // ------------------------------------------------------------------------------------------------
 // Fused tangent + assembly, T10 <10,5>, St.Venant-Kirchhoff (+ Kelvin-Voigt): compute_hessian_assemble_csr
 // (FEAT10DataFunc.cuh:513-791) + assemble_sparse_hessian_{mass,tangent,constraints} (SyncedNewton.cu:214-341) in ONE
-// launch with no element-block buffer in HBM.  Owner computes: a wavefront owns a GROUP of node rows of H (RowGroups;
-// rows in Morton order, groups dealt to the XCDs in contiguous ranges so that the grad-N re-reads of neighbouring
+// launch with no element-block buffer in HBM.  Owner computes: a wavefront owns a chunk of row GROUPS of H (RowGroups;
+// rows in Morton order, chunks dealt to the XCDs in contiguous ranges so that the grad-N re-reads of neighbouring
 // rows hit that XCD's L2) and recomputes, for every (row i, incident element e) INSTANCE, the ten 3x3 blocks
 // K_e(i, j), j = 0..9 -- 100 blocks per element over all its rows instead of the 55 of the symmetric element-wise
 // form, in exchange for 7.9 kB per element of block-buffer traffic and a second kernel.
-//   pass   = 6 instances x 10 column nodes = 60 lanes, lane (k, j) sums its block over the 5 points in 9 registers
+//   pass   = up to 6 instances x 10 column nodes = 60 lanes, lane (k, j) sums its block over the 5 points in registers
 //   staged = per (instance, point) one 26-double record {h_i, F h_i, F, B1 F F^T, A1, B1, C0, C1} in LDS (F comes from
 //            the residual launch that precedes every assembly: Fq); h_j goes from memory straight to registers
-//   sum    = ds_add_f64 into the group's row accumulators in LDS (H layout), rows stream out once at the end
+//   sum    = ds_add_f64 into the group's row accumulators in LDS (H layout); the first contribution to a block also
+//            carries the block's M/h; the rows stream out once when the group's last pass is done (+ h^2 rho on the
+//            diagonal of pinned rows)
+// The kernel is built around load latency, not bandwidth: the pass table entry is read two passes ahead (scalar), the
+// instance codes / packed offsets one pass ahead, so that a pass waits for ONE round trip (grad N, F, mass) before it
+// computes; per-row records travel in registers from the group's first pass to its last.
 // The LDS adds of one wave execute in program order, lanes of one instruction in the hardware's fixed conflict
 // order, so the sum order is fixed: bitwise reproducible like the two-kernel path (tests check it).
 // ------------------------------------------------------------------------------------------------
@@ -960,109 +965,128 @@ constexpr int kAdRec = 26;                            // doubles per staged reco
 constexpr int kAdRecTotal = kAdInst * kNQ * kAdRec;   // 780 doubles = 6.1 KiB
 }  // namespace
 
-__global__ __launch_bounds__(64) void assemble_direct_kernel(ElemView m, Material mat, double h, RowGroups rg,
-                                                            Incidence inc, const double* __restrict__ Fq,
-                                                            const double* __restrict__ mval, double inv_h,
-                                                            const int* __restrict__ fixed_slot,
-                                                            const double* __restrict__ nw, double penalty,
-                                                            double* __restrict__ Hval) {
+__global__ __launch_bounds__(64, 2) void assemble_direct_kernel(ElemView m, Material mat, double h, RowGroups rg,
+                                                               const double* __restrict__ Fq,
+                                                               const double* __restrict__ mval, double inv_h,
+                                                               const int* __restrict__ fixed_slot,
+                                                               const double* __restrict__ nw, double penalty,
+                                                               double* __restrict__ Hval) {
   extern __shared__ __attribute__((aligned(16))) double lds_ad[];
   double* rec = lds_ad;                // [kAdInst][kNQ][kAdRec]
   double* acc = lds_ad + kAdRecTotal;  // the group's rows, each in H's layout [d][3 deg]
-  // blocks b, b + 8, ... share an XCD (round-robin dispatch): XCD x works through groups [x per, (x+1) per)
+  // blocks b, b + 8, ... share an XCD (round-robin dispatch): XCD x works through chunks [x per, (x+1) per)
   const int per = gridDim.x >> 3;
-  const int g = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
-  if (g >= rg.G) return;
+  const int c = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  if (c >= rg.C) return;
   const int lane = threadIdx.x;
-  const int row0 = rg.g_row_off[g], row1 = rg.g_row_off[g + 1];
-  const int inst0 = rg.g_inst_off[g], inst1 = rg.g_inst_off[g + 1];
+  const int k = lane / kNN, j = lane - kNN * k;  // item (instance k, column node j); lanes 60..63: k == 6, idle
+  const int ts = lane & 31;                      // staging: record ts of 30, lanes 0..29 kinematic half, 32..61 material half
+  const bool stager = ts < kAdInst * kNQ;
+  const int ks = stager ? ts / kNQ : 0, qs = stager ? ts - kNQ * (ts / kNQ) : 0;
+  const int E = m.E, last_inst = rg.n_inst - 1;
+  int p = rg.chunk_off[c];
+  const int pend = rg.chunk_off[c + 1];
+  int4 ecur = rg.pt[p];
+  int4 enxt = rg.pt[min(p + 1, pend - 1)];
+  // instance indices of a pass for this lane's two roles (clamped: idle lanes repeat a valid instance)
+  auto inst_of = [&](const int4& en, int slot) { return min(en.x + min(slot, max((en.y & 7) - 1, 0)), last_inst); };
+  int code_i, pk, mb, code_s;
   {
-    const int il = rg.gr_row[row1 - 1];
-    const int acc_n = rg.gr_acc[row1 - 1] + 9 * (inc.off[il + 1] - inc.off[il]);
-    for (int t = lane; t < acc_n; t += 64) acc[t] = 0.0;
+    const int ii = inst_of(ecur, k), is = inst_of(ecur, ks);
+    code_i = rg.gi_code[ii];
+    pk = rg.gi_pack[(size_t)ii * kNN + j];
+    mb = rg.gi_mb[ii];
+    code_s = rg.gi_code[is];
   }
-  __syncthreads();
-  for (int r = row0; r < row1; r++) {  // M/h on the xyz-diagonal of every block (SyncedNewton.cu:214-259)
-    const int i = rg.gr_row[r], a0 = rg.gr_acc[r], off0 = inc.off[i], deg = inc.off[i + 1] - off0, row = 3 * deg;
-    for (int k = lane; k < deg; k += 64) {
-      const double mh = mval[off0 + k] * inv_h;
-      acc[a0 + 3 * k] = mh;
-      acc[a0 + row + 3 * k + 1] = mh;
-      acc[a0 + 2 * row + 3 * k + 2] = mh;
-    }
-  }
-  __syncthreads();
-  if (fixed_slot && lane < 3)  // h^2 rho J^T J: one 1.0 per pinned DOF (SyncedNewton.cu:292-341)
-    for (int r = row0; r < row1; r++) {
-      const int i = rg.gr_row[r];
-      if (fixed_slot[i] >= 0) {
-        const int deg = inc.off[i + 1] - inc.off[i];
-        acc[rg.gr_acc[r] + lane * 3 * deg + 3 * inc.diagpos[i] + lane] += (nw ? nw[i] : 1.0) * penalty;
-      }
-    }
+  int4 ri = make_int4(0, 0, 0, 0);  // this lane's row of the current group (lane < rows)
+  double pen = 0.0;                 // its h^2 rho (x 1/multiplicity) if the row is pinned
 
-  const int k = lane / kNN, j = lane - kNN * k;  // lanes 60..63: k == 6, idle
-  const int E = m.E;
 #pragma unroll 1
-  for (int p0 = inst0; p0 < inst1; p0 += kAdInst) {
-    __syncthreads();  // the previous pass has consumed its records (and orders the accumulator set-up)
-    {                 // ---- stage the 30 (instance, point) records: lanes 0..29 the kinematic half, 32..61 the material half
-      const int t = lane & 31;
-      if (t < kAdInst * kNQ) {
-        const int ks = t / kNQ, q = t - kNQ * ks;
-        const int code = rg.gi_code[min(p0 + ks, inst1 - 1)];
-        const int e = code / kNN, il = code - kNN * e;
-        const double* Fp = Fq + ((size_t)q * E + e) * 9;
-        double F[9];
-#pragma unroll
-        for (int c = 0; c < 9; c++) F[c] = Fp[c];
-        double* R = rec + (ks * kNQ + q) * kAdRec;
-        if (lane < 32) {
-          const double* gN = m.gradN + ((size_t)e * kNQ + q) * (3 * kNN);
-          const double h0 = gN[il], h1 = gN[kNN + il], h2 = gN[2 * kNN + il];
-          double2* R2 = reinterpret_cast<double2*>(R);
-          R2[0] = make_double2(h0, h1);
-          R2[1] = make_double2(h2, F[0] * h0 + F[1] * h1 + F[2] * h2);
-          R2[2] = make_double2(F[3] * h0 + F[4] * h1 + F[5] * h2, F[6] * h0 + F[7] * h1 + F[8] * h2);
-          R2[3] = make_double2(F[0], F[1]);
-          R2[4] = make_double2(F[2], F[3]);
-          R2[5] = make_double2(F[4], F[5]);
-          R2[6] = make_double2(F[6], F[7]);
-          R2[7] = make_double2(F[8], 0.0);
-        } else {
-          const double T00 = F[0] * F[0] + F[1] * F[1] + F[2] * F[2], T01 = F[0] * F[3] + F[1] * F[4] + F[2] * F[5],
-                       T02 = F[0] * F[6] + F[1] * F[7] + F[2] * F[8], T11 = F[3] * F[3] + F[4] * F[4] + F[5] * F[5],
-                       T12 = F[3] * F[6] + F[4] * F[7] + F[5] * F[8], T22 = F[6] * F[6] + F[7] * F[7] + F[8] * F[8];
-          const double trE = 0.5 * (T00 + T11 + T22 - 3.0);
-          const double dV = m.detJ[(size_t)e * kNQ + q] * m.qw[q];
-          // h*K (SVK.cuh:35-55) + C_vis (FEAT10DataFunc.cuh:695-762) share their rank-1 structure:
-          const double A1 = dV * (h * mat.lambda + mat.lamd);      // * Fh_i (x) Fh_j
-          const double B1 = dV * (h * mat.mu + mat.eta);           // * Fh_j (x) Fh_i  and  * (h_i.h_j) FF^T
-          const double C0 = dV * h * (mat.lambda * trE - mat.mu);  // * (h_i.h_j) I
-          const double C1 = dV * h * mat.mu;                       // * (Fh_i.Fh_j) I
-          double2* R2 = reinterpret_cast<double2*>(R + 16);
-          R2[0] = make_double2(B1 * T00, B1 * T01);
-          R2[1] = make_double2(B1 * T02, B1 * T11);
-          R2[2] = make_double2(B1 * T12, B1 * T22);
-          R2[3] = make_double2(A1, B1);
-          R2[4] = make_double2(C0, C1);
-        }
-      }
-    }
-    // ---- this lane's item: block (instance k, column node j)
-    const bool act = (k < kAdInst) && (p0 + k < inst1);
-    const int ii = act ? p0 + k : inst1 - 1;
-    const int code = rg.gi_code[ii];
-    const int e = code / kNN;
-    const int pk = rg.gi_pack[(size_t)ii * kNN + j];
+  for (; p < pend; ++p) {
+    const int4 en2 = rg.pt[min(p + 2, pend - 1)];
+    const int cnt = ecur.y & 7, nrows = ecur.y >> 8;
+    const bool first = (ecur.y & 8) != 0, last = (ecur.y & 16) != 0;
+    // ---- (1) this pass's data: one round trip -------------------------------------------------------------
+    const int e = code_i / kNN;
     const double* gN = m.gradN + (size_t)e * (kNQ * 3 * kNN) + j;
     double hj[kNQ][3];
 #pragma unroll
     for (int q = 0; q < kNQ; q++)
 #pragma unroll
       for (int d = 0; d < 3; d++) hj[q][d] = gN[q * 3 * kNN + d * kNN];
+    const bool act = k < cnt;
+    double mh = 0.0;
+    if (act && pk < 0) mh = mval[mb + (pk & 0xffff) / 3];
+    const int es = code_s / kNN, ils = code_s - kNN * es;
+    double F[9], s0 = 0.0, s1 = 0.0, s2 = 0.0;  // s*: h_i (kinematic half) | det J (material half)
+    if (stager) {
+      const double* Fp = Fq + ((size_t)qs * E + es) * 9;
+#pragma unroll
+      for (int t = 0; t < 9; t++) F[t] = Fp[t];
+      if (lane < 32) {
+        const double* gs = m.gradN + ((size_t)es * kNQ + qs) * (3 * kNN) + ils;
+        s0 = gs[0];
+        s1 = gs[kNN];
+        s2 = gs[2 * kNN];
+      } else {
+        s0 = m.detJ[(size_t)es * kNQ + qs];
+      }
+    }
+    // ---- (2) the next pass's indices ------------------------------------------------------------------------
+    int code_i_n, pk_n, mb_n, code_s_n;
+    {
+      const int ii = inst_of(enxt, k), is = inst_of(enxt, ks);
+      code_i_n = rg.gi_code[ii];
+      pk_n = rg.gi_pack[(size_t)ii * kNN + j];
+      mb_n = rg.gi_mb[ii];
+      code_s_n = rg.gi_code[is];
+    }
+    // ---- (3) first pass of a group: clear its accumulators, fetch its row records ---------------------------
+    if (first) {
+      for (int t = lane; t < ecur.w; t += 64) acc[t] = 0.0;
+      pen = 0.0;
+      if (lane < nrows) {
+        ri = rg.gr_info[ecur.z + lane];
+        if (fixed_slot && fixed_slot[ri.w] >= 0) pen = (nw ? nw[ri.w] : 1.0) * penalty;
+      }
+    }
+    __syncthreads();  // the previous pass has consumed its records; the accumulators are clear
+    // ---- (4) stage the 30 (instance, point) records ---------------------------------------------------------
+    if (stager) {
+      double* R = rec + (ks * kNQ + qs) * kAdRec;
+      if (lane < 32) {
+        double2* R2 = reinterpret_cast<double2*>(R);
+        R2[0] = make_double2(s0, s1);
+        R2[1] = make_double2(s2, F[0] * s0 + F[1] * s1 + F[2] * s2);
+        R2[2] = make_double2(F[3] * s0 + F[4] * s1 + F[5] * s2, F[6] * s0 + F[7] * s1 + F[8] * s2);
+        R2[3] = make_double2(F[0], F[1]);
+        R2[4] = make_double2(F[2], F[3]);
+        R2[5] = make_double2(F[4], F[5]);
+        R2[6] = make_double2(F[6], F[7]);
+        R2[7] = make_double2(F[8], 0.0);
+      } else {
+        const double T00 = F[0] * F[0] + F[1] * F[1] + F[2] * F[2], T01 = F[0] * F[3] + F[1] * F[4] + F[2] * F[5],
+                     T02 = F[0] * F[6] + F[1] * F[7] + F[2] * F[8], T11 = F[3] * F[3] + F[4] * F[4] + F[5] * F[5],
+                     T12 = F[3] * F[6] + F[4] * F[7] + F[5] * F[8], T22 = F[6] * F[6] + F[7] * F[7] + F[8] * F[8];
+        const double trE = 0.5 * (T00 + T11 + T22 - 3.0);
+        const double dV = s0 * m.qw[qs];
+        // h*K (SVK.cuh:35-55) + C_vis (FEAT10DataFunc.cuh:695-762) share their rank-1 structure:
+        const double A1 = dV * (h * mat.lambda + mat.lamd);      // * Fh_i (x) Fh_j
+        const double B1 = dV * (h * mat.mu + mat.eta);           // * Fh_j (x) Fh_i  and  * (h_i.h_j) FF^T
+        const double C0 = dV * h * (mat.lambda * trE - mat.mu);  // * (h_i.h_j) I
+        const double C1 = dV * h * mat.mu;                       // * (Fh_i.Fh_j) I
+        double2* R2 = reinterpret_cast<double2*>(R + 16);
+        R2[0] = make_double2(B1 * T00, B1 * T01);
+        R2[1] = make_double2(B1 * T02, B1 * T11);
+        R2[2] = make_double2(B1 * T12, B1 * T22);
+        R2[3] = make_double2(A1, B1);
+        R2[4] = make_double2(C0, C1);
+      }
+    }
     __syncthreads();
-    double a00 = 0, a01 = 0, a02 = 0, a10 = 0, a11 = 0, a12 = 0, a20 = 0, a21 = 0, a22 = 0, cds = 0;
+    // ---- (5) this lane's block: sum over the 5 points, add into the row accumulator --------------------------
+    double a00 = 0, a01 = 0, a02 = 0, a10 = 0, a11 = 0, a12 = 0, a20 = 0, a21 = 0, a22 = 0;
+    double cds = mh * inv_h;  // M/h on the xyz-diagonal (SyncedNewton.cu:214-259), carried by the block's first item
     const double2* Rk = reinterpret_cast<const double2*>(rec + (size_t)min(k, kAdInst - 1) * kNQ * kAdRec);
 #pragma unroll
     for (int q = 0; q < kNQ; q++) {
@@ -1092,7 +1116,7 @@ __global__ __launch_bounds__(64) void assemble_direct_kernel(ElemView m, Materia
     }
     if (act) {
       double* ap = acc + (pk & 0xffff);
-      const int st = pk >> 16;
+      const int st = (pk >> 16) & 0x7fff;
 #define TLFEA_LDS_ADD(p, v) (void)__hip_atomic_fetch_add((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
       TLFEA_LDS_ADD(ap + 0, a00 + cds);
       TLFEA_LDS_ADD(ap + 1, a01);
@@ -1105,27 +1129,42 @@ __global__ __launch_bounds__(64) void assemble_direct_kernel(ElemView m, Materia
       TLFEA_LDS_ADD(ap + 2 * st + 2, a22 + cds);
 #undef TLFEA_LDS_ADD
     }
-  }
-  __syncthreads();
-  for (int r = row0; r < row1; r++) {  // every row streams out once (no memset of H, no atomics on HBM)
-    const int i = rg.gr_row[r], a0 = rg.gr_acc[r], off0 = inc.off[i], n9 = 9 * (inc.off[i + 1] - off0);
-    double* out = Hval + (size_t)9 * off0;
-    for (int t = lane; t < n9; t += 64) out[t] = acc[a0 + t];
+    // ---- (6) last pass of a group: h^2 rho J^T J on pinned rows (SyncedNewton.cu:292-341), rows stream out once ----
+    if (last) {
+      __syncthreads();
+      if (lane < nrows && pen != 0.0) {
+        const int a0 = ri.x & 0xffff, dpos = ri.x >> 16, row = 3 * ri.z;
+#pragma unroll
+        for (int d = 0; d < 3; d++) acc[a0 + d * row + 3 * dpos + d] += pen;
+      }
+      __syncthreads();
+      for (int r = 0; r < nrows; r++) {
+        const int a0 = __shfl(ri.x, r) & 0xffff, off0 = __shfl(ri.y, r), n9 = 9 * __shfl(ri.z, r);
+        double* out = Hval + (size_t)9 * off0;
+        for (int t = lane; t < n9; t += 64) out[t] = acc[a0 + t];
+      }
+    }
+    ecur = enxt;
+    enxt = en2;
+    code_i = code_i_n;
+    pk = pk_n;
+    mb = mb_n;
+    code_s = code_s_n;
   }
 }
 
 void launch_assemble_direct(hipStream_t s, const ElemView& m, const Material& mat, double h, const RowGroups& rg,
-                            const Incidence& inc, const double* Fq, const double* mval, const int* fixed_slot,
-                            const double* nw, double penalty, double* Hval) {
+                            const double* Fq, const double* mval, const int* fixed_slot, const double* nw,
+                            double penalty, double* Hval) {
   const size_t lds = (size_t)(kAdRecTotal + rg.acc_max) * sizeof(double);
   static size_t lds_attr = 0;
   if (lds > 64 * 1024 && lds > lds_attr) {
     (void)hipFuncSetAttribute((const void*)assemble_direct_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     lds_attr = lds;
   }
-  const int nb = ((rg.G + 7) / 8) * 8;
-  hipLaunchKernelGGL(assemble_direct_kernel, dim3(nb), dim3(64), lds, s, m, mat, h, rg, inc, Fq, mval, 1.0 / h,
-                     fixed_slot, nw, penalty, Hval);
+  const int nb = ((rg.C + 7) / 8) * 8;
+  hipLaunchKernelGGL(assemble_direct_kernel, dim3(nb), dim3(64), lds, s, m, mat, h, rg, Fq, mval, 1.0 / h, fixed_slot, nw,
+                     penalty, Hval);
 }
 
 // ------------------------------------------------------------------------------------------------

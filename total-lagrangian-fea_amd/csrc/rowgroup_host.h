@@ -19,8 +19,16 @@ namespace tlfea {
 
 struct RowGroupsHost {
   std::vector<int> g_inst_off, g_row_off, gr_row, gr_acc, gi_code, gi_pack;
+  // what the kernel reads: a flat table of PASSES (<= 6 instances of one group each), cut into chunks of consecutive
+  // groups (one wavefront per chunk), per-row records, and per instance the base of its row's mass values
+  std::vector<int> pt;         // [P][4]: first instance | count + 8 first-of-group + 16 last-of-group + (rows << 8) |
+                               //         first row | doubles of accumulator the group uses
+  std::vector<int> chunk_off;  // [C+1] passes of chunk c
+  std::vector<int> gr_info;    // [N][4]: acc offset + (position of the diagonal block << 16) | off[row] | deg | node
+  std::vector<int> gi_mb;      // [S*E]: off[row] - acc offset / 3 (mass value of a block = mval[gi_mb + acc offset / 3])
   int acc_max = 0;
   int G() const { return (int)g_inst_off.size() - 1; }
+  int C() const { return (int)chunk_off.size() - 1; }
 };
 
 inline uint64_t morton_spread21(uint64_t v) {  // 21 bits -> every third bit
@@ -37,7 +45,7 @@ inline uint64_t morton_spread21(uint64_t v) {  // 21 bits -> every third bit
 // (e*S + local, ascending e per node), x/y/z: reference coordinates of the N rows.
 inline bool build_row_groups(int N, int E, int S, const int* conn, const int* off, const int* cols, const int* n2e_off,
                              const int* n2e, const double* x, const double* y, const double* z, RowGroupsHost& out) {
-  constexpr int kInstBudget = 24, kAccBudget = 1024, kBigRow = 13;
+  constexpr int kInstBudget = 24, kAccBudget = 1024, kBigRow = 13, kMaxRows = 16, kPassInst = 6, kChunkPasses = 32;
   if (N <= 0 || E <= 0) return false;
   double lo[3] = {x[0], y[0], z[0]}, hi[3] = {x[0], y[0], z[0]};
   for (int i = 1; i < N; i++) {
@@ -85,7 +93,8 @@ inline bool build_row_groups(int N, int E, int S, const int* conn, const int* of
       emit(&i, 1);
       continue;
     }
-    if (!open_rows.empty() && (open_inst + ni > kInstBudget || open_acc + ai > kAccBudget)) {
+    if (!open_rows.empty() &&
+        (open_inst + ni > kInstBudget || open_acc + ai > kAccBudget || (int)open_rows.size() >= kMaxRows)) {
       emit(open_rows.data(), (int)open_rows.size());
       open_rows.clear();
       open_inst = open_acc = 0;
@@ -98,22 +107,58 @@ inline bool build_row_groups(int N, int E, int S, const int* conn, const int* of
   if (out.acc_max >= 65536) return false;
 
   const int G = out.G();
-  out.gi_code.resize((size_t)n_inst);
-  out.gi_pack.resize((size_t)n_inst * S);
+  out.gi_code.resize((size_t)std::max(1, n_inst));
+  out.gi_mb.resize((size_t)std::max(1, n_inst));
+  out.gi_pack.resize((size_t)std::max(1, n_inst) * S);
+  out.gr_info.resize((size_t)N * 4);
 #pragma omp parallel for schedule(dynamic, 256)
   for (int g = 0; g < G; g++) {
     size_t w = (size_t)out.g_inst_off[g];
+    std::vector<char> seen;
     for (int r = out.g_row_off[g]; r < out.g_row_off[g + 1]; r++) {
       const int i = out.gr_row[r], a0 = out.gr_acc[r], deg = off[i + 1] - off[i];
       const int* c = cols + off[i];
+      const int dpos = (int)(std::lower_bound(c, c + deg, i) - c);
+      out.gr_info[4 * (size_t)r + 0] = a0 | (dpos << 16);
+      out.gr_info[4 * (size_t)r + 1] = off[i];
+      out.gr_info[4 * (size_t)r + 2] = deg;
+      out.gr_info[4 * (size_t)r + 3] = i;
+      seen.assign((size_t)deg, 0);
       for (int k = n2e_off[i]; k < n2e_off[i + 1]; k++, w++) {
         const int code = n2e[k], e = code / S;
         out.gi_code[w] = code;
+        out.gi_mb[w] = off[i] - a0 / 3;
         for (int j = 0; j < S; j++) {
           const int pos = (int)(std::lower_bound(c, c + deg, conn[(size_t)j * E + e]) - c);
-          out.gi_pack[w * S + j] = (a0 + 3 * pos) | ((3 * deg) << 16);
+          // bit 31: this item is the first (lowest element) contribution to its block and carries the block's M/h
+          const unsigned first = seen[pos] ? 0u : 0x80000000u;
+          seen[pos] = 1;
+          out.gi_pack[w * S + j] = (int)((unsigned)(a0 + 3 * pos) | ((unsigned)(3 * deg) << 16) | first);
         }
       }
+    }
+  }
+  // pass table and chunks (serial: a few integers per pass)
+  out.chunk_off.push_back(0);
+  int chunk_passes = 0;
+  for (int g = 0; g < G; g++) {
+    const int i0 = out.g_inst_off[g], i1 = out.g_inst_off[g + 1], r0 = out.g_row_off[g], nr = out.g_row_off[g + 1] - r0;
+    const int last_row = out.gr_row[r0 + nr - 1];
+    const int acc_n = out.gr_acc[r0 + nr - 1] + 9 * (off[last_row + 1] - off[last_row]);
+    int p0 = i0;
+    do {  // a group without instances (nodes that belong to no element) still has one pass: its rows are written
+      const int cnt = std::min(kPassInst, i1 - p0);
+      const int flags = (p0 == i0 ? 8 : 0) | (p0 + kPassInst >= i1 ? 16 : 0);
+      out.pt.push_back(p0);
+      out.pt.push_back(cnt | flags | (nr << 8));
+      out.pt.push_back(r0);
+      out.pt.push_back(acc_n);
+      chunk_passes++;
+      p0 += kPassInst;
+    } while (p0 < i1);
+    if (chunk_passes >= kChunkPasses || g == G - 1) {
+      out.chunk_off.push_back((int)(out.pt.size() / 4));
+      chunk_passes = 0;
     }
   }
   return true;

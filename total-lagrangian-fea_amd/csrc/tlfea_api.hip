@@ -938,7 +938,7 @@ struct tlfea_newton_s {
   double *d_H = nullptr, *d_Kbuf = nullptr, *d_Dinv = nullptr;
   // fused tangent + assembly (T10, SVK): row groups (rowgroup_host.h) and the per-point F of the last residual launch.
   // asm_mode (TLFEA_ASSEMBLE=kbuf|direct): 0 auto = fused where it applies, 1 always the two-kernel path via Kbuf
-  RowGroups rg{0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  RowGroups rg{0, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   int* d_rg[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   bool rg_ok = false;
   bool fq_in_residual = true;  // first-order solvers (AdamW, Nesterov, VBD) never assemble: their residual skips Fq
@@ -1126,12 +1126,13 @@ extern "C" int tlfea_newton_analyze_hessian_sparsity(tlfea_newton_t s) {
     RowGroupsHost rh;
     if (build_row_groups(N, d->E, d->S, d->h_conn.data(), d->h_off.data(), d->h_cols.data(), d->h_n2e_off.data(),
                          d->h_n2e.data(), d->h_X0.data(), d->h_X0.data() + N, d->h_X0.data() + 2 * (size_t)N, rh)) {
-      const std::vector<int>* src[6] = {&rh.g_inst_off, &rh.g_row_off, &rh.gr_row, &rh.gr_acc, &rh.gi_code, &rh.gi_pack};
+      const std::vector<int>* src[6] = {&rh.chunk_off, &rh.pt, &rh.gr_info, &rh.gi_code, &rh.gi_mb, &rh.gi_pack};
       for (int k = 0; k < 6; k++) {
-        TRY(dmalloc(&s->d_rg[k], src[k]->size()));
+        TRY(dmalloc(&s->d_rg[k], src[k]->size() + 4));
         HIP_TRY(hipMemcpy(s->d_rg[k], src[k]->data(), src[k]->size() * sizeof(int), hipMemcpyHostToDevice));
       }
-      s->rg = RowGroups{rh.G(), rh.acc_max, s->d_rg[0], s->d_rg[1], s->d_rg[2], s->d_rg[3], s->d_rg[4], s->d_rg[5]};
+      s->rg = RowGroups{rh.C(), d->E * d->S, rh.acc_max, s->d_rg[0], reinterpret_cast<const int4*>(s->d_rg[1]),
+                        reinterpret_cast<const int4*>(s->d_rg[2]), s->d_rg[3], s->d_rg[4], s->d_rg[5]};
       TRY(dmalloc(&s->d_Fq, (size_t)d->E * d->Q * 9));
       s->rg_ok = true;
     }
@@ -1470,7 +1471,7 @@ static int assemble(tlfea_newton_t s, bool fq_fresh = true) {
     StageTimer t(s, 3);
     if (!fq_fresh)
       launch_residual(s->stream, d->view(), d->mat, s->d_v, d->d_fbuf, nullptr, nullptr, nullptr, nullptr, s->d_Fq);
-    launch_assemble_direct(s->stream, d->view(), d->mat, p.time_step, s->rg, d->inc(), s->d_Fq, d->d_mval,
+    launch_assemble_direct(s->stream, d->view(), d->mat, p.time_step, s->rg, s->d_Fq, d->d_mval,
                            pinned ? d->d_fixed_slot : nullptr, s->d_nw, p.time_step * p.time_step * p.rho, s->d_H);
     if (lincons_on(s))  // + h^2 rho J^T J  (SyncedNewton.cu:292-341)
       launch_lin_constraint_hessian(s->stream, 3 * s->N, d->d_jtoff, d->d_jtcol, d->d_jtval, d->d_joff, d->d_jcol,
@@ -2378,7 +2379,7 @@ extern "C" int tlfea_newton_time_kernels(tlfea_newton_t s, int reps, double* out
         TRY(ensure_kbuf(s));
         launch_tangent_blocks(s->stream, d->view(), d->mat, p.time_step, s->d_Kbuf);
       } else if (k == 2 && use_direct(s))  // out[2] = the fused tangent + assembly launch
-        launch_assemble_direct(s->stream, d->view(), d->mat, p.time_step, s->rg, d->inc(), s->d_Fq, d->d_mval,
+        launch_assemble_direct(s->stream, d->view(), d->mat, p.time_step, s->rg, s->d_Fq, d->d_mval,
                                pinned_on(s) ? d->d_fixed_slot : nullptr, s->d_nw,
                                p.time_step * p.time_step * p.rho, s->d_H);
       else if (k == 2)

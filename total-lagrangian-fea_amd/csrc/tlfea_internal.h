@@ -53,18 +53,22 @@ struct Incidence {
   const int* diagpos;   // [N]     position of i in row i
 };
 
-// Row groups of the fused tangent + assembly kernel (T10, SVK): a wavefront owns a few node rows of H (3 CSR rows
-// each) and works through their (row, incident element) instances, 6 at a time.  Built once per mesh on the host
-// (rowgroup_host.h): rows in Morton order of the reference coordinates, so that consecutive groups share elements.
+// Work lists of the fused tangent + assembly kernel (T10, SVK): a wavefront owns a CHUNK of consecutive row groups; a
+// group is a few node rows of H (3 CSR rows each) whose (row, incident element) instances are worked through in PASSES
+// of up to 6.  Built once per mesh on the host (rowgroup_host.h): rows in Morton order of the reference coordinates, so
+// that consecutive groups share elements.
 struct RowGroups {
-  int G;                  // number of groups
+  int C;                  // chunks (one wavefront each)
+  int n_inst;             // S*E instances
   int acc_max;            // doubles of LDS accumulator the largest group needs
-  const int* g_inst_off;  // [G+1] instances of group g: g_inst_off[g] .. g_inst_off[g+1]
-  const int* g_row_off;   // [G+1] rows of group g (indices into gr_row / gr_acc)
-  const int* gr_row;      // [N]   node id of each group row
-  const int* gr_acc;      // [N]   offset (doubles) of the row's 9*deg accumulator inside the group's LDS block
+  const int* chunk_off;   // [C+1] passes of chunk c
+  const int4* pt;         // [P] pass: first instance | count + 8 first + 16 last of group + (rows << 8) | first row |
+                          //          accumulator doubles of the group
+  const int4* gr_info;    // [N] row: acc offset + (diagonal block position << 16) | off[row] | deg | node
   const int* gi_code;     // [S*E] element * S + local node, group order (ascending element inside a row)
-  const int* gi_pack;     // [S*E][S] per (instance, column node j): (gr_acc + 3*pos_j) | (3*deg << 16)
+  const int* gi_mb;       // [S*E] off[row] - acc offset / 3: mass value of an item's block = mval[gi_mb + acc / 3]
+  const int* gi_pack;     // [S*E][S] per (instance, column node j): (acc offset of the block) | (3 deg << 16) |
+                          //          bit 31: first contribution to the block (carries its M/h)
 };
 
 // ---- launch wrappers (defined in the .hip files) -------------------------------------------
@@ -76,8 +80,8 @@ void launch_residual(hipStream_t s, const ElemView& m, const Material& mat, cons
                      double* Fq = nullptr /*[Q][E][9] row-major F per point, for the fused assembly*/);
 // fused tangent + row assembly (T10, SVK): H rows straight from grad N and the F of the last residual launch
 void launch_assemble_direct(hipStream_t s, const ElemView& m, const Material& mat, double h, const RowGroups& rg,
-                            const Incidence& inc, const double* Fq, const double* mval, const int* fixed_slot,
-                            const double* nw, double penalty, double* Hval);
+                            const double* Fq, const double* mval, const int* fixed_slot, const double* nw,
+                            double penalty, double* Hval);
 void launch_tangent_blocks(hipStream_t s, const ElemView& m, const Material& mat, double h,
                            double* Kbuf /*[E][55][9]*/);
 void launch_assemble_rows(hipStream_t s, int N, int S, int maxdeg, const Incidence& inc, const double* Kbuf,
