@@ -11,12 +11,12 @@ extern "C" int rg_build(int N, int E, int S, const int* conn, const int* off, co
   sizes[1] = (int)g_rg.gi_code.size();
   sizes[2] = g_rg.acc_max;
   sizes[3] = (int)(g_rg.pt.size() / 4);
-  sizes[4] = g_rg.C();
+  sizes[4] = g_rg.G();
   return 0;
 }
-extern "C" void rg_fetch_passes(int* pt, int* chunk_off, int* gr_info, int* gi_mb) {
+extern "C" void rg_fetch_passes(int* pt, int* g_pass_off, int* gr_info, int* gi_mb) {
   std::copy(g_rg.pt.begin(), g_rg.pt.end(), pt);
-  std::copy(g_rg.chunk_off.begin(), g_rg.chunk_off.end(), chunk_off);
+  std::copy(g_rg.g_pass_off.begin(), g_rg.g_pass_off.end(), g_pass_off);
   std::copy(g_rg.gr_info.begin(), g_rg.gr_info.end(), gr_info);
   std::copy(g_rg.gi_mb.begin(), g_rg.gi_mb.end(), gi_mb);
 }

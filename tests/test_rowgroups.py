@@ -1,7 +1,7 @@
 """Host set-up of the fused tangent + assembly kernel (csrc/rowgroup_host.h): every row owned once, every (row, element)
 instance listed once in ascending element order, packed accumulator offsets consistent with the sorted column lists,
 accumulators of one group disjoint and within the 16-bit packing; every block's mass carried by exactly one item; the
-pass table walks every instance once, group by group; chunks cut it at group boundaries.  Integer work only -- runs
+pass table walks every instance once, group by group.  Integer work only -- runs
 without a GPU."""
 import ctypes as C
 import os
@@ -60,7 +60,8 @@ def test_row_groups_invariants(shim, mesh):
     x, y, z = (np.ascontiguousarray(X[:, k]) for k in range(3))
     sizes = np.zeros(5, dtype=np.int32)
     assert shim.rg_build(N, E, S, ip(conn_cm), ip(off), ip(cols), ip(n2e_off), ip(n2e), dp(x), dp(y), dp(z), ip(sizes)) == 0
-    G, n_inst, acc_max, P, nchunks = map(int, sizes)
+    G, n_inst, acc_max, P, G2 = map(int, sizes)
+    assert G2 == G
     assert n_inst == E * S
     g_inst_off, g_row_off = np.zeros(G + 1, np.int32), np.zeros(G + 1, np.int32)
     gr_row, gr_acc = np.zeros(N, np.int32), np.zeros(N, np.int32)
@@ -71,9 +72,9 @@ def test_row_groups_invariants(shim, mesh):
     assert np.array_equal(np.sort(gi_code), np.arange(E * S))    # every (element, local node) listed once
     deg = np.diff(off)
     gi_pack = gi_pack.reshape(n_inst, S)
-    pt, chunk_off = np.zeros(4 * P, np.int32), np.zeros(nchunks + 1, np.int32)
+    pt, g_pass_off = np.zeros(4 * P, np.int32), np.zeros(G + 1, np.int32)
     gr_info, gi_mb = np.zeros(4 * N, np.int32), np.zeros(n_inst, np.int32)
-    shim.rg_fetch_passes(ip(pt), ip(chunk_off), ip(gr_info), ip(gi_mb))
+    shim.rg_fetch_passes(ip(pt), ip(g_pass_off), ip(gr_info), ip(gi_mb))
     pt, gr_info = pt.reshape(P, 4), gr_info.reshape(N, 4)
     mass_flag = gi_pack < 0                                      # bit 31: the item carries its block's M/h
     gi_pack = gi_pack & 0x7FFFFFFF
@@ -110,6 +111,7 @@ def test_row_groups_invariants(shim, mesh):
             c = cols[off[i]:off[i + 1]]
             assert gr_info[r0 + t].tolist() == [a0 | (int(np.searchsorted(c, i)) << 16), off[i], deg[i], i]
         i0, i1 = g_inst_off[g], g_inst_off[g + 1]
+        assert g_pass_off[g] == pi
         p0 = i0
         while True:
             inst0, meta, row0, acc_n = pt[pi]
@@ -123,8 +125,7 @@ def test_row_groups_invariants(shim, mesh):
                 break
     assert pi == P
     assert np.all(carried == 1)                                  # every block's M/h enters H exactly once
-    assert chunk_off[0] == 0 and chunk_off[-1] == P and np.all(np.diff(chunk_off) > 0)
-    assert np.all(pt[chunk_off[:-1], 1] & 8) and np.all(pt[chunk_off[1:] - 1, 1] & 16)   # chunks hold whole groups
+    assert g_pass_off[0] == 0 and g_pass_off[-1] == P and np.all(np.diff(g_pass_off) > 0)
     # locality: consecutive groups are spatial neighbours (Morton order) -- the median distance between the first rows of
     # consecutive groups is a few element sizes, far below the body's extent
     first = X[gr_row[g_row_off[:-1]]]

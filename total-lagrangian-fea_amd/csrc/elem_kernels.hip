@@ -965,29 +965,69 @@ constexpr int kAdRec = 26;                            // doubles per staged reco
 constexpr int kAdRecTotal = kAdInst * kNQ * kAdRec;   // 780 doubles = 6.1 KiB
 }  // namespace
 
-__global__ __launch_bounds__(64, 2) void assemble_direct_kernel(ElemView m, Material mat, double h, RowGroups rg,
+// H row store that does not stay in the XCD's L2 (sc1: written through and dropped, MI355X_MICROARCH.md "stores of each
+// flavour"): the 2.7 GB of H would otherwise evict the grad N lines the neighbouring rows are about to re-read
+__device__ __forceinline__ void store_through(double* p, double v, int mode) {
+  if (mode == 2)
+    asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+  else if (mode == 1)
+    __builtin_nontemporal_store(v, p);
+  else
+    *p = v;
+}
+
+template <bool ROLLED>
+__global__ __launch_bounds__(64, ROLLED ? 3 : 2) void assemble_direct_kernel(ElemView m, Material mat, double h, RowGroups rg,
                                                                const double* __restrict__ Fq,
                                                                const double* __restrict__ mval, double inv_h,
                                                                const int* __restrict__ fixed_slot,
                                                                const double* __restrict__ nw, double penalty,
-                                                               double* __restrict__ Hval) {
+                                                               double* __restrict__ Hval, int store_mode) {
   extern __shared__ __attribute__((aligned(16))) double lds_ad[];
   double* rec = lds_ad;                // [kAdInst][kNQ][kAdRec]
   double* acc = lds_ad + kAdRecTotal;  // the group's rows, each in H's layout [d][3 deg]
-  // blocks b, b + 8, ... share an XCD (round-robin dispatch): XCD x works through chunks [x per, (x+1) per)
-  const int per = gridDim.x >> 3;
-  const int c = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
-  if (c >= rg.C) return;
+  // Blocks b, b + 8, ... share an XCD (round-robin dispatch).  XCD x owns groups [x Gper, (x+1) Gper) and its W resident
+  // waves walk that range side by side: wave w takes groups w, w + W, w + 2W, ... -- at any time the XCD works on a
+  // window of ~W consecutive groups, i.e. spatial neighbours whose elements overlap, so that the re-reads of an
+  // element by the owners of its other rows hit the XCD's 4 MiB L2.
+  const int W = gridDim.x >> 3;
+  const int Gper = (rg.G + 7) >> 3;
+  const int gbeg = (blockIdx.x & 7) * Gper, gend = min(rg.G, gbeg + Gper);
+  if (gbeg + (int)(blockIdx.x >> 3) >= gend) return;
   const int lane = threadIdx.x;
   const int k = lane / kNN, j = lane - kNN * k;  // item (instance k, column node j); lanes 60..63: k == 6, idle
   const int ts = lane & 31;                      // staging: record ts of 30, lanes 0..29 kinematic half, 32..61 material half
   const bool stager = ts < kAdInst * kNQ;
   const int ks = stager ? ts / kNQ : 0, qs = stager ? ts - kNQ * (ts / kNQ) : 0;
   const int E = m.E, last_inst = rg.n_inst - 1;
-  int p = rg.chunk_off[c];
-  const int pend = rg.chunk_off[c + 1];
-  int4 ecur = rg.pt[p];
-  int4 enxt = rg.pt[min(p + 1, pend - 1)];
+  // lead cursor: runs two passes ahead of the pass being computed (all scalar state)
+  int lg = gbeg + (blockIdx.x >> 3);                     // its group
+  int lp = rg.g_pass_off[lg], lpe = rg.g_pass_off[lg + 1];  // its pass, end of its group's passes
+  int np = 0, npe = 0;                                   // pass range of the wave's NEXT group (fetched one group ahead)
+  if (lg + W < gend) {
+    np = rg.g_pass_off[lg + W];
+    npe = rg.g_pass_off[lg + W + 1];
+  }
+  bool lvalid = true;
+  auto advance = [&]() {
+    if (lp + 1 < lpe) {
+      lp++;
+      return;
+    }
+    lg += W;
+    lvalid = lg < gend;
+    lp = np;
+    lpe = npe;
+    if (lg + W < gend) {
+      np = rg.g_pass_off[lg + W];
+      npe = rg.g_pass_off[lg + W + 1];
+    }
+  };
+  int4 ecur = rg.pt[lp];
+  advance();
+  bool vnxt = lvalid;
+  int4 enxt = rg.pt[vnxt ? lp : 0];
+  advance();
   // instance indices of a pass for this lane's two roles (clamped: idle lanes repeat a valid instance)
   auto inst_of = [&](const int4& en, int slot) { return min(en.x + min(slot, max((en.y & 7) - 1, 0)), last_inst); };
   int code_i, pk, mb, code_s;
@@ -1001,9 +1041,12 @@ __global__ __launch_bounds__(64, 2) void assemble_direct_kernel(ElemView m, Mate
   int4 ri = make_int4(0, 0, 0, 0);  // this lane's row of the current group (lane < rows)
   double pen = 0.0;                 // its h^2 rho (x 1/multiplicity) if the row is pinned
 
+  bool vcur = true;
 #pragma unroll 1
-  for (; p < pend; ++p) {
-    const int4 en2 = rg.pt[min(p + 2, pend - 1)];
+  while (vcur) {
+    const bool vn2 = lvalid;
+    const int4 en2 = rg.pt[vn2 ? lp : 0];
+    advance();
     const int cnt = ecur.y & 7, nrows = ecur.y >> 8;
     const bool first = (ecur.y & 8) != 0, last = (ecur.y & 16) != 0;
     // ---- (1) this pass's data: one round trip -------------------------------------------------------------
@@ -1088,7 +1131,9 @@ __global__ __launch_bounds__(64, 2) void assemble_direct_kernel(ElemView m, Mate
     double a00 = 0, a01 = 0, a02 = 0, a10 = 0, a11 = 0, a12 = 0, a20 = 0, a21 = 0, a22 = 0;
     double cds = mh * inv_h;  // M/h on the xyz-diagonal (SyncedNewton.cu:214-259), carried by the block's first item
     const double2* Rk = reinterpret_cast<const double2*>(rec + (size_t)min(k, kAdInst - 1) * kNQ * kAdRec);
-#pragma unroll
+    // ROLLED: one point per trip, h_j[q] read through the register index (166 VGPRs, 3 waves per SIMD); unrolled the
+    // scheduler overlaps the points' LDS reads with arithmetic at 230 VGPRs, 2 waves per SIMD
+#pragma unroll(ROLLED ? 1 : kNQ)
     for (int q = 0; q < kNQ; q++) {
       const double2* R2 = Rk + q * (kAdRec / 2);
       const double2 r0 = R2[0], r1 = R2[1], r2 = R2[2], r3 = R2[3], r4 = R2[4], r5 = R2[5], r6 = R2[6], r7 = R2[7],
@@ -1141,11 +1186,13 @@ __global__ __launch_bounds__(64, 2) void assemble_direct_kernel(ElemView m, Mate
       for (int r = 0; r < nrows; r++) {
         const int a0 = __shfl(ri.x, r) & 0xffff, off0 = __shfl(ri.y, r), n9 = 9 * __shfl(ri.z, r);
         double* out = Hval + (size_t)9 * off0;
-        for (int t = lane; t < n9; t += 64) out[t] = acc[a0 + t];
+        for (int t = lane; t < n9; t += 64) store_through(out + t, acc[a0 + t], store_mode);
       }
     }
     ecur = enxt;
     enxt = en2;
+    vcur = vnxt;
+    vnxt = vn2;
     code_i = code_i_n;
     pk = pk_n;
     mb = mb_n;
@@ -1159,12 +1206,46 @@ void launch_assemble_direct(hipStream_t s, const ElemView& m, const Material& ma
   const size_t lds = (size_t)(kAdRecTotal + rg.acc_max) * sizeof(double);
   static size_t lds_attr = 0;
   if (lds > 64 * 1024 && lds > lds_attr) {
-    (void)hipFuncSetAttribute((const void*)assemble_direct_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)assemble_direct_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)assemble_direct_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     lds_attr = lds;
   }
-  const int nb = ((rg.C + 7) / 8) * 8;
-  hipLaunchKernelGGL(assemble_direct_kernel, dim3(nb), dim3(64), lds, s, m, mat, h, rg, Fq, mval, 1.0 / h, fixed_slot, nw,
-                     penalty, Hval);
+  // persistent grid: as many single-wave workgroups as the chip holds at once (8 XCDs x 32 CUs x resident waves per CU),
+  // never more than there are groups; a wave that starts late (fewer resident than assumed) still does its share
+  static int n_cu = 0;
+  static size_t occ_lds = ~(size_t)0;
+  static int occ = 8;
+  if (!n_cu) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+    if (n_cu <= 0) n_cu = 256;
+  }
+  if (occ_lds != lds) {
+    int o = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, (const void*)assemble_direct_kernel<true>, 64, lds) == hipSuccess && o > 0)
+      occ = o;
+    occ_lds = lds;
+  }
+  // experiment switches: TLFEA_AD_ROLLED=0|1 kernel form, TLFEA_AD_WAVES resident waves per CU assumed
+  // by the persistent grid; TLFEA_AD_TUNE=1 re-reads both at every launch (tools/tune_assemble.py)
+  static const bool tune = std::getenv("TLFEA_AD_TUNE") != nullptr;
+  static int rolled = std::getenv("TLFEA_AD_ROLLED") ? std::atoi(std::getenv("TLFEA_AD_ROLLED")) : 1;
+  static int occ_env = std::getenv("TLFEA_AD_WAVES") ? std::atoi(std::getenv("TLFEA_AD_WAVES")) : 0;
+  static int store_mode = std::getenv("TLFEA_AD_STORE") ? std::atoi(std::getenv("TLFEA_AD_STORE")) : 0;
+  if (tune) {
+    store_mode = std::getenv("TLFEA_AD_STORE") ? std::atoi(std::getenv("TLFEA_AD_STORE")) : 0;
+    rolled = std::getenv("TLFEA_AD_ROLLED") ? std::atoi(std::getenv("TLFEA_AD_ROLLED")) : 1;
+    occ_env = std::getenv("TLFEA_AD_WAVES") ? std::atoi(std::getenv("TLFEA_AD_WAVES")) : 0;
+  }
+  const int occ_eff = occ_env > 0 ? occ_env : std::min(occ, rolled ? 12 : 8);
+  const int per_xcd = std::max(1, std::min((n_cu / 8) * occ_eff, (rg.G + 7) / 8));
+  if (rolled)
+    hipLaunchKernelGGL(assemble_direct_kernel<true>, dim3(8 * per_xcd), dim3(64), lds, s, m, mat, h, rg, Fq, mval, 1.0 / h,
+                       fixed_slot, nw, penalty, Hval, store_mode);
+  else
+    hipLaunchKernelGGL(assemble_direct_kernel<false>, dim3(8 * per_xcd), dim3(64), lds, s, m, mat, h, rg, Fq, mval, 1.0 / h,
+                       fixed_slot, nw, penalty, Hval, store_mode);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -19,16 +19,15 @@ namespace tlfea {
 
 struct RowGroupsHost {
   std::vector<int> g_inst_off, g_row_off, gr_row, gr_acc, gi_code, gi_pack;
-  // what the kernel reads: a flat table of PASSES (<= 6 instances of one group each), cut into chunks of consecutive
-  // groups (one wavefront per chunk), per-row records, and per instance the base of its row's mass values
+  // what the kernel reads: a flat table of PASSES (<= 6 instances of one group each) with the pass range of every
+  // group, per-row records, and per instance the base of its row's mass values
   std::vector<int> pt;         // [P][4]: first instance | count + 8 first-of-group + 16 last-of-group + (rows << 8) |
                                //         first row | doubles of accumulator the group uses
-  std::vector<int> chunk_off;  // [C+1] passes of chunk c
+  std::vector<int> g_pass_off; // [G+1] passes of group g
   std::vector<int> gr_info;    // [N][4]: acc offset + (position of the diagonal block << 16) | off[row] | deg | node
   std::vector<int> gi_mb;      // [S*E]: off[row] - acc offset / 3 (mass value of a block = mval[gi_mb + acc offset / 3])
   int acc_max = 0;
   int G() const { return (int)g_inst_off.size() - 1; }
-  int C() const { return (int)chunk_off.size() - 1; }
 };
 
 inline uint64_t morton_spread21(uint64_t v) {  // 21 bits -> every third bit
@@ -45,7 +44,7 @@ inline uint64_t morton_spread21(uint64_t v) {  // 21 bits -> every third bit
 // (e*S + local, ascending e per node), x/y/z: reference coordinates of the N rows.
 inline bool build_row_groups(int N, int E, int S, const int* conn, const int* off, const int* cols, const int* n2e_off,
                              const int* n2e, const double* x, const double* y, const double* z, RowGroupsHost& out) {
-  constexpr int kInstBudget = 24, kAccBudget = 1024, kBigRow = 13, kMaxRows = 16, kPassInst = 6, kChunkPasses = 32;
+  constexpr int kInstBudget = 24, kAccBudget = 864, kBigRow = 13, kMaxRows = 16, kPassInst = 6;
   if (N <= 0 || E <= 0) return false;
   double lo[3] = {x[0], y[0], z[0]}, hi[3] = {x[0], y[0], z[0]};
   for (int i = 1; i < N; i++) {
@@ -138,9 +137,8 @@ inline bool build_row_groups(int N, int E, int S, const int* conn, const int* of
       }
     }
   }
-  // pass table and chunks (serial: a few integers per pass)
-  out.chunk_off.push_back(0);
-  int chunk_passes = 0;
+  // pass table (serial: a few integers per pass)
+  out.g_pass_off.push_back(0);
   for (int g = 0; g < G; g++) {
     const int i0 = out.g_inst_off[g], i1 = out.g_inst_off[g + 1], r0 = out.g_row_off[g], nr = out.g_row_off[g + 1] - r0;
     const int last_row = out.gr_row[r0 + nr - 1];
@@ -153,13 +151,9 @@ inline bool build_row_groups(int N, int E, int S, const int* conn, const int* of
       out.pt.push_back(cnt | flags | (nr << 8));
       out.pt.push_back(r0);
       out.pt.push_back(acc_n);
-      chunk_passes++;
       p0 += kPassInst;
     } while (p0 < i1);
-    if (chunk_passes >= kChunkPasses || g == G - 1) {
-      out.chunk_off.push_back((int)(out.pt.size() / 4));
-      chunk_passes = 0;
-    }
+    out.g_pass_off.push_back((int)(out.pt.size() / 4));
   }
   return true;
 }

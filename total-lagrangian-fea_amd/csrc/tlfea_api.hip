@@ -1126,12 +1126,12 @@ extern "C" int tlfea_newton_analyze_hessian_sparsity(tlfea_newton_t s) {
     RowGroupsHost rh;
     if (build_row_groups(N, d->E, d->S, d->h_conn.data(), d->h_off.data(), d->h_cols.data(), d->h_n2e_off.data(),
                          d->h_n2e.data(), d->h_X0.data(), d->h_X0.data() + N, d->h_X0.data() + 2 * (size_t)N, rh)) {
-      const std::vector<int>* src[6] = {&rh.chunk_off, &rh.pt, &rh.gr_info, &rh.gi_code, &rh.gi_mb, &rh.gi_pack};
+      const std::vector<int>* src[6] = {&rh.g_pass_off, &rh.pt, &rh.gr_info, &rh.gi_code, &rh.gi_mb, &rh.gi_pack};
       for (int k = 0; k < 6; k++) {
         TRY(dmalloc(&s->d_rg[k], src[k]->size() + 4));
         HIP_TRY(hipMemcpy(s->d_rg[k], src[k]->data(), src[k]->size() * sizeof(int), hipMemcpyHostToDevice));
       }
-      s->rg = RowGroups{rh.C(), d->E * d->S, rh.acc_max, s->d_rg[0], reinterpret_cast<const int4*>(s->d_rg[1]),
+      s->rg = RowGroups{rh.G(), d->E * d->S, rh.acc_max, s->d_rg[0], reinterpret_cast<const int4*>(s->d_rg[1]),
                         reinterpret_cast<const int4*>(s->d_rg[2]), s->d_rg[3], s->d_rg[4], s->d_rg[5]};
       TRY(dmalloc(&s->d_Fq, (size_t)d->E * d->Q * 9));
       s->rg_ok = true;

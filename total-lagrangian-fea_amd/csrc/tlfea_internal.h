@@ -53,15 +53,15 @@ struct Incidence {
   const int* diagpos;   // [N]     position of i in row i
 };
 
-// Work lists of the fused tangent + assembly kernel (T10, SVK): a wavefront owns a CHUNK of consecutive row groups; a
-// group is a few node rows of H (3 CSR rows each) whose (row, incident element) instances are worked through in PASSES
-// of up to 6.  Built once per mesh on the host (rowgroup_host.h): rows in Morton order of the reference coordinates, so
-// that consecutive groups share elements.
+// Work lists of the fused tangent + assembly kernel (T10, SVK): a GROUP is a few node rows of H (3 CSR rows each) whose
+// (row, incident element) instances are worked through in PASSES of up to 6; the resident wavefronts of an XCD walk
+// that XCD's range of groups side by side (wave w takes groups w, w + W, w + 2W, ...).  Built once per mesh on the host
+// (rowgroup_host.h): rows in Morton order of the reference coordinates, so that consecutive groups share elements.
 struct RowGroups {
-  int C;                  // chunks (one wavefront each)
+  int G;                  // groups
   int n_inst;             // S*E instances
   int acc_max;            // doubles of LDS accumulator the largest group needs
-  const int* chunk_off;   // [C+1] passes of chunk c
+  const int* g_pass_off;  // [G+1] passes of group g
   const int4* pt;         // [P] pass: first instance | count + 8 first + 16 last of group + (rows << 8) | first row |
                           //          accumulator doubles of the group
   const int4* gr_info;    // [N] row: acc offset + (diagonal block position << 16) | off[row] | deg | node
