@@ -244,11 +244,11 @@ void launch_dndu_pre(hipStream_t s, int E, int Epad, const int* conn, const doub
 // residual: fused compute_p + compute_internal_force (FEAT10DataFunc.cuh:85-293,397-458)
 // thread per element; fbuf[e][a][d] = sum_q (P_q grad N_a) detJ_q w_q
 // ------------------------------------------------------------------------------------------------
-template <int S, int Q, bool STORE>
+template <int S, int Q, bool STORE, bool MASS>
 __global__ __launch_bounds__(128) void residual_kernel(ElemView m, Material mat, const double* __restrict__ v,
                                                       double* __restrict__ fbuf, double* __restrict__ Fo,
                                                       double* __restrict__ Po, double* __restrict__ Fdo,
-                                                      double* __restrict__ Pvo, double* __restrict__ Fq) {
+                                                      double* __restrict__ Pvo, double* __restrict__ Fq, MassTerm mt) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= m.E) return;
   const bool damp = (v != nullptr) && (mat.eta != 0.0 || mat.lamd != 0.0);  // FEAT10DataFunc.cuh:137
@@ -264,6 +264,37 @@ __global__ __launch_bounds__(128) void residual_kernel(ElemView m, Material mat,
   double f[S][3];
 #pragma unroll
   for (int a = 0; a < S; a++) f[a][0] = f[a][1] = f[a][2] = 0.0;
+  if (MASS) {
+    // inertia rows M_e (v - v_prev) / h:  rows_a = rho/h sum_q N_a(q) dV_q sum_b N_b(q) (v - v_prev)_b
+    double dv[S][3], mr[S][3];
+#pragma unroll
+    for (int a = 0; a < S; a++)
+#pragma unroll
+      for (int i = 0; i < 3; i++) {
+        dv[a][i] = v[3 * gn[a] + i] - mt.vprev[3 * gn[a] + i];
+        mr[a][i] = 0.0;
+      }
+#pragma unroll
+    for (int q = 0; q < (MASS ? Q : 0); q++) {
+      double w[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+      for (int a = 0; a < S; a++)
+#pragma unroll
+        for (int i = 0; i < 3; i++) w[i] += mt.Nq[q < kNQ ? q : 0][a < kNN ? a : 0] * dv[a][i];
+      const double c = mt.rho_inv_h * m.detJ[(size_t)e * Q + q] * m.qw[q];
+#pragma unroll
+      for (int a = 0; a < S; a++) {
+        const double ca = c * mt.Nq[q < kNQ ? q : 0][a < kNN ? a : 0];
+#pragma unroll
+        for (int i = 0; i < 3; i++) mr[a][i] += ca * w[i];
+      }
+    }
+    double* mo = mt.mbuf + (size_t)e * (6 * S) + 3;  // [e][a][6]: force row (written below) | inertia row
+#pragma unroll
+    for (int a = 0; a < S; a++)
+#pragma unroll
+      for (int i = 0; i < 3; i++) mo[a * 6 + i] = mr[a][i];
+  }
 
 #pragma unroll 1
   for (int q = 0; q < Q; q++) {
@@ -279,8 +310,8 @@ __global__ __launch_bounds__(128) void residual_kernel(ElemView m, Material mat,
       for (int i = 0; i < 3; i++)
 #pragma unroll
         for (int j = 0; j < 3; j++) F[i][j] += xn[a][i] * hq[a][j];
-    if (Fq) {  // row-major F per (point, element): what the fused assembly stages instead of rebuilding F
-      double* fo = Fq + ((size_t)q * m.E + e) * 9;
+    if (Fq) {  // row-major F per (element, point): what the fused assembly stages instead of rebuilding F
+      double* fo = Fq + ((size_t)e * Q + q) * 9;
 #pragma unroll
       for (int i = 0; i < 3; i++)
 #pragma unroll
@@ -350,6 +381,14 @@ __global__ __launch_bounds__(128) void residual_kernel(ElemView m, Material mat,
         f[a][i] += c * dV;
       }
   }
+  if (MASS) {  // one 48-byte record per (element, node) for the gather of grad_light_kernel
+    double* out = mt.mbuf + (size_t)e * (6 * S);
+#pragma unroll
+    for (int a = 0; a < S; a++)
+#pragma unroll
+      for (int i = 0; i < 3; i++) out[a * 6 + i] = f[a][i];
+    return;
+  }
   double* out = fbuf + (size_t)e * (3 * S);
 #pragma unroll
   for (int a = 0; a < S; a++)
@@ -359,20 +398,25 @@ __global__ __launch_bounds__(128) void residual_kernel(ElemView m, Material mat,
 
 template <int S, int Q>
 static void launch_residual_t(hipStream_t s, const ElemView& m, const Material& mat, const double* v, double* fbuf,
-                              double* F, double* P, double* Fdot, double* Pvis, double* Fq) {
+                              double* F, double* P, double* Fdot, double* Pvis, double* Fq, const MassTerm* mt) {
   const dim3 grid((m.E + 127) / 128), block(128);
+  MassTerm none{};
+  none.vprev = nullptr;
   if (F)
-    hipLaunchKernelGGL((residual_kernel<S, Q, true>), grid, block, 0, s, m, mat, v, fbuf, F, P, Fdot, Pvis, Fq);
+    hipLaunchKernelGGL((residual_kernel<S, Q, true, false>), grid, block, 0, s, m, mat, v, fbuf, F, P, Fdot, Pvis, Fq, none);
+  else if (S == kNN && mt && mt->vprev && v)
+    hipLaunchKernelGGL((residual_kernel<S, Q, false, (S == kNN)>), grid, block, 0, s, m, mat, v, fbuf, nullptr, nullptr,
+                       nullptr, nullptr, Fq, *mt);
   else
-    hipLaunchKernelGGL((residual_kernel<S, Q, false>), grid, block, 0, s, m, mat, v, fbuf, nullptr, nullptr, nullptr,
-                       nullptr, Fq);
+    hipLaunchKernelGGL((residual_kernel<S, Q, false, false>), grid, block, 0, s, m, mat, v, fbuf, nullptr, nullptr, nullptr,
+                       nullptr, Fq, none);
 }
 
 void launch_residual(hipStream_t s, const ElemView& m, const Material& mat, const double* v, double* fbuf, double* F,
-                     double* P, double* Fdot, double* Pvis, double* Fq) {
-  if (m.S == 10) launch_residual_t<10, 5>(s, m, mat, v, fbuf, F, P, Fdot, Pvis, Fq);
-  else if (m.S == 8) launch_residual_t<8, 12>(s, m, mat, v, fbuf, F, P, Fdot, Pvis, Fq);
-  else launch_residual_t<16, 48>(s, m, mat, v, fbuf, F, P, Fdot, Pvis, Fq);
+                     double* P, double* Fdot, double* Pvis, double* Fq, const MassTerm* mt) {
+  if (m.S == 10) launch_residual_t<10, 5>(s, m, mat, v, fbuf, F, P, Fdot, Pvis, Fq, mt);
+  else if (m.S == 8) launch_residual_t<8, 12>(s, m, mat, v, fbuf, F, P, Fdot, Pvis, Fq, nullptr);
+  else launch_residual_t<16, 48>(s, m, mat, v, fbuf, F, P, Fdot, Pvis, Fq, nullptr);
 }
 
 // f_int[3i+d] = sum over the node's elements of their force rows (fixed order: ascending element id)
@@ -556,6 +600,59 @@ void launch_grad(hipStream_t s, int N, const Incidence& inc, const double* fbuf,
                  const double* nw, double h, double rho, double* f_int, double* cons, double* g) {
   hipLaunchKernelGGL(grad_kernel, dim3((N + 7) / 8), dim3(256), 0, s, N, inc, fbuf, mval, v, vprev, f_ext, x, y, z,
                      xt, yt, zt, fixed_slot, lam, nw, h, rho, f_int, cons, g);
+}
+
+// grad L with the inertia rows of the residual launch (T10): 8 lanes per node gather the node's element rows of f_int
+// and of M (v - v_prev) / h in ascending element order, fixed-order butterfly, then the same epilogue as grad_kernel.
+__global__ __launch_bounds__(256) void grad_light_kernel(int N, Incidence inc, const double* __restrict__ fbuf,
+                                                        const double* __restrict__ mbuf, const double* __restrict__ f_ext,
+                                                        const double* __restrict__ x, const double* __restrict__ y,
+                                                        const double* __restrict__ z, const double* __restrict__ xt,
+                                                        const double* __restrict__ yt, const double* __restrict__ zt,
+                                                        const int* __restrict__ fixed_slot, const double* __restrict__ lam,
+                                                        const double* __restrict__ nw, double h, double rho,
+                                                        double* __restrict__ f_int, double* __restrict__ cons,
+                                                        double* __restrict__ g) {
+  const int l8 = threadIdx.x & 7;
+  const int i = blockIdx.x * 32 + (threadIdx.x >> 3);
+  if (i >= N) return;
+  double a[6] = {0, 0, 0, 0, 0, 0};  // f[0..2], inertia[0..2]
+  for (int k = inc.n2e_off[i] + l8; k < inc.n2e_off[i + 1]; k += 8) {
+    const double2* r = reinterpret_cast<const double2*>(mbuf + (size_t)inc.n2e[k] * 6);  // [e][a][6], 16-byte aligned
+    const double2 r0 = r[0], r1 = r[1], r2 = r[2];
+    a[0] += r0.x;
+    a[1] += r0.y;
+    a[2] += r1.x;
+    a[3] += r1.y;
+    a[4] += r2.x;
+    a[5] += r2.y;
+  }
+#pragma unroll
+  for (int o = 4; o > 0; o >>= 1)
+#pragma unroll
+    for (int k = 0; k < 6; k++) a[k] += __shfl_xor(a[k], o);
+  if (l8 < 3) {
+    const int d = l8;
+    const int slot = fixed_slot ? fixed_slot[i] : -1;
+    const double fd = (d == 0) ? a[0] : ((d == 1) ? a[1] : a[2]);
+    const double md = (d == 0) ? a[3] : ((d == 1) ? a[4] : a[5]);
+    f_int[3 * i + d] = fd;
+    double r = md + fd - f_ext[3 * i + d];
+    if (slot >= 0) {
+      const double cv = (d == 0) ? (x[i] - xt[i]) : ((d == 1) ? (y[i] - yt[i]) : (z[i] - zt[i]));
+      cons[3 * slot + d] = cv;
+      r += (nw ? nw[i] : 1.0) * h * (lam[3 * slot + d] + rho * cv);
+    }
+    g[3 * i + d] = r;
+  }
+}
+
+void launch_grad_light(hipStream_t s, int N, const Incidence& inc, const double* fbuf, const double* mbuf,
+                       const double* f_ext, const double* x, const double* y, const double* z, const double* xt,
+                       const double* yt, const double* zt, const int* fixed_slot, const double* lam, const double* nw,
+                       double h, double rho, double* f_int, double* cons, double* g) {
+  hipLaunchKernelGGL(grad_light_kernel, dim3((N + 31) / 32), dim3(256), 0, s, N, inc, fbuf, mbuf, f_ext, x, y, z, xt, yt, zt,
+                     fixed_slot, lam, nw, h, rho, f_int, cons, g);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -963,6 +1060,7 @@ namespace {
 constexpr int kAdInst = 6;                            // instances per pass
 constexpr int kAdRec = 26;                            // doubles per staged record
 constexpr int kAdRecTotal = kAdInst * kNQ * kAdRec;   // 780 doubles = 6.1 KiB
+constexpr int kAdHraw = kAdInst * kNQ * 4;            // 120 doubles
 }  // namespace
 
 // H row store that does not stay in the XCD's L2 (sc1: written through and dropped, MI355X_MICROARCH.md "stores of each
@@ -976,6 +1074,16 @@ __device__ __forceinline__ void store_through(double* p, double v, int mode) {
     *p = v;
 }
 
+// The fused kernel's workgroup is ONE wavefront: its LDS instructions execute in program order, so data written by one
+// lane is visible to the lanes of every later LDS instruction without a barrier.  What remains of __syncthreads() is the
+// compiler-level ordering -- and NOT its s_waitcnt vmcnt(0), which would drain the prefetched index loads and the H row
+// stores at every one of the 3-5 synchronisation points of a pass.
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 template <bool ROLLED>
 __global__ __launch_bounds__(64, ROLLED ? 3 : 2) void assemble_direct_kernel(ElemView m, Material mat, double h, RowGroups rg,
                                                                const double* __restrict__ Fq,
@@ -984,8 +1092,9 @@ __global__ __launch_bounds__(64, ROLLED ? 3 : 2) void assemble_direct_kernel(Ele
                                                                const double* __restrict__ nw, double penalty,
                                                                double* __restrict__ Hval, int store_mode) {
   extern __shared__ __attribute__((aligned(16))) double lds_ad[];
-  double* rec = lds_ad;                // [kAdInst][kNQ][kAdRec]
-  double* acc = lds_ad + kAdRecTotal;  // the group's rows, each in H's layout [d][3 deg]
+  double* rec = lds_ad;                          // [kAdInst][kNQ][kAdRec]
+  double* hraw = lds_ad + kAdRecTotal;           // [kAdInst][kNQ][4]: h_i of the pass's instances
+  double* acc = lds_ad + kAdRecTotal + kAdHraw;  // the group's rows, each in H's layout [d][3 deg]
   // Blocks b, b + 8, ... share an XCD (round-robin dispatch).  XCD x owns groups [x Gper, (x+1) Gper) and its W resident
   // waves walk that range side by side: wave w takes groups w, w + W, w + 2W, ... -- at any time the XCD works on a
   // window of ~W consecutive groups, i.e. spatial neighbours whose elements overlap, so that the re-reads of an
@@ -1050,7 +1159,8 @@ __global__ __launch_bounds__(64, ROLLED ? 3 : 2) void assemble_direct_kernel(Ele
     const int cnt = ecur.y & 7, nrows = ecur.y >> 8;
     const bool first = (ecur.y & 8) != 0, last = (ecur.y & 16) != 0;
     // ---- (1) this pass's data: one round trip -------------------------------------------------------------
-    const int e = code_i / kNN;
+    // (timing experiments, tools/tune_assemble.py: store_mode bit 8 = every load from element 0, bit 9 = no arithmetic)
+    const int e = (store_mode & 256) ? 0 : code_i / kNN;
     const double* gN = m.gradN + (size_t)e * (kNQ * 3 * kNN) + j;
     double hj[kNQ][3];
 #pragma unroll
@@ -1060,20 +1170,17 @@ __global__ __launch_bounds__(64, ROLLED ? 3 : 2) void assemble_direct_kernel(Ele
     const bool act = k < cnt;
     double mh = 0.0;
     if (act && pk < 0) mh = mval[mb + (pk & 0xffff) / 3];
-    const int es = code_s / kNN, ils = code_s - kNN * es;
-    double F[9], s0 = 0.0, s1 = 0.0, s2 = 0.0;  // s*: h_i (kinematic half) | det J (material half)
+    const int es = (store_mode & 256) ? 0 : code_s / kNN;
+    double F[9], s0 = 0.0;  // s0: det J (material half)
     if (stager) {
-      const double* Fp = Fq + ((size_t)qs * E + es) * 9;
-#pragma unroll
-      for (int t = 0; t < 9; t++) F[t] = Fp[t];
-      if (lane < 32) {
-        const double* gs = m.gradN + ((size_t)es * kNQ + qs) * (3 * kNN) + ils;
-        s0 = gs[0];
-        s1 = gs[kNN];
-        s2 = gs[2 * kNN];
-      } else {
-        s0 = m.detJ[(size_t)es * kNQ + qs];
-      }
+      // the 72 bytes of F as four 16-byte loads + one: the five points of an element are contiguous, so the 30 lanes of
+      // one instruction touch ~20 cache lines instead of 30 per 8-byte load (the vector L1 handles a line per clock)
+      const double* Fp = Fq + ((size_t)es * kNQ + qs) * 9;
+      const double2 f01 = *reinterpret_cast<const double2*>(Fp), f23 = *reinterpret_cast<const double2*>(Fp + 2),
+                    f45 = *reinterpret_cast<const double2*>(Fp + 4), f67 = *reinterpret_cast<const double2*>(Fp + 6);
+      F[0] = f01.x; F[1] = f01.y; F[2] = f23.x; F[3] = f23.y; F[4] = f45.x; F[5] = f45.y; F[6] = f67.x; F[7] = f67.y;
+      F[8] = Fp[8];
+      if (lane >= 32) s0 = m.detJ[(size_t)es * kNQ + qs];
     }
     // ---- (2) the next pass's indices ------------------------------------------------------------------------
     int code_i_n, pk_n, mb_n, code_s_n;
@@ -1093,11 +1200,23 @@ __global__ __launch_bounds__(64, ROLLED ? 3 : 2) void assemble_direct_kernel(Ele
         if (fixed_slot && fixed_slot[ri.w] >= 0) pen = (nw ? nw[ri.w] : 1.0) * penalty;
       }
     }
-    __syncthreads();  // the previous pass has consumed its records; the accumulators are clear
+    // h_i of instance k is the h_j of its lane j == il: published through LDS instead of 3 more scattered loads per record
+    if (k < kAdInst && j == code_i - kNN * (code_i / kNN)) {
+      double* hp = hraw + k * (kNQ * 4);
+#pragma unroll
+      for (int q = 0; q < kNQ; q++) {
+        *reinterpret_cast<double2*>(hp + 4 * q) = make_double2(hj[q][0], hj[q][1]);
+        hp[4 * q + 2] = hj[q][2];
+      }
+    }
+    wave_sync();  // the previous pass has consumed its records; the accumulators are clear; h_i is published
     // ---- (4) stage the 30 (instance, point) records ---------------------------------------------------------
     if (stager) {
       double* R = rec + (ks * kNQ + qs) * kAdRec;
       if (lane < 32) {
+        const double* hp = hraw + ks * (kNQ * 4) + 4 * qs;
+        const double2 h01 = *reinterpret_cast<const double2*>(hp);
+        const double s0 = h01.x, s1 = h01.y, s2 = hp[2];
         double2* R2 = reinterpret_cast<double2*>(R);
         R2[0] = make_double2(s0, s1);
         R2[1] = make_double2(s2, F[0] * s0 + F[1] * s1 + F[2] * s2);
@@ -1126,15 +1245,16 @@ __global__ __launch_bounds__(64, ROLLED ? 3 : 2) void assemble_direct_kernel(Ele
         R2[4] = make_double2(C0, C1);
       }
     }
-    __syncthreads();
+    wave_sync();
     // ---- (5) this lane's block: sum over the 5 points, add into the row accumulator --------------------------
     double a00 = 0, a01 = 0, a02 = 0, a10 = 0, a11 = 0, a12 = 0, a20 = 0, a21 = 0, a22 = 0;
     double cds = mh * inv_h;  // M/h on the xyz-diagonal (SyncedNewton.cu:214-259), carried by the block's first item
     const double2* Rk = reinterpret_cast<const double2*>(rec + (size_t)min(k, kAdInst - 1) * kNQ * kAdRec);
     // ROLLED: one point per trip, h_j[q] read through the register index (166 VGPRs, 3 waves per SIMD); unrolled the
     // scheduler overlaps the points' LDS reads with arithmetic at 230 VGPRs, 2 waves per SIMD
+    const int nq = (store_mode & 512) ? 0 : kNQ;
 #pragma unroll(ROLLED ? 1 : kNQ)
-    for (int q = 0; q < kNQ; q++) {
+    for (int q = 0; q < nq; q++) {
       const double2* R2 = Rk + q * (kAdRec / 2);
       const double2 r0 = R2[0], r1 = R2[1], r2 = R2[2], r3 = R2[3], r4 = R2[4], r5 = R2[5], r6 = R2[6], r7 = R2[7],
                     r8 = R2[8], r9 = R2[9], r10 = R2[10], r11 = R2[11], r12 = R2[12];
@@ -1176,17 +1296,17 @@ __global__ __launch_bounds__(64, ROLLED ? 3 : 2) void assemble_direct_kernel(Ele
     }
     // ---- (6) last pass of a group: h^2 rho J^T J on pinned rows (SyncedNewton.cu:292-341), rows stream out once ----
     if (last) {
-      __syncthreads();
+      wave_sync();
       if (lane < nrows && pen != 0.0) {
         const int a0 = ri.x & 0xffff, dpos = ri.x >> 16, row = 3 * ri.z;
 #pragma unroll
         for (int d = 0; d < 3; d++) acc[a0 + d * row + 3 * dpos + d] += pen;
       }
-      __syncthreads();
+      wave_sync();
       for (int r = 0; r < nrows; r++) {
         const int a0 = __shfl(ri.x, r) & 0xffff, off0 = __shfl(ri.y, r), n9 = 9 * __shfl(ri.z, r);
         double* out = Hval + (size_t)9 * off0;
-        for (int t = lane; t < n9; t += 64) store_through(out + t, acc[a0 + t], store_mode);
+        for (int t = lane; t < n9; t += 64) store_through(out + t, acc[a0 + t], store_mode & 3);
       }
     }
     ecur = enxt;
@@ -1203,7 +1323,7 @@ __global__ __launch_bounds__(64, ROLLED ? 3 : 2) void assemble_direct_kernel(Ele
 void launch_assemble_direct(hipStream_t s, const ElemView& m, const Material& mat, double h, const RowGroups& rg,
                             const double* Fq, const double* mval, const int* fixed_slot, const double* nw,
                             double penalty, double* Hval) {
-  const size_t lds = (size_t)(kAdRecTotal + rg.acc_max) * sizeof(double);
+  const size_t lds = (size_t)(kAdRecTotal + kAdHraw + rg.acc_max) * sizeof(double);
   static size_t lds_attr = 0;
   if (lds > 64 * 1024 && lds > lds_attr) {
     (void)hipFuncSetAttribute((const void*)assemble_direct_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1238,7 +1358,7 @@ void launch_assemble_direct(hipStream_t s, const ElemView& m, const Material& ma
     rolled = std::getenv("TLFEA_AD_ROLLED") ? std::atoi(std::getenv("TLFEA_AD_ROLLED")) : 1;
     occ_env = std::getenv("TLFEA_AD_WAVES") ? std::atoi(std::getenv("TLFEA_AD_WAVES")) : 0;
   }
-  const int occ_eff = occ_env > 0 ? occ_env : std::min(occ, rolled ? 12 : 8);
+  const int occ_eff = occ_env > 0 ? occ_env : std::min(occ, rolled ? 10 : 8);  // measured best at config C (tools/tune_assemble.py)
   const int per_xcd = std::max(1, std::min((n_cu / 8) * occ_eff, (rg.G + 7) / 8));
   if (rolled)
     hipLaunchKernelGGL(assemble_direct_kernel<true>, dim3(8 * per_xcd), dim3(64), lds, s, m, mat, h, rg, Fq, mval, 1.0 / h,

@@ -91,6 +91,10 @@ struct tlfea_t10_s {  // any element type; the name is kept for the ABI's first 
   int nnz_mass = 0;
   // sparsity (host copies are kept: the solver and the retrieve calls need them)
   std::vector<int> h_conn, h_off, h_cols, h_n2e_off, h_n2e;
+  double h_q[3][kNQ] = {{0}};  // T10 quadrature points (host copy: shape-function table of the element-wise inertia term)
+  bool fbuf_valid = true;      // d_fbuf holds the force rows of the last residual evaluation (false after a solver
+                               // evaluation on the interleaved-row path: d_fint itself is then current)
+  double mass_rho0 = -1.0;     // density the mass matrix was assembled with (CalcMassMatrix); < 0: not assembled
   std::vector<double> h_X0;  // coordinates handed to Setup (x | y | z): the Morton order of the fused assembly's row groups
   int *d_off = nullptr, *d_cols = nullptr, *d_n2e_off = nullptr, *d_n2e = nullptr, *d_n2e_pos = nullptr,
       *d_diagpos = nullptr;
@@ -199,7 +203,12 @@ extern "C" int tlfea_t10_setup(tlfea_t10_t h, const double* qx, const double* qy
   HIP_TRY(hipMemcpy(h->d_qx, qx, kNQ * sizeof(double), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(h->d_qy, qy, kNQ * sizeof(double), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(h->d_qz, qz, kNQ * sizeof(double), hipMemcpyHostToDevice));
-  for (int q = 0; q < kNQ; q++) h->h_qw[q] = qw[q];
+  for (int q = 0; q < kNQ; q++) {
+    h->h_qw[q] = qw[q];
+    h->h_q[0][q] = qx[q];
+    h->h_q[1][q] = qy[q];
+    h->h_q[2][q] = qz[q];
+  }
   h->h_conn.assign(conn, conn + E * kNN);
   h->h_X0.resize(3 * N);
   std::copy(x, x + N, h->h_X0.begin());
@@ -532,6 +541,7 @@ extern "C" int tlfea_t10_calc_mass_matrix(tlfea_t10_t h) {
   launch_mass_values(h->stream, h->view(), h->inc(), h->d_qx, h->d_qy, h->d_qz, h->mat.rho0, h->d_mval);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipDeviceSynchronize());
+  h->mass_rho0 = h->mat.rho0;
   return 0;
 }
 
@@ -718,13 +728,15 @@ extern "C" int tlfea_t10_calc_p(tlfea_t10_t h) {
   launch_residual(h->stream, h->view(), h->mat, nullptr, h->d_fbuf, h->d_F, h->d_P, h->d_Fdot, h->d_Pvis);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipDeviceSynchronize());
+  h->fbuf_valid = true;
   return 0;
 }
 extern "C" int tlfea_t10_calc_internal_force(tlfea_t10_t h) {
   NEED_SETUP(h, "CalcInternalForce.");
   if (!h->is_csr_setup) TRY(tlfea_t10_build_mass_csr_pattern(h));
-  // d_fbuf holds the per-element force rows of the last residual evaluation (CalcP or the solver)
-  launch_fint_gather(h->stream, h->N, h->inc(), h->d_fbuf, h->d_fint);
+  // d_fbuf holds the per-element force rows of the last residual evaluation (CalcP or the solver); a solver evaluation
+  // on the interleaved-row path has written f_int itself (same P: the reference shares d_P between the two)
+  if (h->fbuf_valid) launch_fint_gather(h->stream, h->N, h->inc(), h->d_fbuf, h->d_fint);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipDeviceSynchronize());
   return 0;
@@ -944,6 +956,8 @@ struct tlfea_newton_s {
   bool fq_in_residual = true;  // first-order solvers (AdamW, Nesterov, VBD) never assemble: their residual skips Fq
   int asm_mode = 0;
   double* d_Fq = nullptr;
+  double* d_mbuf = nullptr;   // T10: per (element, node) force row | inertia row M_e (v - v_prev) / h of the residual launch
+  int mass_mode = 0;          // TLFEA_MASS=csr: always the mass CSR product in grad_kernel
   double *d_p = nullptr, *d_p2 = nullptr, *d_q = nullptr, *d_zv = nullptr;
   double* d_parts = nullptr;  // 6 x kNPart: rz[2], pq, rr, bb, norm
   double* d_scal = nullptr;   // 4 scalars
@@ -1013,6 +1027,7 @@ extern "C" int tlfea_newton_create(tlfea_t10_t data, int n_constraints, tlfea_ne
   if (const char* e = std::getenv("TLFEA_CHEB_BITS")) s->lin.cheb_bits = std::atoi(e);
   if (const char* e = std::getenv("TLFEA_PRECOND")) s->lin.precond = std::atoi(e);
   if (const char* e = std::getenv("TLFEA_ASSEMBLE")) s->asm_mode = (std::string(e) == "kbuf") ? 1 : 0;
+  if (const char* e = std::getenv("TLFEA_MASS")) s->mass_mode = (std::string(e) == "csr") ? 1 : 0;
   *out = s;
   return tlfea_newton_setup(s);
 }
@@ -1027,6 +1042,7 @@ extern "C" int tlfea_newton_destroy(tlfea_newton_t s) {
   for (int* p : s->d_rg)
     if (p) (void)hipFree(p);
   if (s->d_Fq) (void)hipFree(s->d_Fq);
+  if (s->d_mbuf) (void)hipFree(s->d_mbuf);
   for (auto& e : s->ev)
     if (e) (void)hipEventDestroy(e);
   if (s->h_pin) (void)hipHostFree(s->h_pin);
@@ -1429,18 +1445,47 @@ static int ensure_kbuf(tlfea_newton_t s) {
   return dmalloc(&s->d_Kbuf, (size_t)d->E * (d->S * (d->S + 1) / 2) * 9);
 }
 
+// T10: the inertia term of grad L element by element in the residual launch (same quadrature rule as the mass matrix,
+// the density it was assembled with) instead of the mass CSR product with gathered velocities
+static bool mass_in_residual(tlfea_newton_t s) {
+  return s->mass_mode == 0 && s->d->kind == kT10 && s->d->mass_rho0 >= 0.0;
+}
+static int fill_mass_term(tlfea_newton_t s, MassTerm& mt) {
+  tlfea_t10_t d = s->d;
+  if (!s->d_mbuf) TRY(dmalloc(&s->d_mbuf, (size_t)d->E * 6 * d->S));
+  mt.vprev = s->d_vprev;
+  mt.mbuf = s->d_mbuf;
+  mt.rho_inv_h = d->mass_rho0 / s->prm.time_step;
+  const int edges[6][2] = {{0, 1}, {1, 2}, {0, 2}, {0, 3}, {1, 3}, {2, 3}};  // FEAT10Data.cu:143
+  for (int q = 0; q < kNQ; q++) {
+    const double L[4] = {1.0 - d->h_q[0][q] - d->h_q[1][q] - d->h_q[2][q], d->h_q[0][q], d->h_q[1][q], d->h_q[2][q]};
+    for (int k = 0; k < 4; k++) mt.Nq[q][k] = L[k] * (2.0 * L[k] - 1.0);
+    for (int k = 0; k < 6; k++) mt.Nq[q][k + 4] = 4.0 * L[edges[k][0]] * L[edges[k][1]];
+  }
+  return 0;
+}
+
 static int eval_gradient(tlfea_newton_t s, double* norm_g) {
   tlfea_t10_t d = s->d;
   const tlfea_newton_params& p = s->prm;
+  const bool mir = mass_in_residual(s);
   {
     StageTimer t(s, 0);
+    MassTerm mt{};
+    if (mir) TRY(fill_mass_term(s, mt));
     launch_residual(s->stream, d->view(), d->mat, s->d_v, d->d_fbuf, nullptr, nullptr, nullptr, nullptr,
-                    (use_direct(s) && s->fq_in_residual) ? s->d_Fq : nullptr);
+                    (use_direct(s) && s->fq_in_residual) ? s->d_Fq : nullptr, mir ? &mt : nullptr);
+    d->fbuf_valid = !mir;
     t.stop();
   }
   {
     StageTimer t(s, 1);
     const bool pinned = pinned_on(s);
+    if (mir)
+      launch_grad_light(s->stream, s->N, d->inc(), d->d_fbuf, s->d_mbuf, d->d_fext, d->d_x, d->d_y, d->d_z, d->d_xt,
+                        d->d_yt, d->d_zt, pinned ? d->d_fixed_slot : nullptr, s->d_lam, s->d_nw, p.time_step, p.rho,
+                        d->d_fint, d->d_cons, s->d_g);
+    else
     launch_grad(s->stream, s->N, d->inc(), d->d_fbuf, d->d_mval, s->d_v, s->d_vprev, d->d_fext, d->d_x, d->d_y, d->d_z,
                 d->d_xt, d->d_yt, d->d_zt, pinned ? d->d_fixed_slot : nullptr, s->d_lam, s->d_nw, p.time_step, p.rho,
                 d->d_fint, d->d_cons, s->d_g);
@@ -2371,9 +2416,13 @@ extern "C" int tlfea_newton_time_kernels(tlfea_newton_t s, int reps, double* out
     if (k >= 5 && !(s->pmg.ok && s->pmg.d_B8c)) break;
     HIP_TRY(hipEventRecord(s->ev[6], s->stream));
     for (int r = 0; r < reps; r++) {
-      if (k == 0)
+      if (k == 0) {
+        MassTerm mt{};
+        const bool mir = mass_in_residual(s);
+        if (mir) TRY(fill_mass_term(s, mt));
         launch_residual(s->stream, d->view(), d->mat, s->d_v, d->d_fbuf, nullptr, nullptr, nullptr, nullptr,
-                        use_direct(s) ? s->d_Fq : nullptr);
+                        use_direct(s) ? s->d_Fq : nullptr, mir ? &mt : nullptr);
+      }
       else if (k == 1) {
         if (use_direct(s)) break;  // no separate tangent launch on the fused path: out[1] = 0
         TRY(ensure_kbuf(s));

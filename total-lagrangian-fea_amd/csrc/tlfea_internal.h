@@ -43,6 +43,16 @@ struct ElemView {
   double qw[kMaxQ];       // combined quadrature weights
 };
 
+// T10 only: the inertia term M (v - v_prev) / h of grad L (SyncedNewton.cu:362-371) evaluated element by element in the
+// residual launch (M = sum_e M_e with the rule of FEAT10Data.cu:206-278) instead of a CSR product with gathered
+// velocities: Nq = shape functions at the 5 Keast points, rho = the density the mass matrix was assembled with.
+struct MassTerm {
+  const double* vprev;   // null: no mass term (mbuf is not written)
+  double* mbuf;          // [E][10][6] per (element, node): force row | inertia row (replaces fbuf on this path)
+  double rho_inv_h;      // rho0 / h
+  double Nq[kNQ][kNN];
+};
+
 // node -> element incidence and the scatter map of the row-owner ("gather") assembly
 struct Incidence {
   const int* n2e_off;   // [N+1]
@@ -77,7 +87,13 @@ void launch_dndu_pre(hipStream_t s, int E, int Epad, const int* conn, const doub
                      double* gradN, double* gradN_t, double* detJ);
 void launch_residual(hipStream_t s, const ElemView& m, const Material& mat, const double* v /*or null*/,
                      double* fbuf /*[E][30]*/, double* F, double* P, double* Fdot, double* Pvis,
-                     double* Fq = nullptr /*[Q][E][9] row-major F per point, for the fused assembly*/);
+                     double* Fq = nullptr /*[Q][E][9] row-major F per point, for the fused assembly*/,
+                     const MassTerm* mt = nullptr /*T10: also write the per-element inertia rows*/);
+// grad L without the mass CSR product (T10, inertia rows from the residual launch): 8 lanes per node
+void launch_grad_light(hipStream_t s, int N, const Incidence& inc, const double* fbuf, const double* mbuf,
+                       const double* f_ext, const double* x, const double* y, const double* z, const double* xt,
+                       const double* yt, const double* zt, const int* fixed_slot, const double* lam, const double* nw,
+                       double h, double rho, double* f_int, double* cons, double* g);
 // fused tangent + row assembly (T10, SVK): H rows straight from grad N and the F of the last residual launch
 void launch_assemble_direct(hipStream_t s, const ElemView& m, const Material& mat, double h, const RowGroups& rg,
                             const double* Fq, const double* mval, const int* fixed_slot, const double* nw,
