@@ -238,13 +238,13 @@ def main():
         roof_all[k] = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                        "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "avg_us": round(avg_s * 1e6, 2),
                        "launches": n, "alg_bytes": ab[k], "total_ms": round(kt[k] * n, 3)}
-    pmc = load_pmc_traffic() if args.config == "B" and world == 1 else {}
+    pmc, pmc_file = load_pmc_traffic(args.config) if world == 1 else ({}, None)
     for k, v in roof_all.items():
         if k in pmc:
             v["traffic"] = pmc[k]
-            v["traffic_note"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, profiles/r01_configB_pmc_hbm.csv): "
-                                 "(2*FETCH_SIZE + WRITE_SIZE)*1024 B per launch; the x2 is the guide's gfx950 streaming-read "
-                                 "correction, uncalibrated for 8-B-per-lane loads")
+            v["traffic_note"] = (f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, {pmc_file}): (2*FETCH_SIZE + "
+                                 "WRITE_SIZE)*1024 B per launch; FETCH_SIZE counts 64 B per 128-B request on gfx950, calibrated "
+                                 "for this engine's 8-/16-byte and scattered-row loads with tools/microbench/pmc_calib.hip")
     if pmg:
         roof_all["cheb_step"]["note"] = "fine level of the V-cycle only (isolated back-to-back timing); part of poly_step"
         roof_all["cheb_step_coarse"]["note"] = "coarse level of the V-cycle only (isolated timing); part of poly_step"
@@ -297,30 +297,38 @@ def main():
         dist.destroy_process_group()
 
 
-def load_pmc_traffic():
-    """HBM bytes per launch from the committed PMC summary (collected with the same command, config B)."""
-    path = os.path.join(ROOT, "profiles", "r01_configB_pmc_hbm.csv")  # regenerated by tools/summarize_pmc.py
+def load_pmc_traffic(config):
+    """HBM-side bytes per launch from the committed PMC summary of THIS config (rocprofv3 --pmc FETCH_SIZE and
+    --pmc WRITE_SIZE in separate passes of the same command, tools/collect_profiles_r02.sh).  FETCH_SIZE is doubled:
+    tools/microbench/pmc_calib.hip measures exactly half the bytes for this engine's access shapes too (8- and 16-byte
+    streaming loads, scattered 1200-byte rows read in 80-byte segments; profiles/r02_pmc_calibration.txt);
+    WRITE_SIZE is exact."""
+    import csv
     import re
+    path = None
+    for cand in (f"r02_config{config}_pmc_hbm.csv", f"r01_config{config}_pmc_hbm.csv"):
+        if os.path.exists(os.path.join(ROOT, "profiles", cand)):
+            path = os.path.join(ROOT, "profiles", cand)
+            break
+    if path is None:
+        return {}, None
     names = {r"residual_kernel": "residual", r"tangent_blocks_kernel": "tangent_blocks",
-             r"assemble_rows_kernel": "assemble_rows", r"spmv_dir_dot_kernel<true": "spmv",   # the CG variant at config B
+             r"assemble_rows_kernel": "assemble_rows", r"assemble_direct_kernel": "assemble_direct",
+             r"spmv_dir_dot_kernel": "spmv",
              r"cheb_step_kernel<false>": "cheb_step",                 # fp64 polynomial steps (cheb_bits 64)
              # fp32 recurrence, non-final steps (rocprofv3 leaves names with _Float16 arguments mangled)
              r"cheb32_kernel<[^,]+, \d+, false": "cheb_step", r"cheb32_kernelI\w+?_Li\d+ELb0E": "cheb_step"}
-    out = {}
-    if not os.path.exists(path):
-        return out
-    import csv
-    acc = {}
+    out, acc = {}, {}
     poly = {}   # counter -> [sum KB, launches] over every non-final launch of the polynomial-step kernel (both levels)
     for r in csv.DictReader(open(path)):
         if re.search(r"cheb32_kernelI\w+?_Li\d+ELb0E|cheb32_kernel<[^,]+, \d+, false", r["kernel"]):
-            p = poly.setdefault(r["counter"], [0.0, 0])
-            p[0] += float(r["mean_KB"]) * int(r["launches"])
-            p[1] += int(r["launches"])
+            pp = poly.setdefault(r["counter"], [0.0, 0])
+            pp[0] += float(r["mean_KB"]) * int(r["launches"])
+            pp[1] += int(r["launches"])
         for frag, key in names.items():
             if re.search(frag, r["kernel"]):
                 # several rows can match (the polynomial step runs on both levels of the p-multigrid cycle, one row per
-                # grid size): the fine level is the one with the larger traffic
+                # grid size; the SpMV has two instantiations): keep the one with the larger traffic
                 c = acc.setdefault(key, {})
                 c[r["counter"]] = max(c.get(r["counter"], 0.0), float(r["mean_KB"]))
     for key, c in acc.items():
@@ -329,7 +337,7 @@ def load_pmc_traffic():
     if "FETCH_SIZE" in poly and "WRITE_SIZE" in poly and poly["FETCH_SIZE"][1] and poly["WRITE_SIZE"][1]:
         out["poly_step"] = int((2 * poly["FETCH_SIZE"][0] / poly["FETCH_SIZE"][1] +
                                 poly["WRITE_SIZE"][0] / poly["WRITE_SIZE"][1]) * 1024)
-    return out
+    return out, os.path.relpath(path, ROOT)
 
 
 def cpu_baseline(w, args):

@@ -289,11 +289,14 @@ __global__ __launch_bounds__(128) void residual_kernel(ElemView m, Material mat,
         for (int i = 0; i < 3; i++) mr[a][i] += ca * w[i];
       }
     }
-    double* mo = mt.mbuf + (size_t)e * (6 * S) + 3;  // [e][a][6]: force row (written below) | inertia row
+    // [a][Epad][6]: force row (written below) | inertia row -- node-major, so that the lanes of a store (consecutive
+    // elements) write consecutive 48-byte records
 #pragma unroll
-    for (int a = 0; a < S; a++)
+    for (int a = 0; a < S; a++) {
+      double* mo = mt.mbuf + ((size_t)a * m.Epad + e) * 6 + 3;
 #pragma unroll
-      for (int i = 0; i < 3; i++) mo[a * 6 + i] = mr[a][i];
+      for (int i = 0; i < 3; i++) mo[i] = mr[a][i];
+    }
   }
 
 #pragma unroll 1
@@ -382,11 +385,12 @@ __global__ __launch_bounds__(128) void residual_kernel(ElemView m, Material mat,
       }
   }
   if (MASS) {  // one 48-byte record per (element, node) for the gather of grad_light_kernel
-    double* out = mt.mbuf + (size_t)e * (6 * S);
 #pragma unroll
-    for (int a = 0; a < S; a++)
+    for (int a = 0; a < S; a++) {
+      double* out = mt.mbuf + ((size_t)a * m.Epad + e) * 6;
 #pragma unroll
-      for (int i = 0; i < 3; i++) out[a * 6 + i] = f[a][i];
+      for (int i = 0; i < 3; i++) out[i] = f[a][i];
+    }
     return;
   }
   double* out = fbuf + (size_t)e * (3 * S);
@@ -604,7 +608,7 @@ void launch_grad(hipStream_t s, int N, const Incidence& inc, const double* fbuf,
 
 // grad L with the inertia rows of the residual launch (T10): 8 lanes per node gather the node's element rows of f_int
 // and of M (v - v_prev) / h in ascending element order, fixed-order butterfly, then the same epilogue as grad_kernel.
-__global__ __launch_bounds__(256) void grad_light_kernel(int N, Incidence inc, const double* __restrict__ fbuf,
+__global__ __launch_bounds__(256) void grad_light_kernel(int N, int Epad, Incidence inc, const double* __restrict__ fbuf,
                                                         const double* __restrict__ mbuf, const double* __restrict__ f_ext,
                                                         const double* __restrict__ x, const double* __restrict__ y,
                                                         const double* __restrict__ z, const double* __restrict__ xt,
@@ -618,7 +622,8 @@ __global__ __launch_bounds__(256) void grad_light_kernel(int N, Incidence inc, c
   if (i >= N) return;
   double a[6] = {0, 0, 0, 0, 0, 0};  // f[0..2], inertia[0..2]
   for (int k = inc.n2e_off[i] + l8; k < inc.n2e_off[i + 1]; k += 8) {
-    const double2* r = reinterpret_cast<const double2*>(mbuf + (size_t)inc.n2e[k] * 6);  // [e][a][6], 16-byte aligned
+    const int code = inc.n2e[k], e = code / kNN, a = code - kNN * e;
+    const double2* r = reinterpret_cast<const double2*>(mbuf + ((size_t)a * Epad + e) * 6);  // [a][Epad][6], 16-byte aligned
     const double2 r0 = r[0], r1 = r[1], r2 = r[2];
     a[0] += r0.x;
     a[1] += r0.y;
@@ -647,11 +652,11 @@ __global__ __launch_bounds__(256) void grad_light_kernel(int N, Incidence inc, c
   }
 }
 
-void launch_grad_light(hipStream_t s, int N, const Incidence& inc, const double* fbuf, const double* mbuf,
+void launch_grad_light(hipStream_t s, int N, int Epad, const Incidence& inc, const double* fbuf, const double* mbuf,
                        const double* f_ext, const double* x, const double* y, const double* z, const double* xt,
                        const double* yt, const double* zt, const int* fixed_slot, const double* lam, const double* nw,
                        double h, double rho, double* f_int, double* cons, double* g) {
-  hipLaunchKernelGGL(grad_light_kernel, dim3((N + 31) / 32), dim3(256), 0, s, N, inc, fbuf, mbuf, f_ext, x, y, z, xt, yt, zt,
+  hipLaunchKernelGGL(grad_light_kernel, dim3((N + 31) / 32), dim3(256), 0, s, N, Epad, inc, fbuf, mbuf, f_ext, x, y, z, xt, yt, zt,
                      fixed_slot, lam, nw, h, rho, f_int, cons, g);
 }
 

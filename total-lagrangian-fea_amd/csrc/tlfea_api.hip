@@ -1452,7 +1452,7 @@ static bool mass_in_residual(tlfea_newton_t s) {
 }
 static int fill_mass_term(tlfea_newton_t s, MassTerm& mt) {
   tlfea_t10_t d = s->d;
-  if (!s->d_mbuf) TRY(dmalloc(&s->d_mbuf, (size_t)d->E * 6 * d->S));
+  if (!s->d_mbuf) TRY(dmalloc(&s->d_mbuf, (size_t)d->Epad * 6 * d->S));
   mt.vprev = s->d_vprev;
   mt.mbuf = s->d_mbuf;
   mt.rho_inv_h = d->mass_rho0 / s->prm.time_step;
@@ -1482,7 +1482,7 @@ static int eval_gradient(tlfea_newton_t s, double* norm_g) {
     StageTimer t(s, 1);
     const bool pinned = pinned_on(s);
     if (mir)
-      launch_grad_light(s->stream, s->N, d->inc(), d->d_fbuf, s->d_mbuf, d->d_fext, d->d_x, d->d_y, d->d_z, d->d_xt,
+      launch_grad_light(s->stream, s->N, d->Epad, d->inc(), d->d_fbuf, s->d_mbuf, d->d_fext, d->d_x, d->d_y, d->d_z, d->d_xt,
                         d->d_yt, d->d_zt, pinned ? d->d_fixed_slot : nullptr, s->d_lam, s->d_nw, p.time_step, p.rho,
                         d->d_fint, d->d_cons, s->d_g);
     else

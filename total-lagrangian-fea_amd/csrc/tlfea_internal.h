@@ -48,7 +48,7 @@ struct ElemView {
 // velocities: Nq = shape functions at the 5 Keast points, rho = the density the mass matrix was assembled with.
 struct MassTerm {
   const double* vprev;   // null: no mass term (mbuf is not written)
-  double* mbuf;          // [E][10][6] per (element, node): force row | inertia row (replaces fbuf on this path)
+  double* mbuf;          // [10][Epad][6] per (node, element): force row | inertia row (replaces fbuf on this path)
   double rho_inv_h;      // rho0 / h
   double Nq[kNQ][kNN];
 };
@@ -90,7 +90,7 @@ void launch_residual(hipStream_t s, const ElemView& m, const Material& mat, cons
                      double* Fq = nullptr /*[Q][E][9] row-major F per point, for the fused assembly*/,
                      const MassTerm* mt = nullptr /*T10: also write the per-element inertia rows*/);
 // grad L without the mass CSR product (T10, inertia rows from the residual launch): 8 lanes per node
-void launch_grad_light(hipStream_t s, int N, const Incidence& inc, const double* fbuf, const double* mbuf,
+void launch_grad_light(hipStream_t s, int N, int Epad, const Incidence& inc, const double* fbuf, const double* mbuf,
                        const double* f_ext, const double* x, const double* y, const double* z, const double* xt,
                        const double* yt, const double* zt, const int* fixed_slot, const double* lam, const double* nw,
                        double h, double rho, double* f_int, double* cons, double* g);
