@@ -622,8 +622,8 @@ __global__ __launch_bounds__(256) void grad_light_kernel(int N, int Epad, Incide
   if (i >= N) return;
   double a[6] = {0, 0, 0, 0, 0, 0};  // f[0..2], inertia[0..2]
   for (int k = inc.n2e_off[i] + l8; k < inc.n2e_off[i + 1]; k += 8) {
-    const int code = inc.n2e[k], e = code / kNN, a = code - kNN * e;
-    const double2* r = reinterpret_cast<const double2*>(mbuf + ((size_t)a * Epad + e) * 6);  // [a][Epad][6], 16-byte aligned
+    const int code = inc.n2e[k], e = code / kNN, la = code - kNN * e;
+    const double2* r = reinterpret_cast<const double2*>(mbuf + ((size_t)la * Epad + e) * 6);  // [a][Epad][6], 16-byte aligned
     const double2 r0 = r[0], r1 = r[1], r2 = r[2];
     a[0] += r0.x;
     a[1] += r0.y;
