@@ -69,10 +69,10 @@ def main():
                          "(clock ramp / first-touch events of a fresh process), then the state is reset")
     ap.add_argument("--local-precond", action="store_true",
                     help="multi-GPU: rank-local polynomial preconditioner (fewer collectives, 3-4x more CG iterations)")
-    ap.add_argument("--native-rccl", action="store_true",
-                    help="multi-GPU: the engine's built-in RCCL all-reduce (enqueued from C++, ~1.6 us of host time per "
-                         "exchange instead of ~15-29 us through torch.distributed); validated with one rank only so far, "
-                         "hence opt-in (also TLFEA_BENCH_NATIVE_RCCL=1)")
+    ap.add_argument("--torch-collectives", action="store_true",
+                    help="multi-GPU: exchange through the torch.distributed callback (~15-29 us of host time per collective) "
+                         "instead of the engine's built-in RCCL all-reduce (enqueued from C++ on the solver's stream, ~1.6 us; "
+                         "the default with the nccl backend; falls back to the callback if its communicator cannot be built)")
     ap.add_argument("--precond", type=int, default=0, choices=(0, 1, 2),
                     help="0 auto, 1 Chebyshev polynomial, 2 two-level p-multigrid (T10, one GPU)")
     ap.add_argument("--cheb-kappa", type=float, default=0.0, help="polynomial interval [lmax/kappa, lmax] (0 = default)")
@@ -137,8 +137,24 @@ def main():
     s.SetLinSolveOpts(tl.LinSolveOpts(args.rel_tol, args.max_pcg, 25, args.cheb_deg, args.cheb_kappa, args.cheb_bits,
                                       args.precond, 0, int(args.max_pcg != 50000)))
     if world > 1:
-        native = args.native_rccl or bool(os.environ.get("TLFEA_BENCH_NATIVE_RCCL"))
-        comm = par.rccl_communicator(dist, rank, world) if (native and backend == "nccl") else None
+        comm = None
+        if backend == "nccl" and not args.torch_collectives and not os.environ.get("TLFEA_BENCH_TORCH_COLLECTIVES"):
+            # every rank must take the same path: agree on whether ALL ranks built their communicator
+            # (probe first -- resolving RCCL inside the engine -- so that no rank waits in ncclCommInitRank for a peer that
+            # never joins)
+            try:
+                import ctypes
+                binding = import_module("total-lagrangian-fea_amd.binding")
+                probe_ok = binding.load_library().tlfea_rccl_unique_id(ctypes.create_string_buffer(128)) == 0
+            except Exception:   # noqa: BLE001
+                probe_ok = False
+            okf = torch.tensor([1 if probe_ok else 0], device="cuda")
+            dist.all_reduce(okf, op=dist.ReduceOp.MIN)
+            if int(okf.item()) == 1:
+                comm = par.rccl_communicator(dist, rank, world)
+            elif rank == 0:
+                print("built-in RCCL exchange unavailable on some rank, using the torch.distributed callback", file=sys.stderr)
+        exchange_path = "built-in RCCL (C++)" if comm is not None else f"torch.distributed callback ({backend})"
         par.attach(s, part, torch, dist, local_preconditioner=args.local_precond, native_rccl=comm)
     d.UpdatePositions(w["x0"][:, 0], w["x0"][:, 1], w["x0"][:, 2])
     E, N = w["conn"].shape[0], w["X"].shape[0]
@@ -177,10 +193,12 @@ def main():
         step_ms.clear()
     run(args.warmup)
     barrier()
+    c0 = s.Collectives()
     t0 = time.perf_counter()
     pcg_its = run(args.steps, args.warmup)
     barrier()
     dt = time.perf_counter() - t0
+    n_coll = s.Collectives() - c0
     lin_status = s.GetLinSolveStatus()
     if world > 1:
         t = torch.tensor([dt], device="cuda" if backend == "nccl" else "cpu", dtype=torch.float64)
@@ -264,6 +282,8 @@ def main():
                                f"implicit Newton iteration incl. PCG solve (rel_tol {args.rel_tol:g})",
                    "elements_per_gpu": E, "nodes_per_gpu": N, "hessian_nnz": 9 * nnz_coef,
                    "pcg_outer_iters_per_step": round(float(np.mean(pcg_its)), 1),
+                   **({"exchange": exchange_path, "collectives_per_cg_iteration":
+                       round(n_coll / max(1.0, float(np.sum(pcg_its))), 1)} if world > 1 else {}),
                    "last_solve_rel_residual": float(lin_status["rel_res"]), "last_solve_converged": lin_status["converged"],
                    "preconditioner": ("block-Jacobi (3x3)" if deg_eff <= 1 else
                                       (f"two-level p-multigrid V-cycle (T10 -> vertex mesh, {pmg[0]} coarse nodes, Galerkin "

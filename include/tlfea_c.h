@@ -227,6 +227,8 @@ int tlfea_newton_retrieve_lambda(tlfea_newton_t s, double *lam /*n_constraints*/
 /* stats of the last tlfea_newton_solve(): [0] outer iterations, [1] Newton solves, [2] last ||g||,
  * [3] last ||c||, [4] total PCG iterations, [5] device ms of the step (hipEvent) */
 int tlfea_newton_get_stats(tlfea_newton_t s, double *stats6);
+/* all-reduce calls the solver has issued since it was built (any exchange path); multi-GPU tests divide by CG iterations */
+long tlfea_newton_collectives(tlfea_newton_t s);
 /* number of multipliers the solver holds now (follows the data object's count at the start of every solve: an
  * UpdateNodalFixed with another size restarts them from zero) */
 int tlfea_newton_n_constraints(tlfea_newton_t s);

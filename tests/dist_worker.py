@@ -200,7 +200,8 @@ def main():
             st = s.GetStats()
             counts.append((st["outer"], st["newton"]))
             pcg_iters += int(st["pcg_iters"])
-        n_collectives = s.n_collectives
+        n_collectives = s.Collectives()
+        precond = s.GetPreconditioner()
         x_loc = np.stack(d.RetrievePositionToCPU(), axis=1)
         del s
         d.Destroy()
@@ -233,7 +234,8 @@ def main():
         report = dict(err=err, disp=disp, max_dup=max_dup, counts=counts, ref_counts=ref_counts, ok=ok,
                       n_iface=part.n_global_iface)
         if args.engine != "oracle":
-            report.update(collectives=n_collectives, pcg_iters=pcg_iters)
+            report.update(collectives=n_collectives, pcg_iters=pcg_iters, precond=precond,
+                          newton=int(sum(c[1] for c in counts)))
         print(json.dumps(report), flush=True)
         if args.out:
             json.dump(report, open(args.out, "w"))

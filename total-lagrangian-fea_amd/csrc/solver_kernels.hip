@@ -867,7 +867,7 @@ __global__ __launch_bounds__(TPB) void cheb32_kernel(int N, Incidence inc, const
                                                      const float* __restrict__ z, float* __restrict__ z_new,
                                                      const float* __restrict__ res, float* __restrict__ res_new,
                                                      const double* __restrict__ r, double* __restrict__ z_out,
-                                                     double* __restrict__ rz_part) {
+                                                     double* __restrict__ rz_part, C32Bnd bnd) {
   __shared__ double sh[32];
   const float c1 = (float)coef[0], c2 = (float)coef[1];
   constexpr int G = TPB / L;
@@ -962,8 +962,16 @@ __global__ __launch_bounds__(TPB) void cheb32_kernel(int N, Incidence inc, const
       for (int w = 0; w < 2; w++) {
         if (w == 1 && !two) break;
         const int iw = w ? iB : iA;
-        const float e0 = (w ? eB0 : eA0) - (w ? sB0 : sA0), e1 = (w ? eB1 : eA1) - (w ? sB1 : sA1),
-                    e2 = (w ? eB2 : eA2) - (w ? sB2 : sA2);
+        float t0 = w ? sB0 : sA0, t1 = w ? sB1 : sA1, t2 = w ? sB2 : sA2;
+        if (bnd.bslot) {  // multi-GPU: a partition-boundary row takes the sum over ranks of its partial rows
+          const int sl = bnd.bslot[iw];
+          if (sl >= 0) {
+            t0 = (float)bnd.bsum[3 * sl];
+            t1 = (float)bnd.bsum[3 * sl + 1];
+            t2 = (float)bnd.bsum[3 * sl + 2];
+          }
+        }
+        const float e0 = (w ? eB0 : eA0) - t0, e1 = (w ? eB1 : eA1) - t1, e2 = (w ? eB2 : eA2) - t2;
         const float dn = c1 * (w ? dcB : dcA) +
                          c2 * ((w ? DB0 : DA0) * e0 + (w ? DB1 : DA1) * e1 + (w ? DB2 : DA2) * e2);
         const float zn = (w ? zcB : zcA) + dn;
@@ -971,7 +979,7 @@ __global__ __launch_bounds__(TPB) void cheb32_kernel(int N, Incidence inc, const
         if (LAST) {
           const double zt = sc[3 * iw + c] * (double)zn;
           z_out[3 * iw + c] = zt;
-          rz += r[3 * iw + c] * zt;
+          rz += (bnd.w ? bnd.w[3 * iw + c] : 1.0) * r[3 * iw + c] * zt;
         } else {
           z_new[3 * iw + c] = zn;
           res_new[3 * iw + c] = (c == 0) ? e0 : ((c == 1) ? e1 : e2);
@@ -1005,8 +1013,8 @@ template <typename T, int LL>
 static void launch_cheb32_t(hipStream_t s, int N, const Incidence& inc, const void* B8, const void* B1,
                             const float* Dinv_f, const double* sc, const float* d_old, const double* coef,
                             float* d_new, const float* z, float* z_new, const float* res, float* res_new,
-                            const double* r, double* z_out, double* rz_part, bool last) {
-#define TLFEA_C32_ARGS N, inc, (const Blk8<T>*)B8, (const T*)B1, Dinv_f, sc, d_old, coef, d_new, z, z_new, res, res_new, r, z_out, rz_part
+                            const double* r, double* z_out, double* rz_part, bool last, C32Bnd bnd) {
+#define TLFEA_C32_ARGS N, inc, (const Blk8<T>*)B8, (const T*)B1, Dinv_f, sc, d_old, coef, d_new, z, z_new, res, res_new, r, z_out, rz_part, bnd
   if (last) {
     constexpr int TPB = 1024, G = TPB / LL;
     const dim3 g(std::max(1, std::min(kNPart, (N + G - 1) / G))), b(TPB);
@@ -1027,7 +1035,7 @@ static void launch_cheb32_t(hipStream_t s, int N, const Incidence& inc, const vo
 void launch_cheb32(hipStream_t s, int N, int nnz_coef, const Incidence& inc, const void* B8, const void* B1, int bits,
                    const float* Dinv_f, const double* sc, const float* d_old, const double* coef, float* d_new,
                    const float* z, float* z_new, const float* res, float* res_new, const double* r, double* z_out,
-                   double* rz_part, bool last) {
+                   double* rz_part, bool last, C32Bnd bnd) {
   // lanes per row: two blocks per lane and round; the vertex level of the p-multigrid cycle has ~15 blocks per row
   // (8 lanes hold them in one round with every lane busy), quadratic tets ~30 (16 lanes), the ANCF shells 100+ (32)
   static const int forced = std::getenv("TLFEA_C32_LANES") ? std::atoi(std::getenv("TLFEA_C32_LANES")) : 0;
@@ -1035,7 +1043,7 @@ void launch_cheb32(hipStream_t s, int N, int nnz_coef, const Incidence& inc, con
   int L = lp_lanes(N, nnz_coef) >= 32 ? 32 : (avg <= 18.0 ? 8 : 16);
   if (forced == 8 || forced == 16 || forced == 32) L = forced;
 #define TLFEA_C32(T, LL) \
-  launch_cheb32_t<T, LL>(s, N, inc, B8, B1, Dinv_f, sc, d_old, coef, d_new, z, z_new, res, res_new, r, z_out, rz_part, last)
+  launch_cheb32_t<T, LL>(s, N, inc, B8, B1, Dinv_f, sc, d_old, coef, d_new, z, z_new, res, res_new, r, z_out, rz_part, last, bnd)
   if (bits == 16) {
     if (L == 32) TLFEA_C32(_Float16, 32);
     else if (L == 8) TLFEA_C32(_Float16, 8);
@@ -1046,6 +1054,48 @@ void launch_cheb32(hipStream_t s, int N, int nnz_coef, const Incidence& inc, con
     else TLFEA_C32(float, 16);
   }
 #undef TLFEA_C32
+}
+
+// Multi-GPU: this rank's part of (Hs d) on a list of rows (the partition-boundary rows), 16 lanes per row, written
+// as doubles straight into the exchange buffer (slot order agreed by all ranks); the fused step then reads the sum.
+template <typename HT>
+__global__ __launch_bounds__(256) void spmv32_rows_kernel(int n_rows, const int* __restrict__ rows,
+                                                         const int* __restrict__ slots, Incidence inc,
+                                                         const Blk8<HT>* __restrict__ B8, const HT* __restrict__ B1,
+                                                         const float* __restrict__ d, double* __restrict__ out) {
+  const int lane = threadIdx.x & 15;
+  const int k = blockIdx.x * 16 + (threadIdx.x >> 4);
+  if (k >= n_rows) return;
+  const int i = rows[k], base = inc.off[i], deg = inc.off[i + 1] - base;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+  for (int t = lane; t < deg; t += 16) {
+    const int g = base + t;
+    const Blk8<HT> a = B8[g];
+    const HT a8 = B1[g];
+    const float* x = d + 3 * (size_t)inc.cols[g];
+    const float x0 = x[0], x1 = x[1], x2 = x[2];
+    s0 += (float)a.v[0] * x0 + (float)a.v[1] * x1 + (float)a.v[2] * x2;
+    s1 += (float)a.v[3] * x0 + (float)a.v[4] * x1 + (float)a.v[5] * x2;
+    s2 += (float)a.v[6] * x0 + (float)a.v[7] * x1 + (float)a8 * x2;
+  }
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) {
+    s0 += __shfl_xor(s0, o);
+    s1 += __shfl_xor(s1, o);
+    s2 += __shfl_xor(s2, o);
+  }
+  if (lane < 3) out[3 * (size_t)slots[k] + lane] = (double)(lane == 0 ? s0 : (lane == 1 ? s1 : s2));
+}
+void launch_spmv32_rows(hipStream_t s, int n_rows, const int* rows, const int* slots, const Incidence& inc, const void* B8,
+                        const void* B1, int bits, const float* d, double* out) {
+  if (n_rows <= 0) return;
+  const dim3 g((n_rows + 15) / 16), b(256);
+  if (bits == 16)
+    hipLaunchKernelGGL(spmv32_rows_kernel<_Float16>, g, b, 0, s, n_rows, rows, slots, inc, (const Blk8<_Float16>*)B8,
+                       (const _Float16*)B1, d, out);
+  else
+    hipLaunchKernelGGL(spmv32_rows_kernel<float>, g, b, 0, s, n_rows, rows, slots, inc, (const Blk8<float>*)B8,
+                       (const float*)B1, d, out);
 }
 
 // ---- two-level p-multigrid for T10 (pmg_host.h): Galerkin coarse operator and grid transfers ----------------
@@ -1099,7 +1149,7 @@ __global__ __launch_bounds__(256) void pmg_restrict_init_kernel(
     int Nc, const int* __restrict__ child_off, const int* __restrict__ child, const float* __restrict__ child_w,
     const float* __restrict__ res_f, const double* __restrict__ sc_f, const double* __restrict__ sc_c,
     const float* __restrict__ Dinv_c, const double* __restrict__ coef_c, float* __restrict__ d_c,
-    float* __restrict__ z_c, float* __restrict__ res_c) {
+    float* __restrict__ z_c, float* __restrict__ res_c, const int* __restrict__ bslot, const double* __restrict__ bsum) {
   // 16 lanes per coarse node: the ~15 children are loaded in parallel and summed by a fixed-order butterfly
   const int lane = threadIdx.x & 15;
   const int I = blockIdx.x * 16 + (threadIdx.x >> 4);
@@ -1118,6 +1168,12 @@ __global__ __launch_bounds__(256) void pmg_restrict_init_kernel(
     r[2] += __shfl_xor(r[2], o);
   }
   if (lane >= 3) return;
+  if (bslot && bslot[I] >= 0) {  // multi-GPU: a partition-boundary coarse node takes the sum over ranks (restrict_rows)
+    const double* b = bsum + 3 * (size_t)bslot[I];
+    r[0] = b[0];
+    r[1] = b[1];
+    r[2] = b[2];
+  }
   const int c = lane;
   const float inv_theta = (float)coef_c[0];
   const float rs0 = (float)(r[0] * sc_c[3 * I]), rs1 = (float)(r[1] * sc_c[3 * I + 1]), rs2 = (float)(r[2] * sc_c[3 * I + 2]);
@@ -1129,9 +1185,42 @@ __global__ __launch_bounds__(256) void pmg_restrict_init_kernel(
 }
 void launch_pmg_restrict_init(hipStream_t s, int Nc, const int* child_off, const int* child, const float* child_w,
                               const float* res_f, const double* sc_f, const double* sc_c, const float* Dinv_c,
-                              const double* coef_c, float* d_c, float* z_c, float* res_c) {
+                              const double* coef_c, float* d_c, float* z_c, float* res_c, const int* bslot,
+                              const double* bsum) {
   hipLaunchKernelGGL(pmg_restrict_init_kernel, dim3((Nc + 15) / 16), dim3(256), 0, s, Nc, child_off, child, child_w,
-                     res_f, sc_f, sc_c, Dinv_c, coef_c, d_c, z_c, res_c);
+                     res_f, sc_f, sc_c, Dinv_c, coef_c, d_c, z_c, res_c, bslot, bsum);
+}
+__global__ __launch_bounds__(256) void pmg_restrict_rows_kernel(int n_rows, const int* __restrict__ rows,
+                                                               const int* __restrict__ slots,
+                                                               const int* __restrict__ child_off,
+                                                               const int* __restrict__ child,
+                                                               const float* __restrict__ child_w,
+                                                               const float* __restrict__ res_f,
+                                                               const double* __restrict__ sc_f, double* __restrict__ out) {
+  const int lane = threadIdx.x & 15;
+  const int k = blockIdx.x * 16 + (threadIdx.x >> 4);
+  if (k >= n_rows) return;
+  const int I = rows[k];
+  double r[3] = {0.0, 0.0, 0.0};
+  for (int t = child_off[I] + lane; t < child_off[I + 1]; t += 16) {
+    const int n = child[t];
+    const double w = (double)child_w[t];
+#pragma unroll
+    for (int c = 0; c < 3; c++) r[c] += w * (double)res_f[3 * n + c] / sc_f[3 * n + c];
+  }
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) {
+    r[0] += __shfl_xor(r[0], o);
+    r[1] += __shfl_xor(r[1], o);
+    r[2] += __shfl_xor(r[2], o);
+  }
+  if (lane < 3) out[3 * (size_t)slots[k] + lane] = lane == 0 ? r[0] : (lane == 1 ? r[1] : r[2]);
+}
+void launch_pmg_restrict_rows(hipStream_t s, int n_rows, const int* rows, const int* slots, const int* child_off,
+                              const int* child, const float* child_w, const float* res_f, const double* sc_f, double* out) {
+  if (n_rows <= 0) return;
+  hipLaunchKernelGGL(pmg_restrict_rows_kernel, dim3((n_rows + 15) / 16), dim3(256), 0, s, n_rows, rows, slots, child_off,
+                     child, child_w, res_f, sc_f, out);
 }
 
 // Prolongation of the coarse correction:  corr^ = S_f^-1 P S_c z^_c ;  z^ += corr^ ;  d := corr^ (the next fine step

@@ -912,6 +912,14 @@ struct tlfea_newton_s {
     float* d_f32c = nullptr;   // coarse d, z^, res^ ping-pong pairs (6 x 3Nc) + (S D S)^-1 (9 Nc)
     double* d_coef = nullptr;  // [0..7] fine smoother, [8..] coarse polynomial
     double lam_c = 0.0;
+    // multi-GPU: the coarse level is partitioned like the fine one (vertex nodes of the partition boundary are
+    // replicated); slots of the coarse exchange buffer are agreed once (pmg_prepare), child weights carry 1/multiplicity
+    int n_ifc_loc = 0, n_ifc_glob = 0;
+    int Nc_glob = 0;                  // coarse nodes over all ranks: what the coarse polynomial's degree goes by (every
+                                      // rank must run the same number of steps -- each is a collective)
+    int *d_ifc_node = nullptr, *d_ifc_slot = nullptr, *d_bslot_c = nullptr;
+    double* d_wc3 = nullptr;          // [3 Nc] 1/multiplicity of the coarse DOFs
+    float* d_child_w_dist = nullptr;  // child weights x 1/multiplicity of the child
     // the coarse polynomial's degree is a size-based guess (fitted on configs B, C); when a solve stalls because the
     // vertex-level operator is worse conditioned than the guess covers (a 5 x 3.3 x 1.7 bar of 4.5 M elements needs
     // degree ~50 where the guess says 39), the solver raises it for this and all later solves
@@ -977,6 +985,10 @@ struct tlfea_newton_s {
   // multi-GPU interface
   int n_if_loc = 0, n_if_glob = 0;  // local interface nodes / slots of the global exchange buffer
   int *d_if_node = nullptr, *d_if_slot = nullptr;
+  int* d_bslot_f = nullptr;         // [N] exchange slot of a partition-boundary node, -1 inside
+  std::vector<int> h_if_node, h_if_slot;
+  std::vector<double> h_nw;
+  long n_collectives = 0;           // all-reduce calls since the solver was built (tests: collectives per CG iteration)
   double *d_ibuf = nullptr, *d_w = nullptr, *d_nw = nullptr, *d_wc = nullptr, *d_D = nullptr;
   // rank-local polynomial preconditioner (multi-GPU): 1 for the nodes this rank owns (every replicated node has
   // exactly one owner), and the scaling vector masked by it
@@ -1049,6 +1061,9 @@ extern "C" int tlfea_newton_destroy(tlfea_newton_t s) {
   cg_graphs_destroy(s);
   {
     auto& m = s->pmg;
+    void* pd[] = {m.d_ifc_node, m.d_ifc_slot, m.d_bslot_c, m.d_wc3, m.d_child_w_dist, s->d_bslot_f};
+    for (void* q : pd)
+      if (q) (void)hipFree(q);
     void* pp[] = {m.d_par0, m.d_par1, m.d_c_off, m.d_c_cols, m.d_c_diagpos, m.d_cblk_row, m.d_child_off, m.d_child,
                   m.d_con_off, m.d_con_base, m.d_con_deg, m.d_child_w, m.d_con_w, m.d_Hc, m.d_Dc, m.d_Dinv_c, m.d_sc_c,
                   m.d_Dinv_s_c, m.d_eigv_c, m.d_q_c, m.d_p_c, m.d_B8c, m.d_B1c, m.d_f32c, m.d_coef};
@@ -1182,6 +1197,9 @@ extern "C" int tlfea_newton_set_interface(tlfea_newton_t s, const int* iface_nod
       (void)hipFree(*p);
       *p = nullptr;
     }
+  if (s->pmg.tried)
+    return fail("tlfea_newton_set_interface: set the interface before the first linear solve (the p-multigrid hierarchy "
+                "is partitioned with it)");
   s->n_if_loc = n_local;
   s->n_if_glob = n_global;
   s->ar = fn;
@@ -1210,6 +1228,16 @@ extern "C" int tlfea_newton_set_interface(tlfea_newton_t s, const int* iface_nod
   if (n_local) {
     HIP_TRY(hipMemcpy(s->d_if_node, iface_nodes, (size_t)n_local * sizeof(int), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(s->d_if_slot, iface_slots, (size_t)n_local * sizeof(int), hipMemcpyHostToDevice));
+  }
+  s->h_if_node.assign(iface_nodes, iface_nodes + n_local);
+  s->h_if_slot.assign(iface_slots, iface_slots + n_local);
+  s->h_nw.assign(node_weight, node_weight + N);
+  {
+    std::vector<int> bs(N, -1);
+    for (int k = 0; k < n_local; k++) bs[iface_nodes[k]] = iface_slots[k];
+    if (s->d_bslot_f) (void)hipFree(s->d_bslot_f);
+    TRY(dmalloc(&s->d_bslot_f, N));
+    HIP_TRY(hipMemcpy(s->d_bslot_f, bs.data(), N * sizeof(int), hipMemcpyHostToDevice));
   }
   std::vector<double> w3(3 * N);
   for (size_t i = 0; i < N; i++) w3[3 * i] = w3[3 * i + 1] = w3[3 * i + 2] = node_weight[i];
@@ -1317,6 +1345,7 @@ extern "C" int tlfea_newton_set_interface_owners(tlfea_newton_t s, const int* ow
 }
 
 static int call_allreduce(tlfea_newton_t s, double* d_buf, int n) {
+  s->n_collectives++;
   if (s->sync_before_cb) HIP_TRY(hipStreamSynchronize(s->stream));
   if (s->ar(s->ar_user, d_buf, n)) return fail("interface all-reduce callback failed");
   return 0;
@@ -1324,12 +1353,19 @@ static int call_allreduce(tlfea_newton_t s, double* d_buf, int n) {
 
 // Sum over ranks of the partition-boundary entries of a nodal field with `dim` values per node (3 for
 // vectors, 9 for diagonal blocks), optionally fused with `n_extra` reduction slots (one collective).
+static int iface_sum_lvl(tlfea_newton_t s, int n_loc, int n_glob, const int* d_node, const int* d_slot, double* d_vec,
+                         int dim, double* d_extra = nullptr, int n_extra = 0, double* d_extra2 = nullptr);
 static int iface_sum(tlfea_newton_t s, double* d_vec, int dim, double* d_extra = nullptr, int n_extra = 0,
                      double* d_extra2 = nullptr) {
+  return iface_sum_lvl(s, s->n_if_loc, s->n_if_glob, s->d_if_node, s->d_if_slot, d_vec, dim, d_extra, n_extra, d_extra2);
+}
+// the same for any level of the multigrid hierarchy (its own boundary node / slot lists)
+static int iface_sum_lvl(tlfea_newton_t s, int n_if_loc, int n_if_glob, const int* d_if_node, const int* d_if_slot,
+                         double* d_vec, int dim, double* d_extra, int n_extra, double* d_extra2) {
   if (!s->ar) return 0;
-  const int nb = dim * s->n_if_glob;
+  const int nb = dim * n_if_glob;
   if (nb) HIP_TRY(hipMemsetAsync(s->d_ibuf, 0, (size_t)nb * sizeof(double), s->stream));
-  launch_pack(s->stream, s->n_if_loc, dim, s->d_if_node, s->d_if_slot, d_vec, s->d_ibuf);
+  launch_pack(s->stream, n_if_loc, dim, d_if_node, d_if_slot, d_vec, s->d_ibuf);
   int total = nb;
   if (d_extra) {
     HIP_TRY(hipMemcpyAsync(s->d_ibuf + total, d_extra, (size_t)n_extra * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
@@ -1341,7 +1377,7 @@ static int iface_sum(tlfea_newton_t s, double* d_vec, int dim, double* d_extra =
   }
   if (total == 0) return 0;
   TRY(call_allreduce(s, s->d_ibuf, total));
-  launch_unpack(s->stream, s->n_if_loc, dim, s->d_if_node, s->d_if_slot, s->d_ibuf, d_vec);
+  launch_unpack(s->stream, n_if_loc, dim, d_if_node, d_if_slot, s->d_ibuf, d_vec);
   int o = nb;
   if (d_extra) {
     HIP_TRY(hipMemcpyAsync(d_extra, s->d_ibuf + o, (size_t)n_extra * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
@@ -1566,6 +1602,7 @@ static int cheb_bits_eff(tlfea_newton_t s) {
 }
 
 // (re)build the low-precision copy from the current H and block diagonal (d_D, d_Dinv must be current)
+static int precond_eff(tlfea_newton_t s);
 static int lp_build(tlfea_newton_t s) {
   tlfea_t10_t d = s->d;
   const int bits = cheb_bits_eff(s);
@@ -1584,7 +1621,8 @@ static int lp_build(tlfea_newton_t s) {
   launch_lp_convert(s->stream, s->N, d->inc(), s->d_H, s->d_sc, local ? s->d_own : nullptr, s->d_D, s->d_B8, s->d_B1,
                     bits);
   if (local) launch_mask_scale(s->stream, s->N, s->d_sc, s->d_own, s->d_sc_mask);
-  if (!s->ar || local) launch_to_float(s->stream, (size_t)9 * s->N, s->d_Dinv_s, s->d_f32 + (size_t)18 * s->N);
+  if (!s->ar || local || precond_eff(s) == 2)
+    launch_to_float(s->stream, (size_t)9 * s->N, s->d_Dinv_s, s->d_f32 + (size_t)18 * s->N);
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -1762,7 +1800,7 @@ static double pmg_kappa_coarse(int kc) {
   return forced > 1.0 ? forced : 1.5 * kc * kc;
 }
 static int pmg_coarse_degree_eff(tlfea_newton_t s) {
-  const int base = pmg_coarse_degree(s->pmg.Nc);
+  const int base = pmg_coarse_degree((s->ar && s->pmg.Nc_glob > 0) ? s->pmg.Nc_glob : s->pmg.Nc);
   return std::min(kPmgMaxCoarseDeg, (int)std::lround(base * s->pmg.kc_boost));
 }
 static const double kPmgKappaS = std::getenv("TLFEA_PMG_KAPPA_S") ? std::atof(std::getenv("TLFEA_PMG_KAPPA_S")) : 8.0;
@@ -1801,7 +1839,7 @@ static int upload_vec(T** dst, const std::vector<T>& v) {
 static int precond_eff(tlfea_newton_t s) {
   if (s->lin.precond == 1) return 1;
   tlfea_t10_t d = s->d;
-  const bool possible = d->kind == kT10 && !s->ar && d->cons_mode != 2 && cheb_degree_eff(s) > 1 &&
+  const bool possible = d->kind == kT10 && !(s->ar && s->d_own) && d->cons_mode != 2 && cheb_degree_eff(s) > 1 &&
                         cheb_bits_eff(s) != 64 && !(s->pmg.tried && !s->pmg.ok);
   return possible ? 2 : 1;
 }
@@ -1833,6 +1871,59 @@ static int pmg_prepare(tlfea_newton_t s) {
   TRY(dmalloc(&m.d_coef, (size_t)8 + 2 * kPmgMaxCoarseDeg));
   m.ok = true;
   if (s->verbose) std::printf("p-multigrid: %d fine nodes -> %d vertex nodes, %d coarse blocks\n", d->N, m.Nc, m.nnz_c);
+  if (s->ar) {
+    // Multi-GPU: the coarse level inherits the partition.  A vertex node on the partition boundary is a coarse node
+    // replicated on the same ranks; every rank flags the exchange slots of ITS boundary vertices, the flags are summed
+    // once, and the flagged slots numbered in ascending order give all ranks the same coarse slot numbering.
+    const int ng = s->n_if_glob, nl = s->n_if_loc;
+    std::vector<double> flag((size_t)std::max(1, ng), 0.0);
+    for (int k = 0; k < nl; k++) {
+      const int n = s->h_if_node[k];
+      if (h.par0[n] == h.par1[n]) flag[s->h_if_slot[k]] = 1.0;
+    }
+    HIP_TRY(hipMemcpy(s->d_ibuf, flag.data(), flag.size() * sizeof(double), hipMemcpyHostToDevice));
+    if (ng > 0) {
+      TRY(call_allreduce(s, s->d_ibuf, ng));
+      HIP_TRY(hipStreamSynchronize(s->stream));
+    }
+    HIP_TRY(hipMemcpy(flag.data(), s->d_ibuf, flag.size() * sizeof(double), hipMemcpyDeviceToHost));
+    std::vector<int> cslot((size_t)std::max(1, ng), -1);
+    int nc_glob = 0;
+    for (int t = 0; t < ng; t++)
+      if (flag[t] > 0.5) cslot[t] = nc_glob++;
+    std::vector<int> cn, cs, bs((size_t)m.Nc, -1);
+    for (int k = 0; k < nl; k++) {
+      const int n = s->h_if_node[k];
+      if (h.par0[n] != h.par1[n]) continue;
+      const int I = h.par0[n];
+      cn.push_back(I);
+      cs.push_back(cslot[s->h_if_slot[k]]);
+      bs[I] = cslot[s->h_if_slot[k]];
+    }
+    m.n_ifc_loc = (int)cn.size();
+    m.n_ifc_glob = nc_glob;
+    if (cn.empty()) { cn.push_back(0); cs.push_back(0); }
+    TRY(upload_vec(&m.d_ifc_node, cn)); TRY(upload_vec(&m.d_ifc_slot, cs)); TRY(upload_vec(&m.d_bslot_c, bs));
+    std::vector<double> wc3(nc);
+    for (int I = 0; I < m.Nc; I++) {
+      const double w = s->h_nw[h.child[h.child_off[I]]];  // the vertex itself is its first child
+      wc3[3 * (size_t)I] = wc3[3 * (size_t)I + 1] = wc3[3 * (size_t)I + 2] = w;
+    }
+    TRY(upload_vec(&m.d_wc3, wc3));
+    {
+      double cnt = 0.0;
+      for (int I = 0; I < m.Nc; I++) cnt += wc3[3 * (size_t)I];
+      HIP_TRY(hipMemcpy(s->d_ibuf, &cnt, sizeof(double), hipMemcpyHostToDevice));
+      TRY(call_allreduce(s, s->d_ibuf, 1));
+      HIP_TRY(hipStreamSynchronize(s->stream));
+      HIP_TRY(hipMemcpy(&cnt, s->d_ibuf, sizeof(double), hipMemcpyDeviceToHost));
+      m.Nc_glob = (int)std::lround(cnt);
+    }
+    std::vector<float> cw(h.child_w);
+    for (size_t t = 0; t < cw.size(); t++) cw[t] = (float)(cw[t] * s->h_nw[h.child[t]]);
+    TRY(upload_vec(&m.d_child_w_dist, cw));
+    if (s->verbose) std::printf("p-multigrid: partitioned coarse level, %d of %d boundary vertices on this rank\n", m.n_ifc_loc, nc_glob);
+  }
   if (pmg_levels_wanted(m.Nc) == 3) {
     // reference coordinates of the vertex nodes (slot 0 of a coarse node's children is the vertex itself)
     std::vector<double> xf((size_t)3 * d->N), Xv((size_t)3 * m.Nc);
@@ -1883,6 +1974,8 @@ static int pmg_build_level(tlfea_newton_t s) {
   }
   const Incidence ic = m.inc();
   launch_extract_diag(s->stream, m.Nc, ic, m.d_Hc, m.d_Dc);
+  // multi-GPU: Hc = sum over ranks of P^T H_r P -- the diagonal blocks of boundary vertices are partial per rank
+  if (s->ar) TRY(iface_sum_lvl(s, m.n_ifc_loc, m.n_ifc_glob, m.d_ifc_node, m.d_ifc_slot, m.d_Dc, 9));
   launch_invert_diag(s->stream, m.Nc, m.d_Dc, m.d_Dinv_c);
   launch_lp_scale(s->stream, m.Nc, m.d_Dc, m.d_Dinv_c, m.d_sc_c, m.d_Dinv_s_c);
   launch_lp_convert(s->stream, m.Nc, ic, m.d_Hc, m.d_sc_c, nullptr, m.d_Dc, m.d_B8c, m.d_B1c, bits);
@@ -1922,13 +2015,16 @@ static int pmg_coefficients(tlfea_newton_t s) {
   if (cold) {  // start vector: D^-1 applied to the restricted scaling vector (positive on every DOF)
     HIP_TRY(hipMemcpyAsync(m.d_eigv_c, m.d_sc_c, (size_t)nc * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
   }
-  launch_norm2(s->stream, m.d_eigv_c, nullptr, nc, part(s, 5), s->d_scal);
+  // multi-GPU: norms weigh replicated DOFs by 1/multiplicity and are summed over ranks, boundary rows of Hc v are
+  // summed like the fine level's -- every rank ends with the same estimate, hence the same polynomial
+  TRY(device_sumsq_async(s, m.d_eigv_c, s->ar ? m.d_wc3 : nullptr, nc));
   launch_scale_inv_sqrt(s->stream, nc, s->d_scal, m.d_eigv_c);
   for (int k = 0; k < (cold ? 16 : 2); k++) {
     launch_spmv_dir_dot(s->stream, Nc, ic, m.d_Hc, m.d_eigv_c, m.d_eigv_c, 1, part(s, 1), part(s, 0), m.d_p_c, m.d_q_c,
                         part(s, 2), false, false);
+    if (s->ar) TRY(iface_sum_lvl(s, m.n_ifc_loc, m.n_ifc_glob, m.d_ifc_node, m.d_ifc_slot, m.d_q_c, 3));
     launch_apply_dinv(s->stream, Nc, m.d_Dinv_c, m.d_q_c, m.d_eigv_c);
-    launch_norm2(s->stream, m.d_eigv_c, nullptr, nc, part(s, 5), s->d_scal);
+    TRY(device_sumsq_async(s, m.d_eigv_c, s->ar ? m.d_wc3 : nullptr, nc));
     launch_scale_inv_sqrt(s->stream, nc, s->d_scal, m.d_eigv_c);
   }
   double ss = 0.0;
@@ -2019,6 +2115,56 @@ static int pmg_apply(tlfea_newton_t s, const double* d_r, double* d_z, double* r
   const float* Dinv_fc = c_r2 + nc;
   const double* cf = m.d_coef;
   const Incidence inc_f = d->inc(), inc_c = m.inc();
+  if (s->ar) {
+    // Multi-GPU V-cycle: the same sequence, every polynomial step on either level preceded by the exchange of the
+    // partition-boundary rows of Hs d (this rank's partial rows -> all-reduce -> the fused step reads the sums), the
+    // restriction by the exchange of the boundary vertices' restricted residuals.  One collective per step: 4 on the
+    // fine level, kc - 1 on the coarse level, 1 for the restriction.
+    if (m.agg.ok) return fail("p-multigrid: the third level is single-GPU only");
+    auto fine_step = [&](const float* din, const double* co, float* dout, const float* zin, float* zout, const float* rin,
+                         float* rout, bool last) -> int {
+      const int nb = 3 * s->n_if_glob;
+      if (nb) HIP_TRY(hipMemsetAsync(s->d_ibuf, 0, (size_t)nb * sizeof(double), s->stream));
+      launch_spmv32_rows(s->stream, s->n_if_loc, s->d_if_node, s->d_if_slot, inc_f, s->d_B8, s->d_B1, bits, din, s->d_ibuf);
+      if (nb) TRY(call_allreduce(s, s->d_ibuf, nb));
+      launch_cheb32(s->stream, N, d->nnz_coef, inc_f, s->d_B8, s->d_B1, bits, Dinv_f, s->d_sc, din, co, dout, zin, zout, rin,
+                    rout, d_r, d_z, rz_part, last, C32Bnd{s->d_bslot_f, s->d_ibuf, s->d_w});
+      return 0;
+    };
+    auto coarse_step = [&](const float* din, const double* co, float* dout, const float* zin, float* zout,
+                           const float* rin, float* rout) -> int {
+      const int nb = 3 * m.n_ifc_glob;
+      if (nb) HIP_TRY(hipMemsetAsync(s->d_ibuf, 0, (size_t)nb * sizeof(double), s->stream));
+      launch_spmv32_rows(s->stream, m.n_ifc_loc, m.d_ifc_node, m.d_ifc_slot, inc_c, m.d_B8c, m.d_B1c, bits, din, s->d_ibuf);
+      if (nb) TRY(call_allreduce(s, s->d_ibuf, nb));
+      launch_cheb32(s->stream, Nc, m.nnz_c, inc_c, m.d_B8c, m.d_B1c, bits, Dinv_fc, m.d_sc_c, din, co, dout, zin, zout, rin,
+                    rout, d_r, d_z, rz_part, false, C32Bnd{m.d_bslot_c, s->d_ibuf, nullptr});
+      return 0;
+    };
+    launch_cheb32_init(s->stream, N, Dinv_f, d_r, s->d_sc, cf, f_d, f_z, f_r);
+    TRY(fine_step(f_d, cf + 2, f_d2, f_z, f_z2, f_r, f_r2, false));
+    TRY(fine_step(f_d2, cf + 4, f_d, f_z2, f_z, f_r2, f_r, false));
+    {
+      const int nb = 3 * m.n_ifc_glob;
+      if (nb) HIP_TRY(hipMemsetAsync(s->d_ibuf, 0, (size_t)nb * sizeof(double), s->stream));
+      launch_pmg_restrict_rows(s->stream, m.n_ifc_loc, m.d_ifc_node, m.d_ifc_slot, m.d_child_off, m.d_child,
+                               m.d_child_w_dist, f_r, s->d_sc, s->d_ibuf);
+      if (nb) TRY(call_allreduce(s, s->d_ibuf, nb));
+      launch_pmg_restrict_init(s->stream, Nc, m.d_child_off, m.d_child, m.d_child_w, f_r, s->d_sc, m.d_sc_c, Dinv_fc, cf + 8,
+                               c_d, c_z, c_r, m.d_bslot_c, s->d_ibuf);
+    }
+    const int kc = pmg_coarse_degree_eff(s);
+    for (int k = 1; k < kc; k++) {
+      TRY(coarse_step(c_d, cf + 8 + 2 * k, c_d2, c_z, c_z2, c_r, c_r2));
+      std::swap(c_d, c_d2);
+      std::swap(c_z, c_z2);
+      std::swap(c_r, c_r2);
+    }
+    launch_pmg_prolong(s->stream, N, m.d_par0, m.d_par1, c_z, m.d_sc_c, s->d_sc, f_z, f_d);
+    TRY(fine_step(f_d, cf + 6, f_d2, f_z, f_z2, f_r, f_r2, false));
+    TRY(fine_step(f_d2, cf + 2, f_d, f_z2, f_z, f_r2, f_r, true));
+    return 0;
+  }
   // pre-smooth: d0 = (SDS)^-1 r^/theta ; one Chebyshev step ; residual of the result
   if (!init_done) launch_cheb32_init(s->stream, N, Dinv_f, d_r, s->d_sc, cf, f_d, f_z, f_r);
   launch_cheb32(s->stream, N, d->nnz_coef, inc_f, s->d_B8, s->d_B1, bits, Dinv_f, s->d_sc, f_d, cf + 2, f_d2, f_z, f_z2, f_r,
@@ -2621,6 +2767,7 @@ extern "C" int tlfea_newton_get_stats(tlfea_newton_t s, double* st) {
   std::copy(s->stats, s->stats + 6, st);
   return 0;
 }
+extern "C" long tlfea_newton_collectives(tlfea_newton_t s) { return s ? s->n_collectives : -1; }
 extern "C" int tlfea_newton_n_constraints(tlfea_newton_t s) { return s ? s->n_constraints : -1; }
 extern "C" int tlfea_newton_get_linsolve_status(tlfea_newton_t s, double* out4) {
   if (!s || !out4) return fail("null argument");

@@ -161,16 +161,31 @@ void launch_mask_scale(hipStream_t s, int N, const double* sc, const int* own, d
 void launch_to_float(hipStream_t s, size_t n, const double* a, float* b);
 void launch_cheb32_init(hipStream_t s, int N, const float* Dinv_f, const double* r, const double* sc,
                         const double* coef, float* d, float* z, float* res);
+// Partition-boundary rows of the single-precision polynomial on the multi-GPU path: their Hs d is the SUM over ranks of
+// the ranks' partial rows (launch_spmv32_rows -> all-reduce), handed to the fused step through bsum; w = 1/multiplicity
+// of a DOF in the r.z partials of the last step.
+struct C32Bnd {
+  const int* bslot = nullptr;    // [N] slot of a boundary node in the exchange buffer, -1 for interior nodes
+  const double* bsum = nullptr;  // [3 slots] summed Hs d of the boundary rows
+  const double* w = nullptr;     // [3N] weights of the r.z partials (last step), null = 1
+};
 void launch_cheb32(hipStream_t s, int N, int nnz_coef, const Incidence& inc, const void* B8, const void* B1, int bits,
                    const float* Dinv_f, const double* sc, const float* d_old, const double* coef, float* d_new,
                    const float* z, float* z_new, const float* res, float* res_new, const double* r, double* z_out,
-                   double* rz_part, bool last);
+                   double* rz_part, bool last, C32Bnd bnd = C32Bnd());
+// out[3 slot[k] + c] = (Hs d)_{rows[k], c} for a list of rows (this rank's part of the partition-boundary rows)
+void launch_spmv32_rows(hipStream_t s, int n_rows, const int* rows, const int* slots, const Incidence& inc, const void* B8,
+                        const void* B1, int bits, const float* d, double* out);
+// restriction of the partition-boundary coarse rows only: out[3 slot[k] + c] = sum_children w res_f / sc_f (this rank's part)
+void launch_pmg_restrict_rows(hipStream_t s, int n_rows, const int* rows, const int* slots, const int* child_off,
+                              const int* child, const float* child_w, const float* res_f, const double* sc_f, double* out);
 // two-level p-multigrid (T10): Galerkin coarse operator and grid transfers (pmg_host.h holds the integer set-up)
 void launch_pmg_galerkin(hipStream_t s, int nnz_c, const int* c_off, const int* cblk_row, const int* con_off,
                          const int* con_base, const int* con_deg, const float* con_w, const double* Hf, double* Hc);
 void launch_pmg_restrict_init(hipStream_t s, int Nc, const int* child_off, const int* child, const float* child_w,
                               const float* res_f, const double* sc_f, const double* sc_c, const float* Dinv_c,
-                              const double* coef_c, float* d_c, float* z_c, float* res_c);
+                              const double* coef_c, float* d_c, float* z_c, float* res_c, const int* bslot = nullptr,
+                              const double* bsum = nullptr);
 // third level: rigid-body-mode aggregation of the vertex level (pmg_host.h agg_build)
 void launch_agg_galerkin(hipStream_t s, int n_pairs, const int* pair_A, const int* pair_pos, const int* pair_B,
                          const int* pcon_off, const int* pcon_base, const int* pcon_deg, const int* pcon_i,

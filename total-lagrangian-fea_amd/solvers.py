@@ -73,6 +73,11 @@ class SyncedNewtonSolver:
         """0 block-Jacobi, 1 Chebyshev polynomial, 2 two-level p-multigrid (what a solve would use now)"""
         return int(self._lib.tlfea_newton_get_precond(self._h))
 
+    def Collectives(self):
+        """all-reduce calls issued by the engine since the solver was built (torch.distributed callback or built-in RCCL)"""
+        self._lib.tlfea_newton_collectives.restype = C.c_long
+        return int(self._lib.tlfea_newton_collectives(self._h))
+
     def GetAssemblyMode(self):
         """1: tangent blocks + row-owner gather (two launches), 2: fused row-owner tangent + assembly (T10, SVK)"""
         return int(self._lib.tlfea_newton_get_assembly_mode(self._h))
