@@ -28,3 +28,19 @@ extern "C" void rg_fetch(int* g_inst_off, int* g_row_off, int* gr_row, int* gr_a
   std::copy(g_rg.gi_code.begin(), g_rg.gi_code.end(), gi_code);
   std::copy(g_rg.gi_pack.begin(), g_rg.gi_pack.end(), gi_pack);
 }
+
+// ---- sparse direct solve: ordering + symbolic factorisation (csrc/direct_host.h) ----------------------------------------
+#include "../../total-lagrangian-fea_amd/csrc/direct_host.h"
+static tlfea::DirectHost g_dh;
+extern "C" int dh_build(int N, const int* off, const int* cols, const double* x, const double* y, const double* z,
+                        long long max_nnz, int* sizes) {
+  if (!tlfea::direct_symbolic(N, off, cols, x, y, z, max_nnz, g_dh)) return 1;
+  sizes[0] = g_dh.n;
+  sizes[1] = (int)g_dh.indT.size();
+  return 0;
+}
+extern "C" void dh_fetch(int* perm, int* ptrT, int* indT) {
+  std::copy(g_dh.perm.begin(), g_dh.perm.end(), perm);
+  std::copy(g_dh.ptrT.begin(), g_dh.ptrT.end(), ptrT);
+  std::copy(g_dh.indT.begin(), g_dh.indT.end(), indT);
+}

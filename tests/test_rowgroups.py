@@ -131,3 +131,46 @@ def test_row_groups_invariants(shim, mesh):
     first = X[gr_row[g_row_off[:-1]]]
     hop = np.linalg.norm(np.diff(first, axis=0), axis=1)
     assert np.median(hop) < 0.35 * np.linalg.norm(X.max(0) - X.min(0))
+
+
+@pytest.mark.parametrize("mesh", ["beam_3x2x1", "res2"])
+def test_direct_solver_symbolic_factor(shim, mesh):
+    """Host set-up of the sparse direct solve (csrc/direct_host.h): the permutation is a bijection that keeps the three
+    DOFs of a node together, and the pattern it predicts for the Cholesky factor of Q^T H Q is exactly the pattern a dense
+    symbolic elimination of the permuted matrix produces (no entry missing: rocSOLVER's re-factorisation computes on
+    this pattern only; none superfluous at node level)."""
+    X, conn = load_mesh(mesh)
+    conn = np.ascontiguousarray(conn, dtype=np.int32)
+    N = X.shape[0]
+    off, cols, _, _ = adjacency(conn, N)
+    x, y, z = (np.ascontiguousarray(X[:, k]) for k in range(3))
+    sizes = np.zeros(2, dtype=np.int32)
+    shim.dh_build.argtypes = [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                              C.POINTER(C.c_double), C.c_longlong, C.POINTER(C.c_int)]
+    assert shim.dh_build(N, ip(off), ip(cols), dp(x), dp(y), dp(z), 10**9, ip(sizes)) == 0
+    n, nnzT = map(int, sizes)
+    assert n == 3 * N
+    perm, ptrT, indT = np.zeros(n, np.int32), np.zeros(n + 1, np.int32), np.zeros(nnzT, np.int32)
+    shim.dh_fetch(ip(perm), ip(ptrT), ip(indT))
+    assert np.array_equal(np.sort(perm), np.arange(n))
+    assert np.array_equal(perm.reshape(N, 3) % 3, np.tile(np.arange(3), (N, 1)))        # blocks stay together, in order
+    assert np.all(perm.reshape(N, 3)[:, 0] // 3 == perm.reshape(N, 3)[:, 2] // 3)
+    # dense symbolic elimination of the permuted NODE graph
+    order = perm.reshape(N, 3)[:, 0] // 3
+    inv = np.empty(N, dtype=np.int64)
+    inv[order] = np.arange(N)
+    A = np.zeros((N, N), dtype=bool)
+    for i in range(N):
+        A[inv[i], inv[cols[off[i]:off[i + 1]]]] = True
+    L = np.tril(A)
+    for k in range(N):
+        below = np.where(L[k + 1:, k])[0] + k + 1
+        L[np.ix_(below, below)] |= np.tril(np.ones((len(below), len(below)), dtype=bool))
+    # expected DOF pattern: full 3x3 blocks below the diagonal, lower triangle of the diagonal blocks
+    for k in range(N):
+        js = np.where(L[k, :k])[0]
+        for r in range(3):
+            row = indT[ptrT[3 * k + r]:ptrT[3 * k + r + 1]]
+            expect = np.concatenate([(3 * js[:, None] + np.arange(3)[None, :]).reshape(-1), 3 * k + np.arange(r + 1)])
+            assert np.array_equal(row, expect), (k, r)
+    assert ptrT[-1] == nnzT

@@ -1597,6 +1597,13 @@ __global__ void neg_kernel(int n, const double* __restrict__ g, double* __restri
 void launch_axpy_neg(hipStream_t s, int n, const double* g, double* r) {
   hipLaunchKernelGGL(neg_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, g, r);
 }
+__global__ void diff_kernel(int n, const double* __restrict__ a, const double* __restrict__ b, double* __restrict__ r) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) r[i] = a[i] - b[i];
+}
+void launch_diff(hipStream_t s, int n, const double* a, const double* b, double* r) {  // r = a - b
+  hipLaunchKernelGGL(diff_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, a, b, r);
+}
 
 __global__ void dual_update_kernel(int nc, const double* __restrict__ c, double rho, double* __restrict__ lam) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -18,6 +18,7 @@
 #include "tlfea_internal.h"
 #include "pmg_host.h"
 #include "rowgroup_host.h"
+#include "direct_host.h"
 #include "vbd_host.h"
 
 using namespace tlfea;
@@ -964,6 +965,14 @@ struct tlfea_newton_s {
   bool fq_in_residual = true;  // first-order solvers (AdamW, Nesterov, VBD) never assemble: their residual skips Fq
   int asm_mode = 0;
   double* d_Fq = nullptr;
+  // sparse direct solve (lin.method == 1): rocSOLVER re-factorisation on a host-computed ordering + factor pattern
+  struct Direct {
+    bool tried = false, ok = false;
+    int n = 0, nnzT = 0;
+    void *blas = nullptr, *rfinfo = nullptr;
+    int *d_ptrA = nullptr, *d_indA = nullptr, *d_ptrT = nullptr, *d_indT = nullptr, *d_pivQ = nullptr;
+    double* d_valT = nullptr;
+  } direct;
   double* d_mbuf = nullptr;   // T10: per (element, node) force row | inertia row M_e (v - v_prev) / h of the residual launch
   int mass_mode = 0;          // TLFEA_MASS=csr: always the mass CSR product in grad_kernel
   double *d_p = nullptr, *d_p2 = nullptr, *d_q = nullptr, *d_zv = nullptr;
@@ -1045,6 +1054,7 @@ extern "C" int tlfea_newton_create(tlfea_t10_t data, int n_constraints, tlfea_ne
 }
 
 static void cg_graphs_destroy(tlfea_newton_t s);
+static void direct_destroy(tlfea_newton_t s);
 extern "C" int tlfea_newton_destroy(tlfea_newton_t s) {
   if (!s) return 0;
   void* ptrs[] = {s->d_v, s->d_vprev, s->d_lam, s->d_g, s->d_dv, s->d_r, s->d_b, s->d_eigv, s->d_cd, s->d_cd2, s->d_cres, s->d_xp, s->d_yp, s->d_zp, s->d_H,
@@ -1055,6 +1065,7 @@ extern "C" int tlfea_newton_destroy(tlfea_newton_t s) {
     if (p) (void)hipFree(p);
   if (s->d_Fq) (void)hipFree(s->d_Fq);
   if (s->d_mbuf) (void)hipFree(s->d_mbuf);
+  direct_destroy(s);
   for (auto& e : s->ev)
     if (e) (void)hipEventDestroy(e);
   if (s->h_pin) (void)hipHostFree(s->h_pin);
@@ -1109,6 +1120,7 @@ extern "C" int tlfea_newton_set_linsolve_opts(tlfea_newton_t s, const tlfea_lins
   if (s->lin.cheb_bits != 16 && s->lin.cheb_bits != 32 && s->lin.cheb_bits != 64) s->lin.cheb_bits = 0;
   if (s->lin.precond < 0 || s->lin.precond > 2) s->lin.precond = 0;
   s->lin.on_unconverged = s->lin.on_unconverged ? 1 : 0;
+  s->lin.method = s->lin.method == 1 ? 1 : 0;
   return 0;
 }
 extern "C" int tlfea_newton_set_fixed_sparsity_pattern(tlfea_newton_t s, int fixed) {
@@ -2312,8 +2324,164 @@ static int cg_graphs_prepare(tlfea_newton_t s, double* d_x, bool fused, int deg,
   return 0;
 }
 
+// ---- sparse direct solve: rocSOLVER's re-factorisation path in place of cuDSS (SyncedNewton.cu:995-1029 analysis once,
+// :1103-1114 REFACTORIZATION + SOLVE per Newton iteration) ------------------------------------------------------------
+// rocSOLVER (and the rocBLAS handle it needs) are resolved at run time, like RCCL: the default iterative path never
+// depends on them.  rocsolver_dcsrrf_* re-factorise a matrix of FIXED pattern given the permutation and the pattern of
+// its Cholesky factor, which direct_host.h computes once per mesh (nested dissection + symbolic factorisation).
+namespace {
+struct RocsolverApi {
+  void* lib = nullptr;
+  int (*blas_create)(void**) = nullptr;
+  int (*blas_destroy)(void*) = nullptr;
+  int (*blas_set_stream)(void*, hipStream_t) = nullptr;
+  int (*rf_create)(void**, void*) = nullptr;
+  int (*rf_destroy)(void*) = nullptr;
+  int (*rf_set_mode)(void*, int) = nullptr;
+  int (*analysis)(void*, int, int, int, int*, int*, double*, int, int*, int*, double*, int*, int*, double*, int, void*) = nullptr;
+  int (*refactchol)(void*, int, int, int*, int*, double*, int, int*, int*, double*, int*, void*) = nullptr;
+  int (*solve)(void*, int, int, int, int*, int*, double*, int*, int*, double*, int, void*) = nullptr;
+};
+RocsolverApi& rocsolver_api() {
+  static RocsolverApi a;
+  static bool tried = false;
+  if (tried) return a;
+  tried = true;
+  for (const char* name : {"librocsolver.so.0", "librocsolver.so", "/opt/rocm/lib/librocsolver.so.0"}) {
+    a.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+    if (a.lib) break;
+  }
+  if (!a.lib) return a;
+  auto sym = [&](const char* n) { return dlsym(a.lib, n) ? dlsym(a.lib, n) : dlsym(RTLD_DEFAULT, n); };
+  a.blas_create = (int (*)(void**))sym("rocblas_create_handle");
+  a.blas_destroy = (int (*)(void*))sym("rocblas_destroy_handle");
+  a.blas_set_stream = (int (*)(void*, hipStream_t))sym("rocblas_set_stream");
+  a.rf_create = (int (*)(void**, void*))sym("rocsolver_create_rfinfo");
+  a.rf_destroy = (int (*)(void*))sym("rocsolver_destroy_rfinfo");
+  a.rf_set_mode = (int (*)(void*, int))sym("rocsolver_set_rfinfo_mode");
+  a.analysis = (decltype(a.analysis))sym("rocsolver_dcsrrf_analysis");
+  a.refactchol = (decltype(a.refactchol))sym("rocsolver_dcsrrf_refactchol");
+  a.solve = (decltype(a.solve))sym("rocsolver_dcsrrf_solve");
+  if (!a.blas_create || !a.blas_destroy || !a.blas_set_stream || !a.rf_create || !a.rf_destroy || !a.rf_set_mode ||
+      !a.analysis || !a.refactchol || !a.solve)
+    a.lib = nullptr;
+  return a;
+}
+}  // namespace
+
+static void direct_destroy(tlfea_newton_t s) {
+  auto& m = s->direct;
+  RocsolverApi& a = rocsolver_api();
+  if (m.rfinfo && a.lib) (void)a.rf_destroy(m.rfinfo);
+  if (m.blas && a.lib) (void)a.blas_destroy(m.blas);
+  void* pp[] = {m.d_ptrA, m.d_indA, m.d_ptrT, m.d_indT, m.d_pivQ, m.d_valT};
+  for (void* q : pp)
+    if (q) (void)hipFree(q);
+  m = tlfea_newton_s::Direct();
+}
+
+// once per mesh: ordering + symbolic factor on the host, rocSOLVER's analysis on the device
+static int direct_prepare(tlfea_newton_t s) {
+  auto& m = s->direct;
+  if (m.tried) return m.ok ? 0 : fail("sparse direct solve is not available (see the earlier message)");
+  m.tried = true;
+  tlfea_t10_t d = s->d;
+  if (s->ar) return fail("sparse direct solve: single-GPU path only");
+  RocsolverApi& a = rocsolver_api();
+  if (!a.lib) return fail("sparse direct solve: librocsolver / librocblas could not be resolved at run time");
+  // coordinates of the coefficient vectors for the dissection planes (ANCF: the 4 vectors of a node share its position)
+  const int N = s->N;
+  std::vector<double> X(3 * (size_t)N);
+  D2H(X.data(), d->d_xt, (size_t)N);
+  D2H(X.data() + N, d->d_yt, (size_t)N);
+  D2H(X.data() + 2 * (size_t)N, d->d_zt, (size_t)N);
+  if (d->kind != kT10)
+    for (int i = 0; i < N; i++)
+      for (int c = 0; c < 3; c++) X[(size_t)c * N + i] = X[(size_t)c * N + (i / 4) * 4];
+  DirectHost h;
+  static const long long max_nnz = std::getenv("TLFEA_DIRECT_MAX_NNZ") ? std::atoll(std::getenv("TLFEA_DIRECT_MAX_NNZ")) : 400000000LL;
+  if (!direct_symbolic(N, d->h_off.data(), d->h_cols.data(), X.data(), X.data() + N, X.data() + 2 * (size_t)N, max_nnz, h))
+    return fail("sparse direct solve: the Cholesky factor of this mesh exceeds the size limit (TLFEA_DIRECT_MAX_NNZ, default "
+                "4e8 entries = 3.2 GB); use the iterative solver");
+  m.n = h.n;
+  m.nnzT = (int)h.indT.size();
+  TRY(dmalloc(&m.d_ptrA, s->h_row_offsets.size()));
+  TRY(dmalloc(&m.d_indA, s->h_col_indices.size()));
+  TRY(dmalloc(&m.d_ptrT, h.ptrT.size()));
+  TRY(dmalloc(&m.d_indT, h.indT.size()));
+  TRY(dmalloc(&m.d_pivQ, h.perm.size()));
+  TRY(dmalloc(&m.d_valT, h.indT.size()));
+  HIP_TRY(hipMemcpy(m.d_ptrA, s->h_row_offsets.data(), s->h_row_offsets.size() * sizeof(int), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(m.d_indA, s->h_col_indices.data(), s->h_col_indices.size() * sizeof(int), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(m.d_ptrT, h.ptrT.data(), h.ptrT.size() * sizeof(int), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(m.d_indT, h.indT.data(), h.indT.size() * sizeof(int), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(m.d_pivQ, h.perm.data(), h.perm.size() * sizeof(int), hipMemcpyHostToDevice));
+  {  // a valid factor for the analysis phase (it inspects the pattern): the identity on T's pattern
+    std::vector<double> vT(h.indT.size(), 0.0);
+    for (int r = 0; r < h.n; r++) vT[(size_t)h.ptrT[r + 1] - 1] = 1.0;  // the diagonal is the last entry of a row
+    HIP_TRY(hipMemcpy(m.d_valT, vT.data(), vT.size() * sizeof(double), hipMemcpyHostToDevice));
+  }
+  if (a.blas_create(&m.blas)) return fail("rocblas_create_handle failed");
+  if (a.blas_set_stream(m.blas, s->stream)) return fail("rocblas_set_stream failed");
+  if (a.rf_create(&m.rfinfo, m.blas)) return fail("rocsolver_create_rfinfo failed");
+  if (a.rf_set_mode(m.rfinfo, /*rocsolver_rfinfo_mode_cholesky*/ 272)) return fail("rocsolver_set_rfinfo_mode failed");
+  const int rc = a.analysis(m.blas, m.n, 1, s->h_nnz, m.d_ptrA, m.d_indA, s->d_H, m.nnzT, m.d_ptrT, m.d_indT, m.d_valT,
+                            nullptr, m.d_pivQ, s->d_dv, m.n, m.rfinfo);
+  if (rc) return fail("rocsolver_dcsrrf_analysis failed with status " + std::to_string(rc));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  m.ok = true;
+  if (s->verbose)
+    std::printf("sparse direct solve: %d DOF, factor %d entries (%.1f x the lower triangle of H), nested dissection\n", m.n,
+                m.nnzT, (double)m.nnzT / (0.5 * s->h_nnz));
+  return 0;
+}
+
+// H x = b by re-factorisation + triangular solves; the true residual is measured with the fp64 SpMV of the CG
+static int direct_solve(tlfea_newton_t s, const double* d_b, double* d_x, int* iters_out, double* rel_out) {
+  TRY(direct_prepare(s));
+  auto& m = s->direct;
+  RocsolverApi& a = rocsolver_api();
+  tlfea_t10_t d = s->d;
+  StageTimer t(s, 4);
+  const size_t nb = (size_t)m.n * sizeof(double);
+  int rc = a.refactchol(m.blas, m.n, s->h_nnz, m.d_ptrA, m.d_indA, s->d_H, m.nnzT, m.d_ptrT, m.d_indT, m.d_valT, m.d_pivQ,
+                        m.rfinfo);
+  if (rc) return fail("rocsolver_dcsrrf_refactchol failed with status " + std::to_string(rc) + " (H not positive definite?)");
+  HIP_TRY(hipMemcpyAsync(d_x, d_b, nb, hipMemcpyDeviceToDevice, s->stream));
+  rc = a.solve(m.blas, m.n, 1, m.nnzT, m.d_ptrT, m.d_indT, m.d_valT, nullptr, m.d_pivQ, d_x, m.n, m.rfinfo);
+  if (rc) return fail("rocsolver_dcsrrf_solve failed with status " + std::to_string(rc));
+  // r = b - H x, ||r|| / ||b||
+  HIP_TRY(hipMemsetAsync(s->d_parts, 0, (size_t)5 * kNPart * sizeof(double), s->stream));
+  launch_spmv_dir_dot(s->stream, s->N, d->inc(), s->d_H, d_x, s->d_p, 1, part(s, 1), part(s, 0), s->d_p2, s->d_q, part(s, 2),
+                      true, s->spmv_nt);
+  launch_diff(s->stream, m.n, d_b, s->d_q, s->d_r);
+  double rr = 0.0, bb = 0.0;
+  launch_norm2(s->stream, s->d_r, nullptr, m.n, part(s, 5), s->d_scal);
+  launch_norm2(s->stream, d_b, nullptr, m.n, part(s, 4), s->d_scal + 1);
+  TRY(fetch_scalar2(s, s->d_scal, &rr, &bb));
+  HIP_TRY(hipGetLastError());
+  t.stop();
+  const double rel = bb > 0.0 ? std::sqrt(rr / bb) : 0.0;
+  if (iters_out) *iters_out = 1;
+  if (rel_out) *rel_out = rel;
+  // a backward-stable factorisation leaves ||r||/||b|| at a few ulp times the growth of the factor: the tolerance of the
+  // iterative path does not apply; what is reported (and tested) is the measured residual
+  s->lin_last_rel = rel;
+  s->lin_last_ok = rel == rel && rel <= 1e-8;
+  s->lin_worst_rel = (rel != rel) ? rel : std::max(s->lin_worst_rel, rel);
+  s->lin_all_ok = s->lin_all_ok && s->lin_last_ok;
+  if (!s->lin_last_ok && !s->lin.on_unconverged) {
+    char msg[200];
+    std::snprintf(msg, sizeof msg, "sparse direct solve left ||r||/||b|| = %.3e (H not positive definite, or ill-conditioned "
+                  "beyond fp64)", rel);
+    return fail(msg);
+  }
+  return 0;
+}
+
 // Solve H x = b on the device (b, x device vectors of 3N).  Standard PCG, block-Jacobi.
 static int pcg(tlfea_newton_t s, const double* d_b, double* d_x, int* iters_out, double* rel_out) {
+  if (s->lin.method == 1) return direct_solve(s, d_b, d_x, iters_out, rel_out);
   tlfea_t10_t d = s->d;
   const int N = s->N;
   StageTimer t(s, 4);
@@ -2523,7 +2691,8 @@ extern "C" int tlfea_newton_get_linsolve_info(tlfea_newton_t s, int* cheb_degree
   if (!s) return fail("null argument");
   if (cheb_degree) *cheb_degree = cheb_degree_eff(s);
   if (cheb_bits) *cheb_bits = cheb_bits_eff(s);
-  if (cheb_vector_bits) *cheb_vector_bits = (cheb_bits_eff(s) != 64 && (!s->ar || s->d_own)) ? 32 : 64;
+  if (cheb_vector_bits)
+    *cheb_vector_bits = (cheb_bits_eff(s) != 64 && (!s->ar || s->d_own || precond_eff(s) == 2)) ? 32 : 64;
   return 0;
 }
 extern "C" int tlfea_newton_eval_gradient(tlfea_newton_t s, double* norm_g) {

@@ -216,6 +216,7 @@ void launch_scale_inv_sqrt(hipStream_t s, int n, const double* sumsq, double* v)
 void launch_newton_update(hipStream_t s, int N, const double* dv, double* v, const double* xp, const double* yp,
                           const double* zp, double h, double* x, double* y, double* z);
 void launch_axpy_neg(hipStream_t s, int n, const double* g, double* r);
+void launch_diff(hipStream_t s, int n, const double* a, const double* b, double* r);  // r = a - b
 void launch_adamw_update_velocity(hipStream_t s, int n, const double* g, double beta1, double beta2, double eps,
                                   double weight_decay, double lr, double inv_1mb1t, double inv_1mb2t, double* m,
                                   double* va, double* v);
