@@ -18,12 +18,12 @@ s.SetLinSolveOpts(tl.LinSolveOpts(1e-12, 300, 25, on_unconverged=1))
 d.UpdatePositions(w["x0"][:, 0], w["x0"][:, 1], w["x0"][:, 2])
 s.BeginStep()
 s.NewtonIteration()
-for store in (0, 512):
-    for rolled in (1,):
-        for waves in (8, 10):
+for store in (0,):
+    for rolled in (1, 0):
+        for waves in ((10, 11, 12) if rolled else (8,)):
             os.environ["TLFEA_AD_ROLLED"], os.environ["TLFEA_AD_WAVES"] = str(rolled), str(waves)
             os.environ["TLFEA_AD_STORE"] = str(store)
             t = s.TimeKernels(reps=5)
-            print(f"store={store} rolled={rolled} waves/CU={waves}: assemble_direct {t['assemble_rows'] * 1e3:.1f} us", flush=True)
+            print(f"store={store} rolled={rolled} waves/CU={waves}: assemble_direct {t['assemble_rows'] * 1e3:.1f} us residual {t['residual'] * 1e3:.1f} us", flush=True)
 del s
 d.Destroy()

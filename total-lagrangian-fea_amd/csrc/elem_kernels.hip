@@ -1089,7 +1089,7 @@ __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-template <bool ROLLED>
+template <int ROLLED>  // 0: points unrolled (234 VGPRs, 2 waves per SIMD), 1: rolled (168 VGPRs, 3 waves per SIMD)
 __global__ __launch_bounds__(64, ROLLED ? 3 : 2) void assemble_direct_kernel(ElemView m, Material mat, double h, RowGroups rg,
                                                                const double* __restrict__ Fq,
                                                                const double* __restrict__ mval, double inv_h,
@@ -1331,8 +1331,8 @@ void launch_assemble_direct(hipStream_t s, const ElemView& m, const Material& ma
   const size_t lds = (size_t)(kAdRecTotal + kAdHraw + rg.acc_max) * sizeof(double);
   static size_t lds_attr = 0;
   if (lds > 64 * 1024 && lds > lds_attr) {
-    (void)hipFuncSetAttribute((const void*)assemble_direct_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute((const void*)assemble_direct_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)assemble_direct_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)assemble_direct_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     lds_attr = lds;
   }
   // persistent grid: as many single-wave workgroups as the chip holds at once (8 XCDs x 32 CUs x resident waves per CU),
@@ -1348,7 +1348,7 @@ void launch_assemble_direct(hipStream_t s, const ElemView& m, const Material& ma
   }
   if (occ_lds != lds) {
     int o = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, (const void*)assemble_direct_kernel<true>, 64, lds) == hipSuccess && o > 0)
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, (const void*)assemble_direct_kernel<1>, 64, lds) == hipSuccess && o > 0)
       occ = o;
     occ_lds = lds;
   }
@@ -1363,13 +1363,15 @@ void launch_assemble_direct(hipStream_t s, const ElemView& m, const Material& ma
     rolled = std::getenv("TLFEA_AD_ROLLED") ? std::atoi(std::getenv("TLFEA_AD_ROLLED")) : 1;
     occ_env = std::getenv("TLFEA_AD_WAVES") ? std::atoi(std::getenv("TLFEA_AD_WAVES")) : 0;
   }
-  const int occ_eff = occ_env > 0 ? occ_env : std::min(occ, rolled ? 10 : 8);  // measured best at config C (tools/tune_assemble.py)
+  // measured at config C (tools/tune_assemble.py): every resident slot of the rolled form (12 per CU: 168 VGPRs, 12 KiB of
+  // LDS), 8 of the unrolled one; more workgroups than fit leave a tail
+  const int occ_eff = occ_env > 0 ? occ_env : std::min(occ, rolled ? 12 : 8);
   const int per_xcd = std::max(1, std::min((n_cu / 8) * occ_eff, (rg.G + 7) / 8));
   if (rolled)
-    hipLaunchKernelGGL(assemble_direct_kernel<true>, dim3(8 * per_xcd), dim3(64), lds, s, m, mat, h, rg, Fq, mval, 1.0 / h,
+    hipLaunchKernelGGL(assemble_direct_kernel<1>, dim3(8 * per_xcd), dim3(64), lds, s, m, mat, h, rg, Fq, mval, 1.0 / h,
                        fixed_slot, nw, penalty, Hval, store_mode);
   else
-    hipLaunchKernelGGL(assemble_direct_kernel<false>, dim3(8 * per_xcd), dim3(64), lds, s, m, mat, h, rg, Fq, mval, 1.0 / h,
+    hipLaunchKernelGGL(assemble_direct_kernel<0>, dim3(8 * per_xcd), dim3(64), lds, s, m, mat, h, rg, Fq, mval, 1.0 / h,
                        fixed_slot, nw, penalty, Hval, store_mode);
 }
 

@@ -13,6 +13,7 @@
 #pragma once
 #include <algorithm>
 #include <cstdint>
+#include <cstdlib>
 #include <vector>
 
 namespace tlfea {
@@ -44,7 +45,8 @@ inline uint64_t morton_spread21(uint64_t v) {  // 21 bits -> every third bit
 // (e*S + local, ascending e per node), x/y/z: reference coordinates of the N rows.
 inline bool build_row_groups(int N, int E, int S, const int* conn, const int* off, const int* cols, const int* n2e_off,
                              const int* n2e, const double* x, const double* y, const double* z, RowGroupsHost& out) {
-  constexpr int kInstBudget = 24, kAccBudget = 864, kBigRow = 13, kMaxRows = 16, kPassInst = 6;
+  constexpr int kInstBudget = 24, kBigRow = 13, kMaxRows = 16, kPassInst = 6;
+  static const int kAccBudget = std::getenv("TLFEA_AD_ACC") ? std::atoi(std::getenv("TLFEA_AD_ACC")) : 600;  // doubles
   if (N <= 0 || E <= 0) return false;
   double lo[3] = {x[0], y[0], z[0]}, hi[3] = {x[0], y[0], z[0]};
   for (int i = 1; i < N; i++) {
