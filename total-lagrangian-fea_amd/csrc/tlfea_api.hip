@@ -2371,6 +2371,7 @@ RocsolverApi& rocsolver_api() {
 
 static void direct_destroy(tlfea_newton_t s) {
   auto& m = s->direct;
+  if (!m.tried) return;  // never used: do not resolve (dlopen) rocSOLVER / rocBLAS just to tear nothing down
   RocsolverApi& a = rocsolver_api();
   if (m.rfinfo && a.lib) (void)a.rf_destroy(m.rfinfo);
   if (m.blas && a.lib) (void)a.blas_destroy(m.blas);
