@@ -2382,13 +2382,22 @@ static void direct_destroy(tlfea_newton_t s) {
 }
 
 // once per mesh: ordering + symbolic factor on the host, rocSOLVER's analysis on the device
+#define DTRACE(msg)                                                          \
+  do {                                                                       \
+    if (std::getenv("TLFEA_DIRECT_TRACE")) {                                 \
+      std::fprintf(stderr, "tlfea direct: %s\n", msg);                       \
+      std::fflush(stderr);                                                   \
+    }                                                                        \
+  } while (0)
 static int direct_prepare(tlfea_newton_t s) {
   auto& m = s->direct;
   if (m.tried) return m.ok ? 0 : fail("sparse direct solve is not available (see the earlier message)");
   m.tried = true;
   tlfea_t10_t d = s->d;
   if (s->ar) return fail("sparse direct solve: single-GPU path only");
+  DTRACE("resolving rocsolver");
   RocsolverApi& a = rocsolver_api();
+  DTRACE("resolved");
   if (!a.lib) return fail("sparse direct solve: librocsolver / librocblas could not be resolved at run time");
   // coordinates of the coefficient vectors for the dissection planes (ANCF: the 4 vectors of a node share its position)
   const int N = s->N;
@@ -2422,14 +2431,18 @@ static int direct_prepare(tlfea_newton_t s) {
     for (int r = 0; r < h.n; r++) vT[(size_t)h.ptrT[r + 1] - 1] = 1.0;  // the diagonal is the last entry of a row
     HIP_TRY(hipMemcpy(m.d_valT, vT.data(), vT.size() * sizeof(double), hipMemcpyHostToDevice));
   }
+  DTRACE("symbolic done, creating rocblas handle");
   if (a.blas_create(&m.blas)) return fail("rocblas_create_handle failed");
+  DTRACE("handle created");
   if (a.blas_set_stream(m.blas, s->stream)) return fail("rocblas_set_stream failed");
   if (a.rf_create(&m.rfinfo, m.blas)) return fail("rocsolver_create_rfinfo failed");
   if (a.rf_set_mode(m.rfinfo, /*rocsolver_rfinfo_mode_cholesky*/ 272)) return fail("rocsolver_set_rfinfo_mode failed");
+  DTRACE("rfinfo ready, analysis");
   const int rc = a.analysis(m.blas, m.n, 1, s->h_nnz, m.d_ptrA, m.d_indA, s->d_H, m.nnzT, m.d_ptrT, m.d_indT, m.d_valT,
                             nullptr, m.d_pivQ, s->d_dv, m.n, m.rfinfo);
   if (rc) return fail("rocsolver_dcsrrf_analysis failed with status " + std::to_string(rc));
   HIP_TRY(hipStreamSynchronize(s->stream));
+  DTRACE("analysis done");
   m.ok = true;
   if (s->verbose)
     std::printf("sparse direct solve: %d DOF, factor %d entries (%.1f x the lower triangle of H), nested dissection\n", m.n,
@@ -2448,9 +2461,11 @@ static int direct_solve(tlfea_newton_t s, const double* d_b, double* d_x, int* i
   int rc = a.refactchol(m.blas, m.n, s->h_nnz, m.d_ptrA, m.d_indA, s->d_H, m.nnzT, m.d_ptrT, m.d_indT, m.d_valT, m.d_pivQ,
                         m.rfinfo);
   if (rc) return fail("rocsolver_dcsrrf_refactchol failed with status " + std::to_string(rc) + " (H not positive definite?)");
+  DTRACE("refactchol enqueued");
   HIP_TRY(hipMemcpyAsync(d_x, d_b, nb, hipMemcpyDeviceToDevice, s->stream));
   rc = a.solve(m.blas, m.n, 1, m.nnzT, m.d_ptrT, m.d_indT, m.d_valT, nullptr, m.d_pivQ, d_x, m.n, m.rfinfo);
   if (rc) return fail("rocsolver_dcsrrf_solve failed with status " + std::to_string(rc));
+  DTRACE("solve enqueued");
   // r = b - H x, ||r|| / ||b||
   HIP_TRY(hipMemsetAsync(s->d_parts, 0, (size_t)5 * kNPart * sizeof(double), s->stream));
   launch_spmv_dir_dot(s->stream, s->N, d->inc(), s->d_H, d_x, s->d_p, 1, part(s, 1), part(s, 0), s->d_p2, s->d_q, part(s, 2),
