@@ -21,3 +21,13 @@ python3 bench.py > $O/r02_bench_configC.json 2> $O/bench_C.err || { tail -20 $O/
 echo "bench C done"; cut -c1-400 $O/r02_bench_configC.json
 python3 bench.py --config B > $O/r02_bench_configB.json 2> $O/bench_B.err || { tail -20 $O/bench_B.err; exit 1; }
 echo "bench B done"; cut -c1-300 $O/r02_bench_configB.json
+# config D (ANCF-3443 plate, 256 000 shells: the two-kernel tangent / assembly path): PMC traffic of the element kernels
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $c --kernel-include-regex 'residual_kernel|grad_kernel|tangent_blocks|assemble_rows' -d $O/pmcD_$c -o run --output-format csv -- python3 tools/prof_elem.py D 3 > $O/pmcD_$c.log 2>&1 || { tail -20 $O/pmcD_$c.log; exit 1; }
+  echo "pmc D $c done"
+done
+F=$(find $O/pmcD_FETCH_SIZE -name "*counter_collection.csv" | head -1); W=$(find $O/pmcD_WRITE_SIZE -name "*counter_collection.csv" | head -1)
+python3 tools/summarize_pmc.py "$F" "$W" $O/r02_configD_pmc_hbm.csv > $O/pmcD_summary.txt || exit 1
+grep "us per launch" $O/pmcD_FETCH_SIZE.log | tee $O/r02_configD_kernel_us.txt
+rm -rf $O/pmcD_FETCH_SIZE $O/pmcD_WRITE_SIZE
+cat $O/r02_configD_pmc_hbm.csv
