@@ -45,6 +45,10 @@ def alg_bytes(E, N, nnz_coef, S=10, Q=5, cheb_bits=64, cheb_vec_bits=64):
         # fused tangent + assembly (T10, SVK): grad N + det J + per-point F in (each once: the re-reads by the owners of
         # an element's other rows are L2 traffic), instance map (code + S packed words), mass in, H out once
         "assemble_direct": E * (24 * S * Q + 8 * Q + 72 * Q) + E * S * (4 + 4 * S) + nnz_coef * 8 + nnz_coef * 72,
+        # affine-element form (straight-sided T10): the element's 128-byte vertex-gradient record and Q 128-byte point
+        # records {F, B1 F F^T, C0} in (each once), instance map (8-byte header + four 8-byte words), H out once; grad N,
+        # det J and the mass values are not read
+        "assemble_affine": E * (128 + 128 * Q) + E * S * (8 + 32) + nnz_coef * 72,
         # H values + node-level columns + z,p_old in, p_new,q out
         "spmv": nnz_coef * 72 + nnz_coef * 4 + N * 96,
         # Chebyshev step: matrix (9 entries per block at cheb_bits: H itself or its scaled fp32/fp16 copy) + columns +
@@ -218,15 +222,16 @@ def main():
     s.SetProfiling(False)
     deg_eff, bits_eff, vec_bits = s.GetLinSolveInfo()
     ab = alg_bytes(E, N, nnz_coef, d.S, d.Q, bits_eff, vec_bits)
-    fused = s.GetAssemblyMode() == 2   # one fused tangent + assembly launch instead of tangent_blocks + assemble_rows
-    if fused:
-        ab["residual"] += E * 72 * d.Q   # the residual launch also writes the per-point F the fused assembly stages
+    fused = s.GetAssemblyMode() >= 2  # one fused tangent + assembly launch instead of tangent_blocks + assemble_rows
+    fkey = "assemble_affine" if s.GetAssemblyMode() == 3 else "assemble_direct"
+    if fused:   # the residual launch also writes the per-point records the fused assembly stages (F | F, B1 F F^T, C0)
+        ab["residual"] += E * (128 if fkey == "assemble_affine" else 72) * d.Q
     # mean launch duration: `reps` back-to-back launches per kernel between one hipEvent pair on the launch stream
     # (kernel time + same-stream boundary; agrees with rocprofv3 --kernel-trace, profiles/*kernel_stats.csv)
     kt = s.TimeKernels(reps=40 if E < 200000 else 10)
     if fused:
-        kt["assemble_direct"] = kt.pop("assemble_rows")
-        st = dict(st, assemble_direct=st["assemble_rows"])
+        kt[fkey] = kt.pop("assemble_rows")
+        st = dict(st, **{fkey: st["assemble_rows"]})
         st.pop("assemble_rows")
         st["tangent_blocks"] = (0.0, 0)
     roof_all = {}
@@ -244,8 +249,8 @@ def main():
                   cheb_step_coarse=(0.0, n_outer * ncs), poly_step=(0.0, n_outer * (nf + ncs)))
     else:
         st = dict(st, spmv=(st["spmv"][0], n_outer), cheb_step=(0.0, n_outer * (deg_eff - 1)))
-    for k in ("residual", "tangent_blocks", "assemble_rows", "assemble_direct", "spmv", "cheb_step", "cheb_step_coarse",
-              "poly_step"):
+    for k in ("residual", "tangent_blocks", "assemble_rows", "assemble_direct", "assemble_affine", "spmv", "cheb_step",
+              "cheb_step_coarse", "poly_step"):
         if k not in st:
             continue
         ms, n = st[k]
@@ -269,7 +274,7 @@ def main():
     dominant = max((k for k in roof_all if not (pmg and k in ("cheb_step", "cheb_step_coarse"))),
                    key=lambda k: roof_all[k]["total_ms"])
     roofline = dict(roof_all[dominant], kernel=dominant)
-    elem_keys = ("residual", "grad", "assemble_direct") if fused else ("residual", "grad", "tangent_blocks", "assemble_rows")
+    elem_keys = ("residual", "grad", fkey) if fused else ("residual", "grad", "tangent_blocks", "assemble_rows")
     elem_ms = sum(st[k][0] for k in elem_keys) / nprof
     b_alg = 4 * d.S + 24 * d.S * d.Q + 8 * d.Q + 24 * d.S + 72.0 * nnz_coef / E + 24.0 * N / E
     stage_share = {k: round(st[k][0] / nprof, 4) for k in elem_keys + ("pcg", "update")}
@@ -334,6 +339,7 @@ def load_pmc_traffic(config):
         return {}, None
     names = {r"residual_kernel": "residual", r"tangent_blocks_kernel": "tangent_blocks",
              r"assemble_rows_kernel": "assemble_rows", r"assemble_direct_kernel": "assemble_direct",
+             r"assemble_affine_kernel": "assemble_affine",
              r"spmv_dir_dot_kernel": "spmv",
              r"cheb_step_kernel<false>": "cheb_step",                 # fp64 polynomial steps (cheb_bits 64)
              # fp32 recurrence, non-final steps (rocprofv3 leaves names with _Float16 arguments mangled)

@@ -29,6 +29,30 @@ extern "C" void rg_fetch(int* g_inst_off, int* g_row_off, int* gr_row, int* gr_a
   std::copy(g_rg.gi_pack.begin(), g_rg.gi_pack.end(), gi_pack);
 }
 
+// ---- affine-element form (build_row_groups4) -----------------------------------------------------------------------------
+static tlfea::RowGroups4Host g_rg4;
+extern "C" int rg4_build(int N, int E, const int* conn, const int* off, const int* cols, const int* n2e_off, const int* n2e,
+                         const double* x, const double* y, const double* z, int* sizes) {
+  if (!tlfea::build_row_groups4(N, E, conn, off, cols, n2e_off, n2e, x, y, z, g_rg4)) return 1;
+  sizes[0] = g_rg4.G();
+  sizes[1] = (int)(g_rg4.gi_head.size() / 2);
+  sizes[2] = g_rg4.acc_max;
+  sizes[3] = (int)(g_rg4.pt.size() / 4);
+  return 0;
+}
+extern "C" void rg4_fetch(int* g_inst_off, int* g_row_off, int* gr_row, int* gr_acc, int* gi_head, int* gi_ent, int* pt,
+                          int* g_pass_off, int* gr_info) {
+  std::copy(g_rg4.g_inst_off.begin(), g_rg4.g_inst_off.end(), g_inst_off);
+  std::copy(g_rg4.g_row_off.begin(), g_rg4.g_row_off.end(), g_row_off);
+  std::copy(g_rg4.gr_row.begin(), g_rg4.gr_row.end(), gr_row);
+  std::copy(g_rg4.gr_acc.begin(), g_rg4.gr_acc.end(), gr_acc);
+  std::copy(g_rg4.gi_head.begin(), g_rg4.gi_head.end(), gi_head);
+  std::copy(g_rg4.gi_ent.begin(), g_rg4.gi_ent.end(), gi_ent);
+  std::copy(g_rg4.pt.begin(), g_rg4.pt.end(), pt);
+  std::copy(g_rg4.g_pass_off.begin(), g_rg4.g_pass_off.end(), g_pass_off);
+  std::copy(g_rg4.gr_info.begin(), g_rg4.gr_info.end(), gr_info);
+}
+
 // ---- sparse direct solve: ordering + symbolic factorisation (csrc/direct_host.h) ----------------------------------------
 #include "../../total-lagrangian-fea_amd/csrc/direct_host.h"
 static tlfea::DirectHost g_dh;

@@ -138,6 +138,53 @@ def test_hessian(mesh, mat):
     d.Destroy()
 
 
+@pytest.mark.parametrize("tag", ["beam_3x2x1", "res2", "bunny"])
+@pytest.mark.parametrize("mat", ["svk", "svk_damped"])
+def test_hessian_affine_and_general_forms(tag, mat, monkeypatch):
+    """The fused assembly has two forms: straight-sided meshes (every reference mesh) take the affine-element kernel
+    (assembly mode 3), a mesh with ONE displaced mid-edge node must fall back to the general kernel (mode 2); both give
+    the oracle's H to 1e-12, and on the straight mesh the two forms agree with each other."""
+    X, conn = load_mesh(tag)
+    m = MATERIALS[mat]
+    fixed = fixed_x0(X) if len(fixed_x0(X)) else np.array([0, 3], dtype=np.int32)
+    h, rho = 1e-3, 1e12
+
+    def assemble(Xr, env):
+        if env:
+            monkeypatch.setenv("TLFEA_ASSEMBLE", env)
+        else:
+            monkeypatch.delenv("TLFEA_ASSEMBLE", raising=False)
+        o, d = make_oracle(Xr, conn, m, fixed), make_gpu(Xr, conn, m, fixed)
+        x, _ = perturbed_state(Xr)
+        set_state(o, d, x)
+        s = tl.SyncedNewtonSolver(d, d.get_n_constraint())
+        s.SetParameters(tl.SyncedNewtonParams(1e-4, 1e-4, 1e-4, rho, 5, 10, h))
+        s.AnalyzeHessianSparsity()
+        mode = s.GetAssemblyMode()
+        s.AssembleHessian()
+        ro, ci, val = s.RetrieveHessianCSRToCPU()
+        ro_o, ci_o, val_o = o.assemble_hessian(h, rho)
+        assert np.array_equal(ro, ro_o) and np.array_equal(ci, ci_o)
+        assert relerr(val, val_o) < TOL_ELEM, (env, mode)
+        s.AssembleHessian()
+        assert np.array_equal(val, s.RetrieveHessianCSRToCPU()[2])     # bitwise reproducible
+        del s
+        d.Destroy()
+        return mode, val
+
+    mode_a, val_a = assemble(X, None)
+    assert mode_a == 3
+    mode_g, val_g = assemble(X, "general")
+    assert mode_g == 2
+    assert relerr(val_a, val_g) < TOL_ELEM
+    Xc = X.copy()
+    mid = int(conn[0, 4])                                               # a mid-edge node of element 0: curve that edge
+    edge = np.linalg.norm(X[conn[0, 0]] - X[conn[0, 1]])
+    Xc[mid] += 0.03 * edge * np.array([0.3, -0.5, 0.8])
+    mode_c, _ = assemble(Xc, None)
+    assert mode_c == 2
+
+
 @pytest.mark.parametrize("tag", ["beam_3x2x1", "res2", "res4"])
 def test_linear_solve_pmg_vs_chebyshev_vs_direct(tag):
     """The same fp64 solution with the Chebyshev polynomial and with the two-level p-multigrid preconditioner."""

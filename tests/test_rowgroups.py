@@ -133,6 +133,76 @@ def test_row_groups_invariants(shim, mesh):
     assert np.median(hop) < 0.35 * np.linalg.norm(X.max(0) - X.min(0))
 
 
+@pytest.mark.parametrize("mesh", ["res2", "bunny", "box"])
+def test_row_groups_affine_form(shim, mesh):
+    """Work lists of the affine-element kernel (build_row_groups4): rows and instances owned once, the header and the
+    sixteen 16-bit block offsets of every instance -- entry (n, p) is the column of vertex n (p == n) or of the mid-edge
+    node of (n, p) --, passes of at most 16 instances that walk every group once."""
+    if mesh == "box":
+        X, conn = mu.structured_t10_box(5, 4, 3, 2.5, 2.0, 1.5)
+    else:
+        X, conn = load_mesh(mesh)
+    conn = np.ascontiguousarray(conn, dtype=np.int32)
+    N, (E, S) = X.shape[0], conn.shape
+    off, cols, n2e_off, n2e = adjacency(conn, N)
+    conn_cm = np.ascontiguousarray(conn.T)
+    x, y, z = (np.ascontiguousarray(X[:, k]) for k in range(3))
+    sizes = np.zeros(4, dtype=np.int32)
+    assert shim.rg4_build(N, E, ip(conn_cm), ip(off), ip(cols), ip(n2e_off), ip(n2e), dp(x), dp(y), dp(z), ip(sizes)) == 0
+    G, n_inst, acc_max, P = map(int, sizes)
+    assert n_inst == E * S and acc_max < 65536
+    g_inst_off, g_row_off = np.zeros(G + 1, np.int32), np.zeros(G + 1, np.int32)
+    gr_row, gr_acc = np.zeros(N, np.int32), np.zeros(N, np.int32)
+    gi_head, gi_ent = np.zeros(2 * n_inst, np.int32), np.zeros(8 * n_inst, np.int32)
+    pt, g_pass_off, gr_info = np.zeros(4 * P, np.int32), np.zeros(G + 1, np.int32), np.zeros(4 * N, np.int32)
+    shim.rg4_fetch(ip(g_inst_off), ip(g_row_off), ip(gr_row), ip(gr_acc), ip(gi_head), ip(gi_ent), ip(pt), ip(g_pass_off),
+                   ip(gr_info))
+    gi_head, pt, gr_info = gi_head.reshape(n_inst, 2), pt.reshape(P, 4), gr_info.reshape(N, 4)
+    words = gi_ent.view(np.uint16).reshape(n_inst, 4, 4)          # little endian: low half first = p 0, 1 | 2, 3
+    assert np.array_equal(np.sort(gr_row), np.arange(N))
+    assert np.array_equal(np.sort(gi_head[:, 0]), np.arange(E * S))
+    mid = np.array([[-1, 4, 6, 7], [4, -1, 5, 8], [6, 5, -1, 9], [7, 8, 9, -1]])   # FEAT10Data.cu:143
+    deg = np.diff(off)
+    pi = 0
+    for g in range(G):
+        rows = gr_row[g_row_off[g]:g_row_off[g + 1]]
+        acc = gr_acc[g_row_off[g]:g_row_off[g + 1]]
+        assert acc[0] == 0 and np.array_equal(np.diff(acc), 9 * deg[rows[:-1]])
+        assert acc[-1] + 9 * deg[rows[-1]] <= acc_max
+        w = g_inst_off[g]
+        for t, (i, a0) in enumerate(zip(rows, acc)):
+            c = cols[off[i]:off[i + 1]]
+            assert gr_info[g_row_off[g] + t].tolist() == [a0 | (int(np.searchsorted(c, i)) << 16), off[i], deg[i], i]
+            codes = n2e[n2e_off[i]:n2e_off[i + 1]]
+            assert np.array_equal(gi_head[w:w + len(codes), 0], codes)       # ascending element
+            assert np.all(gi_head[w:w + len(codes), 1] == 3 * deg[i])
+            for k, code in enumerate(codes):
+                e = code // S
+                assert conn[e, code % S] == i
+                for n in range(4):
+                    for p in range(4):
+                        j = n if p == n else mid[n, p]
+                        pos = int(np.searchsorted(c, conn[e, j]))
+                        assert c[pos] == conn[e, j] and words[w + k, n, p] == a0 // 3 + pos
+            w += len(codes)
+        assert w == g_inst_off[g + 1]
+        i0, i1, nr = g_inst_off[g], g_inst_off[g + 1], len(rows)
+        assert g_pass_off[g] == pi
+        p0 = i0
+        while True:
+            inst0, meta, row0, acc_n = pt[pi]
+            assert inst0 == p0 and (meta & 31) == min(16, i1 - p0) and (meta >> 8) == nr and row0 == g_row_off[g]
+            assert bool(meta & 32) == (p0 == i0) and bool(meta & 64) == (p0 + 16 >= i1)
+            assert acc_n == acc[-1] + 9 * deg[rows[-1]]
+            pi += 1
+            p0 += 16
+            if p0 >= i1:
+                break
+    assert pi == P and g_pass_off[-1] == P
+    fill = n_inst / (16.0 * P)
+    assert fill > 0.6, fill                                        # passes are mostly full (4 lanes per instance)
+
+
 @pytest.mark.parametrize("mesh", ["beam_3x2x1", "res2"])
 def test_direct_solver_symbolic_factor(shim, mesh):
     """Host set-up of the sparse direct solve (csrc/direct_host.h): the permutation is a bijection that keeps the three

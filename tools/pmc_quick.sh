@@ -6,7 +6,7 @@ export TMPDIR=/tmp
 CFG=${1:-C}; TAG=${2:-pmcQ}
 O=gpurun_out/$TAG
 rm -rf $O; mkdir -p $O
-KR='assemble_direct|residual_kernel|grad_kernel'
+KR='assemble_direct|assemble_affine|residual_kernel|grad_light'
 run() {
   local name=$1; shift
   rocprofv3 --pmc "$@" --kernel-include-regex "$KR" -d $O/$name -o run --output-format csv -- python3 tools/prof_elem.py $CFG 3 > $O/$name.log 2>&1 || { tail -20 $O/$name.log; return 1; }
@@ -21,8 +21,9 @@ for (k, c), v in sorted(agg.items()):
     print(f"{k},{c},{len(v)},{sum(v)/len(v):.1f}")
 PY
   rm -rf $O/$name
-  grep "us per launch" $O/$name.log; grep assemble_direct $O/$name.csv
+  grep "us per launch" $O/$name.log; grep "assemble_" $O/$name.csv
 }
 run tcc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum || exit 1
 run fetch FETCH_SIZE || exit 1
 run sq1 SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_LDS_IDX_ACTIVE || exit 1
+run sq2 SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_INSTS_SMEM SQ_ACTIVE_INST_LDS || exit 1

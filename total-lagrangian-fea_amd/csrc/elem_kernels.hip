@@ -248,7 +248,8 @@ template <int S, int Q, bool STORE, bool MASS>
 __global__ __launch_bounds__(128) void residual_kernel(ElemView m, Material mat, const double* __restrict__ v,
                                                       double* __restrict__ fbuf, double* __restrict__ Fo,
                                                       double* __restrict__ Po, double* __restrict__ Fdo,
-                                                      double* __restrict__ Pvo, double* __restrict__ Fq, MassTerm mt) {
+                                                      double* __restrict__ Pvo, double* __restrict__ Fq, MassTerm mt,
+                                                      double fq_h) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= m.E) return;
   const bool damp = (v != nullptr) && (mat.eta != 0.0 || mat.lamd != 0.0);  // FEAT10DataFunc.cuh:137
@@ -313,7 +314,29 @@ __global__ __launch_bounds__(128) void residual_kernel(ElemView m, Material mat,
       for (int i = 0; i < 3; i++)
 #pragma unroll
         for (int j = 0; j < 3; j++) F[i][j] += xn[a][i] * hq[a][j];
-    if (Fq) {  // row-major F per (element, point): what the fused assembly stages instead of rebuilding F
+    if (Fq && fq_h > 0.0) {
+      // affine form of the fused assembly: one 128-byte record per (element, point) = F row-major, B1 F F^T (upper
+      // triangle), C0 -- the point's share of h K + C_vis that does not depend on the node pair (SVK.cuh:35-55,
+      // FEAT10DataFunc.cuh:695-762)
+      const double T00 = F[0][0] * F[0][0] + F[0][1] * F[0][1] + F[0][2] * F[0][2],
+                   T01 = F[0][0] * F[1][0] + F[0][1] * F[1][1] + F[0][2] * F[1][2],
+                   T02 = F[0][0] * F[2][0] + F[0][1] * F[2][1] + F[0][2] * F[2][2],
+                   T11 = F[1][0] * F[1][0] + F[1][1] * F[1][1] + F[1][2] * F[1][2],
+                   T12 = F[1][0] * F[2][0] + F[1][1] * F[2][1] + F[1][2] * F[2][2],
+                   T22 = F[2][0] * F[2][0] + F[2][1] * F[2][1] + F[2][2] * F[2][2];
+      const double trE = 0.5 * (T00 + T11 + T22 - 3.0);
+      const double dVq = m.detJ[(size_t)e * Q + q] * m.qw[q];
+      const double B1 = dVq * (fq_h * mat.mu + mat.eta), C0 = dVq * fq_h * (mat.lambda * trE - mat.mu);
+      double2* fo = reinterpret_cast<double2*>(Fq + ((size_t)e * Q + q) * 16);
+      fo[0] = make_double2(F[0][0], F[0][1]);
+      fo[1] = make_double2(F[0][2], F[1][0]);
+      fo[2] = make_double2(F[1][1], F[1][2]);
+      fo[3] = make_double2(F[2][0], F[2][1]);
+      fo[4] = make_double2(F[2][2], B1 * T00);
+      fo[5] = make_double2(B1 * T01, B1 * T02);
+      fo[6] = make_double2(B1 * T11, B1 * T12);
+      fo[7] = make_double2(B1 * T22, C0);
+    } else if (Fq) {  // row-major F per (element, point): what the fused assembly stages instead of rebuilding F
       double* fo = Fq + ((size_t)e * Q + q) * 9;
 #pragma unroll
       for (int i = 0; i < 3; i++)
@@ -402,28 +425,29 @@ __global__ __launch_bounds__(128) void residual_kernel(ElemView m, Material mat,
 
 template <int S, int Q>
 static void launch_residual_t(hipStream_t s, const ElemView& m, const Material& mat, const double* v, double* fbuf,
-                              double* F, double* P, double* Fdot, double* Pvis, double* Fq, const MassTerm* mt) {
+                              double* F, double* P, double* Fdot, double* Pvis, double* Fq, const MassTerm* mt,
+                              double fq_h) {
   const dim3 grid((m.E + 127) / 128), block(128);
   MassTerm none{};
   none.vprev = nullptr;
   if (F)
-    hipLaunchKernelGGL((residual_kernel<S, Q, true, false>), grid, block, 0, s, m, mat, v, fbuf, F, P, Fdot, Pvis, Fq, none);
+    hipLaunchKernelGGL((residual_kernel<S, Q, true, false>), grid, block, 0, s, m, mat, v, fbuf, F, P, Fdot, Pvis, Fq, none,
+                       fq_h);
   else if (S == kNN && mt && mt->vprev && v)
     hipLaunchKernelGGL((residual_kernel<S, Q, false, (S == kNN)>), grid, block, 0, s, m, mat, v, fbuf, nullptr, nullptr,
-                       nullptr, nullptr, Fq, *mt);
+                       nullptr, nullptr, Fq, *mt, fq_h);
   else
     hipLaunchKernelGGL((residual_kernel<S, Q, false, false>), grid, block, 0, s, m, mat, v, fbuf, nullptr, nullptr, nullptr,
-                       nullptr, Fq, none);
+                       nullptr, Fq, none, fq_h);
 }
 
 void launch_residual(hipStream_t s, const ElemView& m, const Material& mat, const double* v, double* fbuf, double* F,
-                     double* P, double* Fdot, double* Pvis, double* Fq, const MassTerm* mt) {
-  if (m.S == 10) launch_residual_t<10, 5>(s, m, mat, v, fbuf, F, P, Fdot, Pvis, Fq, mt);
-  else if (m.S == 8) launch_residual_t<8, 12>(s, m, mat, v, fbuf, F, P, Fdot, Pvis, Fq, nullptr);
-  else launch_residual_t<16, 48>(s, m, mat, v, fbuf, F, P, Fdot, Pvis, Fq, nullptr);
+                     double* P, double* Fdot, double* Pvis, double* Fq, const MassTerm* mt, double fq_h) {
+  if (m.S == 10) launch_residual_t<10, 5>(s, m, mat, v, fbuf, F, P, Fdot, Pvis, Fq, mt, fq_h);
+  else if (m.S == 8) launch_residual_t<8, 12>(s, m, mat, v, fbuf, F, P, Fdot, Pvis, Fq, nullptr, 0.0);
+  else launch_residual_t<16, 48>(s, m, mat, v, fbuf, F, P, Fdot, Pvis, Fq, nullptr, 0.0);
 }
 
-// f_int[3i+d] = sum over the node's elements of their force rows (fixed order: ascending element id)
 __global__ void fint_gather_kernel(int N, Incidence inc, const double* __restrict__ fbuf,
                                    double* __restrict__ f_int) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1373,6 +1397,366 @@ void launch_assemble_direct(hipStream_t s, const ElemView& m, const Material& ma
   else
     hipLaunchKernelGGL(assemble_direct_kernel<0>, dim3(8 * per_xcd), dim3(64), lds, s, m, mat, h, rg, Fq, mval, 1.0 / h,
                        fixed_slot, nw, penalty, Hval, store_mode);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Affine-element form of the fused tangent + assembly (T10, SVK + Kelvin-Voigt).  On a straight-sided T10 element
+// grad N_j(q) = sum_n c_jn(q) g_n with the four CONSTANT vertex gradients g_n = grad L_n and coefficients that depend on
+// the rule only (corner j = n: 4 L_n(q) - 1; mid-edge j = (a, b): 4 L_b(q) on g_a, 4 L_a(q) on g_b).  The block of
+// (row node i, column node j) is bilinear in (grad N_i, grad N_j) at every point, so
+//     K_ij = sum_q sum_n c_jn(q) R_n(q),   R_n(q) = block(grad N_i(q), g_n; F(q))
+// and with the 5-point Keast rule (L = 1/4 at q0; L_m = 1/2 at point q_m, 1/6 at the other three) the sums over q
+// collapse:  with D_p = R_n(q_p), S = D_0 + .. + D_3,
+//     column "vertex n"      : 4/3 D_n - 1/3 S
+//     column "mid-edge (n,p)": 4/3 D_p + 2/3 S + R_n(q0)        (the share of vertex n; vertex p adds the mirror image)
+// One lane per (instance, vertex n): 5 block evaluations and four 3x3 results instead of ten lanes x 5 evaluations --
+// 2.2x fewer fp64 operations and 2.5x less LDS traffic per element than assemble_direct_kernel, and grad N (1 200 B per
+// element) is never read: the kernel stages per instance the element's 128-byte g record and the five 128-byte point
+// records {F, B1 F F^T, C0} the residual launch leaves behind.
+//   pass  = up to 16 instances x 4 lanes; records of the pass in LDS (104 doubles per instance: stride = 16 banks)
+//   sum   = ds_add_f64 into the group's row accumulators (H layout) as in assemble_direct_kernel; M/h and the pinned
+//           rows' penalty are added while a finished group streams out
+// Used when launch_affine_pre finds every element affine and the rule of the expected form (tlfea_api.hip); curved
+// elements keep assemble_direct_kernel.
+// ------------------------------------------------------------------------------------------------
+namespace {
+constexpr int kAfInst = 16;                 // instances per pass
+constexpr int kAfRec = 104;                 // doubles per staged instance: 16 (g, det J) + 5 x 16 (points) + pad
+constexpr int kAfStage = kAfInst * kAfRec;  // 1 664 doubles = 13 KiB
+}  // namespace
+
+__global__ void affine_pre_kernel(ElemView m, AffineView av, double* __restrict__ gvec, double* __restrict__ dev_max) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= m.E) return;
+  const double* gN = m.gradN + (size_t)e * (kNQ * 3 * kNN);
+  double g[4][3], gmax = 0.0;
+#pragma unroll
+  for (int p = 0; p < 4; p++)
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+      g[p][d] = gN[(av.qv[p] * 3 + d) * kNN + p];  // 4 L_p - 1 = 1 there
+      gmax = fmax(gmax, fabs(g[p][d]));
+    }
+  const int ea[6] = {0, 1, 0, 0, 1, 2}, eb[6] = {1, 2, 2, 3, 3, 3};  // FEAT10Data.cu:143
+  double dev = 0.0;
+  for (int q = 0; q < kNQ; q++) {
+    double L[4];
+#pragma unroll
+    for (int p = 0; p < 4; p++) L[p] = q == av.q0 ? 0.25 : (q == av.qv[p] ? 0.5 : 1.0 / 6.0);
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+#pragma unroll
+      for (int p = 0; p < 4; p++) dev = fmax(dev, fabs(gN[(q * 3 + d) * kNN + p] - (4.0 * L[p] - 1.0) * g[p][d]));
+#pragma unroll
+      for (int k = 0; k < 6; k++)
+        dev = fmax(dev, fabs(gN[(q * 3 + d) * kNN + 4 + k] - 4.0 * (L[eb[k]] * g[ea[k]][d] + L[ea[k]] * g[eb[k]][d])));
+    }
+  }
+  const double dj = m.detJ[(size_t)e * kNQ];
+  double rel = gmax > 0.0 ? dev / gmax : 1.0;
+  for (int q = 1; q < kNQ; q++) rel = fmax(rel, fabs(m.detJ[(size_t)e * kNQ + q] - dj) / fabs(dj));
+  if (!(rel == rel)) rel = 1.0;
+  double* o = gvec + (size_t)e * 16;
+#pragma unroll
+  for (int p = 0; p < 4; p++) {
+    o[4 * p + 0] = g[p][0];
+    o[4 * p + 1] = g[p][1];
+    o[4 * p + 2] = g[p][2];
+    o[4 * p + 3] = p == 0 ? dj : 0.0;
+  }
+  // positive doubles order like their bit patterns
+  atomicMax(reinterpret_cast<unsigned long long*>(dev_max), (unsigned long long)__double_as_longlong(rel));
+}
+
+void launch_affine_pre(hipStream_t s, const ElemView& m, const AffineView& av, double* gvec, double* dev_max) {
+  hipLaunchKernelGGL(affine_pre_kernel, dim3((m.E + 127) / 128), dim3(128), 0, s, m, av, gvec, dev_max);
+}
+
+struct AffineCoef {  // per rule point in the kernel's order (q0, q_0 .. q_3): record offset and the point's weights
+  int rec[5];        // 16 + 16 q
+  double cA[5], cB[5], cC[5];  // w_q (h lambda + lamd), w_q (h mu + eta), w_q h mu   (x det J = A1, B1, C1)
+};
+
+__global__ __launch_bounds__(64, 2) void assemble_affine_kernel(RowGroups4 rg, AffineCoef ac,
+                                                                const double* __restrict__ gvec,
+                                                                const double* __restrict__ Fq16,
+                                                                const double* __restrict__ cmass, double mscale,
+                                                                const int* __restrict__ fixed_slot,
+                                                                const double* __restrict__ nw, double penalty,
+                                                                double* __restrict__ Hval, int store_mode) {
+  extern __shared__ __attribute__((aligned(16))) double lds_af[];
+  double* stage = lds_af;                  // [kAfInst][kAfRec]
+  double* cml = lds_af + kAfStage;         // [10][16] mass coefficients of (row node, vertex n, p) x rho / h
+  double* acc = lds_af + kAfStage + 160;   // the group's rows, each in H's layout [d][3 deg]
+  // same walk as assemble_direct_kernel: XCD x owns a contiguous range of groups, its resident waves take them side by side
+  const int W = gridDim.x >> 3;
+  const int Gper = (rg.G + 7) >> 3;
+  const int gbeg = (blockIdx.x & 7) * Gper, gend = min(rg.G, gbeg + Gper);
+  if (gbeg + (int)(blockIdx.x >> 3) >= gend) return;
+  const int lane = threadIdx.x;
+  const int k = lane >> 2, n = lane & 3;  // instance k of the pass, vertex n
+  for (int t = lane; t < 160; t += 64) cml[t] = cmass[t] * mscale;
+  const int last_inst = rg.n_inst - 1;
+  int lg = gbeg + (blockIdx.x >> 3);
+  int lp = rg.g_pass_off[lg], lpe = rg.g_pass_off[lg + 1];
+  int np = 0, npe = 0;
+  if (lg + W < gend) {
+    np = rg.g_pass_off[lg + W];
+    npe = rg.g_pass_off[lg + W + 1];
+  }
+  bool lvalid = true;
+  auto advance = [&]() {
+    if (lp + 1 < lpe) {
+      lp++;
+      return;
+    }
+    lg += W;
+    lvalid = lg < gend;
+    lp = np;
+    lpe = npe;
+    if (lg + W < gend) {
+      np = rg.g_pass_off[lg + W];
+      npe = rg.g_pass_off[lg + W + 1];
+    }
+  };
+  // pass entries: current, +1, +2 (the lead cursor runs three passes ahead)
+  int4 ecur = rg.pt[lp];
+  advance();
+  bool vnxt = lvalid;
+  int4 enxt = rg.pt[vnxt ? lp : 0];
+  advance();
+  bool vn2 = lvalid;
+  int4 en2 = rg.pt[vn2 ? lp : 0];
+  advance();
+  auto inst_of = [&](const int4& en) { return min(en.x + min(k, max((en.y & 31) - 1, 0)), last_inst); };
+  int2 head, ent, head_n, ent_n;
+  {
+    const int ii = inst_of(ecur), in = inst_of(enxt);
+    head = rg.gi_head[ii];
+    ent = rg.gi_ent[(size_t)ii * 4 + n];
+    head_n = rg.gi_head[in];
+    ent_n = rg.gi_ent[(size_t)in * 4 + n];
+  }
+  // row records travel one pass ahead of the group they belong to; the pinned flag and the weight of a row are fetched
+  // at the group's first pass (independent loads) and used at its last
+  int4 ri = make_int4(0, 0, 0, 0), ri_n = make_int4(0, 0, 0, 0);
+  if (lane < (ecur.y >> 8)) ri_n = rg.gr_info[ecur.z + lane];
+  int fs = -1;
+  double wv = 1.0;
+  double* Sk = stage + k * kAfRec;
+  // records in flight: the four lanes of an instance fetch its 768 bytes (g record + five point records) 16 at a time;
+  // the loads of pass t + 1 are issued before pass t computes, so that a pass never waits for a round trip to memory
+  double2 sa, sb, s0, s1, s2, s3, s4, s5, s6, s7, s8, s9;
+  auto fetch = [&](const int2& hd) __attribute__((always_inline)) {
+    const int e = (store_mode & 256) ? 0 : hd.x / kNN;
+    const double2* gp = reinterpret_cast<const double2*>(gvec + (size_t)e * 16) + n;
+    const double2* fp = reinterpret_cast<const double2*>(Fq16 + (size_t)e * (kNQ * 16)) + n;
+    sa = gp[0]; sb = gp[4];
+    s0 = fp[0]; s1 = fp[4]; s2 = fp[8]; s3 = fp[12]; s4 = fp[16];
+    s5 = fp[20]; s6 = fp[24]; s7 = fp[28]; s8 = fp[32]; s9 = fp[36];
+  };
+  fetch(head);
+
+  bool vcur = true;
+#pragma unroll 1
+  while (vcur) {
+    const bool vn3 = lvalid;
+    const int4 en3 = rg.pt[vn3 ? lp : 0];
+    advance();
+    const int cnt = ecur.y & 31, nrows = ecur.y >> 8;
+    const bool first = (ecur.y & 32) != 0, last = (ecur.y & 64) != 0;
+    const int il = head.x - kNN * (head.x / kNN);
+    // ---- (1) indices of the pass after the next ---------------------------------------------------------------------
+    int2 head_nn, ent_nn;
+    {
+      const int ii = inst_of(en2);
+      head_nn = rg.gi_head[ii];
+      ent_nn = rg.gi_ent[(size_t)ii * 4 + n];
+    }
+    // ---- (2) first pass of a group: clear its accumulators, fetch its row records ---------------------------------
+    if (first) {
+      for (int t = lane; t < ecur.w; t += 64) acc[t] = 0.0;
+      ri = ri_n;
+      fs = -1;
+      wv = 1.0;
+      if (lane < nrows && fixed_slot) {
+        fs = fixed_slot[ri.w];
+        if (nw) wv = nw[ri.w];
+      }
+    }
+    if (vnxt && (enxt.y & 32) && lane < (enxt.y >> 8)) ri_n = rg.gr_info[enxt.z + lane];
+    wave_sync();  // the previous pass has read its records
+    // ---- (3) this pass's records into LDS, the next pass's records into flight ------------------------------------
+    {
+      double2* S2 = reinterpret_cast<double2*>(Sk) + n;
+      S2[0] = sa; S2[4] = sb;
+      S2[8] = s0; S2[12] = s1; S2[16] = s2; S2[20] = s3; S2[24] = s4;
+      S2[28] = s5; S2[32] = s6; S2[36] = s7; S2[40] = s8; S2[44] = s9;
+    }
+    wave_sync();
+    fetch(head_n);
+    // ---- (4) the lane's five block evaluations --------------------------------------------------------------------
+    // row node: vertex A (corner il) or edge (A, B) (mid-edge il) -- FEAT10Data.cu:143 packed 2 bits per entry
+    const int A = (0x904e4 >> (2 * il)) & 3;   // {0,1,2,3,0,1,0,0,1,2}
+    const int B = (0xfe9e4 >> (2 * il)) & 3;   // {0,1,2,3,1,2,2,3,3,3}
+    const bool mid = il >= 4;
+    double gA[3], gB[3], gn[3], detJ;
+    {
+      const double2 a01 = *reinterpret_cast<const double2*>(Sk + 4 * A), b01 = *reinterpret_cast<const double2*>(Sk + 4 * B),
+                    n01 = *reinterpret_cast<const double2*>(Sk + 4 * n);
+      gA[0] = a01.x; gA[1] = a01.y; gA[2] = Sk[4 * A + 2];
+      gB[0] = b01.x; gB[1] = b01.y; gB[2] = Sk[4 * B + 2];
+      gn[0] = n01.x; gn[1] = n01.y; gn[2] = Sk[4 * n + 2];
+      detJ = Sk[3];
+    }
+    // M/h (SyncedNewton.cu:214-259): on an affine element M_e(i, j) = rho det J sum_q w_q N_i N_j (FEAT10Data.cu:206-278)
+    // is det J times a constant of the rule; the two lanes of a mid-edge column add half of it each
+    double cmv[4];
+    {
+      const double2* cq = reinterpret_cast<const double2*>(cml + il * 16 + 4 * n);
+      const double2 c01 = cq[0], c23 = cq[1];
+      cmv[0] = detJ * c01.x; cmv[1] = detJ * c01.y; cmv[2] = detJ * c23.x; cmv[3] = detJ * c23.y;
+    }
+    double R0[9], D[4][9];
+    auto block = [&](const int sdx, double (&out)[9]) __attribute__((always_inline)) {
+      if (store_mode & 512) {  // timing experiment: no block arithmetic
+#pragma unroll
+        for (int t = 0; t < 9; t++) out[t] = 0.0;
+        return;
+      }
+      // grad N_i at this point = al g_A + be g_B
+      double al, be;
+      if (sdx == 0) {
+        al = mid ? 1.0 : 0.0;
+        be = al;
+      } else {
+        const int p = sdx - 1;
+        al = mid ? (B == p ? 2.0 : 2.0 / 3.0) : (A == p ? 1.0 : -1.0 / 3.0);
+        be = mid ? (A == p ? 2.0 : 2.0 / 3.0) : 0.0;
+      }
+      const double2* R2 = reinterpret_cast<const double2*>(Sk + ac.rec[sdx]);
+      const double2 r0 = R2[0], r1 = R2[1], r2 = R2[2], r3 = R2[3], r4 = R2[4], r5 = R2[5], r6 = R2[6], r7 = R2[7];
+      const double F0 = r0.x, F1 = r0.y, F2 = r1.x, F3 = r1.y, F4 = r2.x, F5 = r2.y, F6 = r3.x, F7 = r3.y, F8 = r4.x;
+      const double T00 = r4.y, T01 = r5.x, T02 = r5.y, T11 = r6.x, T12 = r6.y, T22 = r7.x, C0 = r7.y;
+      const double h0 = al * gA[0] + be * gB[0], h1 = al * gA[1] + be * gB[1], h2 = al * gA[2] + be * gB[2];
+      const double fi0 = F0 * h0 + F1 * h1 + F2 * h2, fi1 = F3 * h0 + F4 * h1 + F5 * h2, fi2 = F6 * h0 + F7 * h1 + F8 * h2;
+      const double b0 = F0 * gn[0] + F1 * gn[1] + F2 * gn[2], b1 = F3 * gn[0] + F4 * gn[1] + F5 * gn[2],
+                   b2 = F6 * gn[0] + F7 * gn[1] + F8 * gn[2];
+      const double sv = h0 * gn[0] + h1 * gn[1] + h2 * gn[2];  // grad N_i . g_n
+      const double tv = fi0 * b0 + fi1 * b1 + fi2 * b2;        // F grad N_i . F g_n
+      const double A1 = detJ * ac.cA[sdx], B1 = detJ * ac.cB[sdx], C1 = detJ * ac.cC[sdx];
+      const double cd = C0 * sv + C1 * tv;
+      const double u0 = A1 * fi0, u1 = A1 * fi1, u2 = A1 * fi2;
+      const double w0 = B1 * b0, w1 = B1 * b1, w2 = B1 * b2;
+      out[0] = u0 * b0 + w0 * fi0 + sv * T00 + cd;
+      out[1] = u0 * b1 + w0 * fi1 + sv * T01;
+      out[2] = u0 * b2 + w0 * fi2 + sv * T02;
+      out[3] = u1 * b0 + w1 * fi0 + sv * T01;
+      out[4] = u1 * b1 + w1 * fi1 + sv * T11 + cd;
+      out[5] = u1 * b2 + w1 * fi2 + sv * T12;
+      out[6] = u2 * b0 + w2 * fi0 + sv * T02;
+      out[7] = u2 * b1 + w2 * fi1 + sv * T12;
+      out[8] = u2 * b2 + w2 * fi2 + sv * T22 + cd;
+    };
+    block(0, R0);
+    block(1, D[0]);
+    block(2, D[1]);
+    block(3, D[2]);
+    block(4, D[3]);
+    // ---- (5) the lane's four blocks into the row accumulator ------------------------------------------------------
+    if (k < cnt && !(store_mode & 1024)) {
+      const int stride = head.y;
+      double S1[9];
+#pragma unroll
+      for (int t = 0; t < 9; t++) S1[t] = (D[0][t] + D[1][t]) + (D[2][t] + D[3][t]);
+#define TLFEA_LDS_ADD(p, v) (void)__hip_atomic_fetch_add((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+#pragma unroll
+      for (int p = 0; p < 4; p++) {
+        const int word = ((p < 2 ? ent.x : ent.y) >> (16 * (p & 1))) & 0xffff;
+        double* ap = acc + 3 * word;
+        const double ks = p == n ? -1.0 / 3.0 : 2.0 / 3.0, km = p == n ? 0.0 : 1.0;
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+#pragma unroll
+          for (int c = 0; c < 3; c++) {
+            const int t = 3 * r + c;
+            TLFEA_LDS_ADD(ap + r * stride + c, (4.0 / 3.0) * D[p][t] + (ks * S1[t] + km * R0[t]) + (r == c ? cmv[p] : 0.0));
+          }
+      }
+#undef TLFEA_LDS_ADD
+    }
+    // ---- (6) last pass of a group: h^2 rho J^T J on pinned rows (SyncedNewton.cu:292-341), rows stream out once ----
+    if (last) {
+      wave_sync();
+      if (lane < nrows && fs >= 0) {
+        const double pen = wv * penalty;
+        const int a0 = ri.x & 0xffff, dpos = ri.x >> 16, row = 3 * ri.z;
+#pragma unroll
+        for (int d = 0; d < 3; d++) acc[a0 + d * row + 3 * dpos + d] += pen;
+      }
+      wave_sync();
+      for (int r = 0; r < ((store_mode & 2048) ? 0 : nrows); r++) {
+        const int a0 = __shfl(ri.x, r) & 0xffff, off0 = __shfl(ri.y, r), n9 = 9 * __shfl(ri.z, r);
+        double* outp = Hval + (size_t)9 * off0;
+        for (int t = lane; t < n9; t += 64) store_through(outp + t, acc[a0 + t], store_mode & 3);
+      }
+    }
+    ecur = enxt;
+    enxt = en2;
+    en2 = en3;
+    vcur = vnxt;
+    vnxt = vn2;
+    vn2 = vn3;
+    head = head_n;
+    ent = ent_n;
+    head_n = head_nn;
+    ent_n = ent_nn;
+  }
+}
+
+void launch_assemble_affine(hipStream_t s, const ElemView& m, const Material& mat, double h, const RowGroups4& rg,
+                            const AffineView& av, const double* Fq16, const double* cmass, double rho0,
+                            const int* fixed_slot, const double* nw, double penalty, double* Hval) {
+  const size_t lds = (size_t)(kAfStage + 160 + rg.acc_max) * sizeof(double);
+  static size_t lds_attr = 0;
+  if (lds > 64 * 1024 && lds > lds_attr) {
+    (void)hipFuncSetAttribute((const void*)assemble_affine_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    lds_attr = lds;
+  }
+  static int n_cu = 0;
+  static size_t occ_lds = ~(size_t)0;
+  static int occ = 8;
+  if (!n_cu) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+    if (n_cu <= 0) n_cu = 256;
+  }
+  if (occ_lds != lds) {
+    int o = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, (const void*)assemble_affine_kernel, 64, lds) == hipSuccess && o > 0)
+      occ = o;
+    occ_lds = lds;
+  }
+  static const bool tune = std::getenv("TLFEA_AD_TUNE") != nullptr;
+  static int occ_env = std::getenv("TLFEA_AD_WAVES") ? std::atoi(std::getenv("TLFEA_AD_WAVES")) : 0;
+  static int store_mode = std::getenv("TLFEA_AD_STORE") ? std::atoi(std::getenv("TLFEA_AD_STORE")) : 0;
+  if (tune) {
+    store_mode = std::getenv("TLFEA_AD_STORE") ? std::atoi(std::getenv("TLFEA_AD_STORE")) : 0;
+    occ_env = std::getenv("TLFEA_AD_WAVES") ? std::atoi(std::getenv("TLFEA_AD_WAVES")) : 0;
+  }
+  const int occ_eff = occ_env > 0 ? occ_env : occ;
+  const int per_xcd = std::max(1, std::min((n_cu / 8) * occ_eff, (rg.G + 7) / 8));
+  AffineCoef ac;
+  for (int sdx = 0; sdx < 5; sdx++) {
+    const int q = sdx == 0 ? av.q0 : av.qv[sdx - 1];
+    ac.rec[sdx] = 16 + 16 * q;
+    ac.cA[sdx] = m.qw[q] * (h * mat.lambda + mat.lamd);
+    ac.cB[sdx] = m.qw[q] * (h * mat.mu + mat.eta);
+    ac.cC[sdx] = m.qw[q] * h * mat.mu;
+  }
+  hipLaunchKernelGGL(assemble_affine_kernel, dim3(8 * per_xcd), dim3(64), lds, s, rg, ac, av.gvec, Fq16, cmass, rho0 / h,
+                     fixed_slot, nw, penalty, Hval, store_mode);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -965,6 +965,15 @@ struct tlfea_newton_s {
   bool fq_in_residual = true;  // first-order solvers (AdamW, Nesterov, VBD) never assemble: their residual skips Fq
   int asm_mode = 0;
   double* d_Fq = nullptr;
+  // affine-element form of the fused kernel (straight-sided elements + the 5-point Keast rule): its work lists, the
+  // per-element vertex gradients; d_Fq then holds 16-double point records.  TLFEA_ASSEMBLE=general keeps the general form.
+  RowGroups4 rg4{0, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr};
+  int* d_rg4[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  AffineView av{nullptr, 0, {0, 0, 0, 0}};
+  double* d_gvec = nullptr;
+  double* d_cmass = nullptr;  // [10][16] element mass coefficients in the kernel's (row node, vertex n, p) order
+  bool affine_ok = false;
+  double affine_dev = -1.0;  // largest relative deviation from the affine form found at set-up (-1: not checked)
   // sparse direct solve (lin.method == 1): rocSOLVER re-factorisation on a host-computed ordering + factor pattern
   struct Direct {
     bool tried = false, ok = false;
@@ -1047,7 +1056,8 @@ extern "C" int tlfea_newton_create(tlfea_t10_t data, int n_constraints, tlfea_ne
   if (const char* e = std::getenv("TLFEA_SPMV_NT")) s->spmv_nt = std::atoi(e) != 0;
   if (const char* e = std::getenv("TLFEA_CHEB_BITS")) s->lin.cheb_bits = std::atoi(e);
   if (const char* e = std::getenv("TLFEA_PRECOND")) s->lin.precond = std::atoi(e);
-  if (const char* e = std::getenv("TLFEA_ASSEMBLE")) s->asm_mode = (std::string(e) == "kbuf") ? 1 : 0;
+  if (const char* e = std::getenv("TLFEA_ASSEMBLE"))
+    s->asm_mode = (std::string(e) == "kbuf") ? 1 : (std::string(e) == "general") ? 2 : 0;
   if (const char* e = std::getenv("TLFEA_MASS")) s->mass_mode = (std::string(e) == "csr") ? 1 : 0;
   *out = s;
   return tlfea_newton_setup(s);
@@ -1063,6 +1073,10 @@ extern "C" int tlfea_newton_destroy(tlfea_newton_t s) {
     if (p) (void)hipFree(p);
   for (int* p : s->d_rg)
     if (p) (void)hipFree(p);
+  for (int* p : s->d_rg4)
+    if (p) (void)hipFree(p);
+  if (s->d_gvec) (void)hipFree(s->d_gvec);
+  if (s->d_cmass) (void)hipFree(s->d_cmass);
   if (s->d_Fq) (void)hipFree(s->d_Fq);
   if (s->d_mbuf) (void)hipFree(s->d_mbuf);
   direct_destroy(s);
@@ -1166,8 +1180,78 @@ extern "C" int tlfea_newton_analyze_hessian_sparsity(tlfea_newton_t s) {
   if (d->kind == kT10 && s->asm_mode != 1 && d->h_X0.size() == 3 * (size_t)N) {
     // row groups of the fused tangent + assembly kernel (the element-block buffer Kbuf is then never allocated
     // unless the material is switched to Mooney-Rivlin: ensure_kbuf)
+    // affine form first: every element straight-sided (checked on the device against the stored grad N / det J) and the
+    // rule the 5-point Keast rule (L = 1/4 at one point, one vertex at 1/2 and three at 1/6 at the others)
+    bool affine = false;
+    if (s->asm_mode == 0 && d->have_dndu) {
+      AffineView av{nullptr, -1, {-1, -1, -1, -1}};
+      bool rule_ok = true;
+      for (int q = 0; q < kNQ && rule_ok; q++) {
+        const double L[4] = {1.0 - d->h_q[0][q] - d->h_q[1][q] - d->h_q[2][q], d->h_q[0][q], d->h_q[1][q], d->h_q[2][q]};
+        int n4 = 0, n2 = 0, n6 = 0, v2 = -1;
+        for (int k = 0; k < 4; k++) {
+          if (std::fabs(L[k] - 0.25) < 1e-14) n4++;
+          else if (std::fabs(L[k] - 0.5) < 1e-14) n2++, v2 = k;
+          else if (std::fabs(L[k] - 1.0 / 6.0) < 1e-14) n6++;
+        }
+        if (n4 == 4 && av.q0 < 0) av.q0 = q;
+        else if (n2 == 1 && n6 == 3 && av.qv[v2] < 0) av.qv[v2] = q;
+        else rule_ok = false;
+      }
+      if (rule_ok) {
+        double* d_dev = nullptr;
+        TRY(dmalloc(&s->d_gvec, (size_t)d->E * 16));
+        TRY(dmalloc(&d_dev, 1));
+        HIP_TRY(hipMemsetAsync(d_dev, 0, sizeof(double), d->stream));
+        av.gvec = s->d_gvec;
+        launch_affine_pre(d->stream, d->view(), av, s->d_gvec, d_dev);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(d->stream));
+        D2H(&s->affine_dev, d_dev, 1);
+        (void)hipFree(d_dev);
+        RowGroups4Host rh;
+        if (s->affine_dev <= 1e-12 &&
+            build_row_groups4(N, d->E, d->h_conn.data(), d->h_off.data(), d->h_cols.data(), d->h_n2e_off.data(),
+                              d->h_n2e.data(), d->h_X0.data(), d->h_X0.data() + N, d->h_X0.data() + 2 * (size_t)N, rh)) {
+          const std::vector<int>* src[5] = {&rh.g_pass_off, &rh.pt, &rh.gr_info, &rh.gi_head, &rh.gi_ent};
+          for (int k = 0; k < 5; k++) {
+            TRY(dmalloc(&s->d_rg4[k], src[k]->size() + 4));
+            HIP_TRY(hipMemcpy(s->d_rg4[k], src[k]->data(), src[k]->size() * sizeof(int), hipMemcpyHostToDevice));
+          }
+          s->rg4 = RowGroups4{rh.G(), d->E * d->S, rh.acc_max, s->d_rg4[0], reinterpret_cast<const int4*>(s->d_rg4[1]),
+                              reinterpret_cast<const int4*>(s->d_rg4[2]), reinterpret_cast<const int2*>(s->d_rg4[3]),
+                              reinterpret_cast<const int2*>(s->d_rg4[4])};
+          s->av = av;
+          {  // element mass coefficients C_ij = sum_q w_q N_i(q) N_j(q) (the rule of FEAT10Data.cu:206-278)
+            const int edges[6][2] = {{0, 1}, {1, 2}, {0, 2}, {0, 3}, {1, 3}, {2, 3}};  // FEAT10Data.cu:143
+            double Nq[kNQ][kNN], cm[160];
+            for (int q = 0; q < kNQ; q++) {
+              const double L[4] = {1.0 - d->h_q[0][q] - d->h_q[1][q] - d->h_q[2][q], d->h_q[0][q], d->h_q[1][q], d->h_q[2][q]};
+              for (int k = 0; k < 4; k++) Nq[q][k] = L[k] * (2.0 * L[k] - 1.0);
+              for (int k = 0; k < 6; k++) Nq[q][k + 4] = 4.0 * L[edges[k][0]] * L[edges[k][1]];
+            }
+            for (int il = 0; il < kNN; il++)
+              for (int n = 0; n < 4; n++)
+                for (int p = 0; p < 4; p++) {
+                  const int j = p == n ? n : t10_mid_of(n, p);
+                  double c = 0.0;
+                  for (int q = 0; q < kNQ; q++) c += d->h_qw[q] * Nq[q][il] * Nq[q][j];
+                  cm[il * 16 + 4 * n + p] = p == n ? c : 0.5 * c;
+                }
+            TRY(dmalloc(&s->d_cmass, 160));
+            HIP_TRY(hipMemcpy(s->d_cmass, cm, sizeof(cm), hipMemcpyHostToDevice));
+          }
+          TRY(dmalloc(&s->d_Fq, (size_t)d->E * d->Q * 16));
+          s->rg_ok = s->affine_ok = affine = true;
+        } else {
+          (void)hipFree(s->d_gvec);
+          s->d_gvec = nullptr;
+        }
+      }
+    }
     RowGroupsHost rh;
-    if (build_row_groups(N, d->E, d->S, d->h_conn.data(), d->h_off.data(), d->h_cols.data(), d->h_n2e_off.data(),
+    if (!affine &&
+        build_row_groups(N, d->E, d->S, d->h_conn.data(), d->h_off.data(), d->h_cols.data(), d->h_n2e_off.data(),
                          d->h_n2e.data(), d->h_X0.data(), d->h_X0.data() + N, d->h_X0.data() + 2 * (size_t)N, rh)) {
       const std::vector<int>* src[6] = {&rh.g_pass_off, &rh.pt, &rh.gr_info, &rh.gi_code, &rh.gi_mb, &rh.gi_pack};
       for (int k = 0; k < 6; k++) {
@@ -1487,6 +1571,19 @@ static bool lincons_on(tlfea_newton_t s) { return s->n_constraints > 0 && s->d->
 static bool use_direct(tlfea_newton_t s) {
   return s->rg_ok && s->asm_mode != 1 && s->d->kind == kT10 && s->d->mat.model == kSVK;
 }
+static double fq_h(tlfea_newton_t s) { return s->affine_ok ? s->prm.time_step : 0.0; }
+static void launch_fused(tlfea_newton_t s) {
+  tlfea_t10_t d = s->d;
+  const tlfea_newton_params& p = s->prm;
+  const int* fixed = pinned_on(s) ? d->d_fixed_slot : nullptr;
+  if (s->affine_ok)
+    launch_assemble_affine(s->stream, d->view(), d->mat, p.time_step, s->rg4, s->av, s->d_Fq, s->d_cmass,
+                           d->mass_rho0 > 0.0 ? d->mass_rho0 : 0.0, fixed, s->d_nw, p.time_step * p.time_step * p.rho,
+                           s->d_H);
+  else
+    launch_assemble_direct(s->stream, d->view(), d->mat, p.time_step, s->rg, s->d_Fq, d->d_mval, fixed, s->d_nw,
+                           p.time_step * p.time_step * p.rho, s->d_H);
+}
 static int ensure_kbuf(tlfea_newton_t s) {
   if (s->d_Kbuf) return 0;
   tlfea_t10_t d = s->d;
@@ -1522,7 +1619,7 @@ static int eval_gradient(tlfea_newton_t s, double* norm_g) {
     MassTerm mt{};
     if (mir) TRY(fill_mass_term(s, mt));
     launch_residual(s->stream, d->view(), d->mat, s->d_v, d->d_fbuf, nullptr, nullptr, nullptr, nullptr,
-                    (use_direct(s) && s->fq_in_residual) ? s->d_Fq : nullptr, mir ? &mt : nullptr);
+                    (use_direct(s) && s->fq_in_residual) ? s->d_Fq : nullptr, mir ? &mt : nullptr, fq_h(s));
     d->fbuf_valid = !mir;
     t.stop();
   }
@@ -1563,9 +1660,9 @@ static int assemble(tlfea_newton_t s, bool fq_fresh = true) {
   if (use_direct(s)) {
     StageTimer t(s, 3);
     if (!fq_fresh)
-      launch_residual(s->stream, d->view(), d->mat, s->d_v, d->d_fbuf, nullptr, nullptr, nullptr, nullptr, s->d_Fq);
-    launch_assemble_direct(s->stream, d->view(), d->mat, p.time_step, s->rg, s->d_Fq, d->d_mval,
-                           pinned ? d->d_fixed_slot : nullptr, s->d_nw, p.time_step * p.time_step * p.rho, s->d_H);
+      launch_residual(s->stream, d->view(), d->mat, s->d_v, d->d_fbuf, nullptr, nullptr, nullptr, nullptr, s->d_Fq, nullptr,
+                      fq_h(s));
+    launch_fused(s);
     if (lincons_on(s))  // + h^2 rho J^T J  (SyncedNewton.cu:292-341)
       launch_lin_constraint_hessian(s->stream, 3 * s->N, d->d_jtoff, d->d_jtcol, d->d_jtval, d->d_joff, d->d_jcol,
                                     d->d_jval, d->d_off, d->d_cols, p.time_step * p.time_step * p.rho, s->d_H);
@@ -2701,7 +2798,7 @@ extern "C" int tlfea_newton_get_precond(tlfea_newton_t s) {  // 1 Chebyshev poly
 extern "C" int tlfea_newton_get_assembly_mode(tlfea_newton_t s) {
   if (!s) return 0;
   if (tlfea_newton_analyze_hessian_sparsity(s)) return 0;
-  return use_direct(s) ? 2 : 1;
+  return use_direct(s) ? (s->affine_ok ? 3 : 2) : 1;
 }
 extern "C" int tlfea_newton_get_linsolve_info(tlfea_newton_t s, int* cheb_degree, int* cheb_bits, int* cheb_vector_bits) {
   if (!s) return fail("null argument");
@@ -2752,16 +2849,14 @@ extern "C" int tlfea_newton_time_kernels(tlfea_newton_t s, int reps, double* out
         const bool mir = mass_in_residual(s);
         if (mir) TRY(fill_mass_term(s, mt));
         launch_residual(s->stream, d->view(), d->mat, s->d_v, d->d_fbuf, nullptr, nullptr, nullptr, nullptr,
-                        use_direct(s) ? s->d_Fq : nullptr, mir ? &mt : nullptr);
+                        use_direct(s) ? s->d_Fq : nullptr, mir ? &mt : nullptr, fq_h(s));
       }
       else if (k == 1) {
         if (use_direct(s)) break;  // no separate tangent launch on the fused path: out[1] = 0
         TRY(ensure_kbuf(s));
         launch_tangent_blocks(s->stream, d->view(), d->mat, p.time_step, s->d_Kbuf);
       } else if (k == 2 && use_direct(s))  // out[2] = the fused tangent + assembly launch
-        launch_assemble_direct(s->stream, d->view(), d->mat, p.time_step, s->rg, s->d_Fq, d->d_mval,
-                               pinned_on(s) ? d->d_fixed_slot : nullptr, s->d_nw,
-                               p.time_step * p.time_step * p.rho, s->d_H);
+        launch_fused(s);
       else if (k == 2)
         launch_assemble_rows(s->stream, N, d->S, d->maxdeg, d->inc(), s->d_Kbuf, d->d_mval, 1.0 / p.time_step,
                              pinned_on(s) ? d->d_fixed_slot : nullptr, s->d_nw,

@@ -81,14 +81,33 @@ struct RowGroups {
                           //          bit 31: first contribution to the block (carries its M/h)
 };
 
+// Work lists of the affine-element form (assemble_affine_kernel; rowgroup_host.h build_row_groups4): passes of up to 16
+// instances, 4 lanes per instance.
+struct RowGroups4 {
+  int G, n_inst, acc_max;
+  const int* g_pass_off;  // [G+1]
+  const int4* pt;         // [P] first instance | count (bits 0-4) + 32 first + 64 last + (rows << 8) | first row | acc doubles
+  const int4* gr_info;    // [N] as RowGroups
+  const int2* gi_head;    // [10 E] element * 10 + local row node | 3 deg
+  const int2* gi_ent;     // [10 E][4] per (instance, vertex n): (acc offset / 3) of the blocks (n, p), p = 0..3, 16 bits each
+};
+// What the affine form knows about the mesh and the rule: straight-sided T10 elements have constant vertex gradients
+// g_m = grad L_m and constant det J; the 5-point Keast rule has L = 1/4 at point q0 and L_m = 1/2 (others 1/6) at
+// point qv[m].  gvec: [E][16] = g_0 | detJ | g_1 | - | g_2 | - | g_3 | -.
+struct AffineView {
+  const double* gvec;
+  int q0, qv[4];
+};
+
 // ---- launch wrappers (defined in the .hip files) -------------------------------------------
 void launch_dndu_pre(hipStream_t s, int E, int Epad, const int* conn, const double* x, const double* y,
                      const double* z, const double* qx, const double* qy, const double* qz,
                      double* gradN, double* gradN_t, double* detJ);
 void launch_residual(hipStream_t s, const ElemView& m, const Material& mat, const double* v /*or null*/,
                      double* fbuf /*[E][30]*/, double* F, double* P, double* Fdot, double* Pvis,
-                     double* Fq = nullptr /*[Q][E][9] row-major F per point, for the fused assembly*/,
-                     const MassTerm* mt = nullptr /*T10: also write the per-element inertia rows*/);
+                     double* Fq = nullptr /*[E][Q][9] row-major F per point, for the fused assembly*/,
+                     const MassTerm* mt = nullptr /*T10: also write the per-element inertia rows*/,
+                     double fq_h = 0.0 /*> 0: Fq holds [E][Q][16] records {F, B1 F F^T, C0} for this time step*/);
 // grad L without the mass CSR product (T10, inertia rows from the residual launch): 8 lanes per node
 void launch_grad_light(hipStream_t s, int N, int Epad, const Incidence& inc, const double* fbuf, const double* mbuf,
                        const double* f_ext, const double* x, const double* y, const double* z, const double* xt,
@@ -98,6 +117,15 @@ void launch_grad_light(hipStream_t s, int N, int Epad, const Incidence& inc, con
 void launch_assemble_direct(hipStream_t s, const ElemView& m, const Material& mat, double h, const RowGroups& rg,
                             const double* Fq, const double* mval, const int* fixed_slot, const double* nw,
                             double penalty, double* Hval);
+// affine-element set-up: gvec from grad N / det J, and the largest relative deviation of the stored grad N / det J from
+// the affine form (dev_max: one double on the device, zeroed by the caller)
+void launch_affine_pre(hipStream_t s, const ElemView& m, const AffineView& av, double* gvec, double* dev_max);
+// fused tangent + row assembly, affine elements: Fq16 = [E][5][16] records {F, B1 F F^T, C0} of the last residual launch
+void launch_assemble_affine(hipStream_t s, const ElemView& m, const Material& mat, double h, const RowGroups4& rg,
+                            const AffineView& av, const double* Fq16,
+                            const double* cmass /*[10][16] sum_q w_q N_i N_j per (row node, vertex n, p); mid-edge columns halved*/,
+                            double rho0 /*density of the assembled mass matrix, 0 = none*/, const int* fixed_slot,
+                            const double* nw, double penalty, double* Hval);
 void launch_tangent_blocks(hipStream_t s, const ElemView& m, const Material& mat, double h,
                            double* Kbuf /*[E][55][9]*/);
 void launch_assemble_rows(hipStream_t s, int N, int S, int maxdeg, const Incidence& inc, const double* Kbuf,
