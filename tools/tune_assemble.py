@@ -22,7 +22,7 @@ mode = s.GetAssemblyMode()
 print("assembly mode", mode, "(3 = affine-element form, 2 = general fused form)", flush=True)
 if mode == 3:
     quick = os.environ.get("TLFEA_TUNE_QUICK")
-    for store, waves in (((0, 0),) if quick else ((0, 0), (512, 0), (1024, 0), (1536, 0), (2048, 0), (3584, 0), (3840, 0))):
+    for store, waves in (((0, 0),) if quick else ((0, 0), (512, 0), (1024, 0), (2048, 0), (4096, 0))):
         os.environ["TLFEA_AD_WAVES"], os.environ["TLFEA_AD_STORE"] = str(waves), str(store)
         t = s.TimeKernels(reps=5)
         print(f"store={store} waves/CU={waves or 'auto'}: assemble_affine {t['assemble_rows'] * 1e3:.1f} us residual {t['residual'] * 1e3:.1f} us", flush=True)

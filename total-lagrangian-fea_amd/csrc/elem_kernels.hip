@@ -249,7 +249,7 @@ __global__ __launch_bounds__(128) void residual_kernel(ElemView m, Material mat,
                                                       double* __restrict__ fbuf, double* __restrict__ Fo,
                                                       double* __restrict__ Po, double* __restrict__ Fdo,
                                                       double* __restrict__ Pvo, double* __restrict__ Fq, MassTerm mt,
-                                                      double fq_h) {
+                                                      double fq_h, int fq_slots) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= m.E) return;
   const bool damp = (v != nullptr) && (mat.eta != 0.0 || mat.lamd != 0.0);  // FEAT10DataFunc.cuh:137
@@ -327,7 +327,7 @@ __global__ __launch_bounds__(128) void residual_kernel(ElemView m, Material mat,
       const double trE = 0.5 * (T00 + T11 + T22 - 3.0);
       const double dVq = m.detJ[(size_t)e * Q + q] * m.qw[q];
       const double B1 = dVq * (fq_h * mat.mu + mat.eta), C0 = dVq * fq_h * (mat.lambda * trE - mat.mu);
-      double2* fo = reinterpret_cast<double2*>(Fq + ((size_t)e * Q + q) * 16);
+      double2* fo = reinterpret_cast<double2*>(Fq + ((size_t)e * Q + ((fq_slots >> (4 * q)) & 15)) * 16);
       fo[0] = make_double2(F[0][0], F[0][1]);
       fo[1] = make_double2(F[0][2], F[1][0]);
       fo[2] = make_double2(F[1][1], F[1][2]);
@@ -426,26 +426,26 @@ __global__ __launch_bounds__(128) void residual_kernel(ElemView m, Material mat,
 template <int S, int Q>
 static void launch_residual_t(hipStream_t s, const ElemView& m, const Material& mat, const double* v, double* fbuf,
                               double* F, double* P, double* Fdot, double* Pvis, double* Fq, const MassTerm* mt,
-                              double fq_h) {
+                              double fq_h, int fq_slots) {
   const dim3 grid((m.E + 127) / 128), block(128);
   MassTerm none{};
   none.vprev = nullptr;
   if (F)
     hipLaunchKernelGGL((residual_kernel<S, Q, true, false>), grid, block, 0, s, m, mat, v, fbuf, F, P, Fdot, Pvis, Fq, none,
-                       fq_h);
+                       fq_h, fq_slots);
   else if (S == kNN && mt && mt->vprev && v)
     hipLaunchKernelGGL((residual_kernel<S, Q, false, (S == kNN)>), grid, block, 0, s, m, mat, v, fbuf, nullptr, nullptr,
-                       nullptr, nullptr, Fq, *mt, fq_h);
+                       nullptr, nullptr, Fq, *mt, fq_h, fq_slots);
   else
     hipLaunchKernelGGL((residual_kernel<S, Q, false, false>), grid, block, 0, s, m, mat, v, fbuf, nullptr, nullptr, nullptr,
-                       nullptr, Fq, none, fq_h);
+                       nullptr, Fq, none, fq_h, fq_slots);
 }
 
 void launch_residual(hipStream_t s, const ElemView& m, const Material& mat, const double* v, double* fbuf, double* F,
-                     double* P, double* Fdot, double* Pvis, double* Fq, const MassTerm* mt, double fq_h) {
-  if (m.S == 10) launch_residual_t<10, 5>(s, m, mat, v, fbuf, F, P, Fdot, Pvis, Fq, mt, fq_h);
-  else if (m.S == 8) launch_residual_t<8, 12>(s, m, mat, v, fbuf, F, P, Fdot, Pvis, Fq, nullptr, 0.0);
-  else launch_residual_t<16, 48>(s, m, mat, v, fbuf, F, P, Fdot, Pvis, Fq, nullptr, 0.0);
+                     double* P, double* Fdot, double* Pvis, double* Fq, const MassTerm* mt, double fq_h, int fq_slots) {
+  if (m.S == 10) launch_residual_t<10, 5>(s, m, mat, v, fbuf, F, P, Fdot, Pvis, Fq, mt, fq_h, fq_slots);
+  else if (m.S == 8) launch_residual_t<8, 12>(s, m, mat, v, fbuf, F, P, Fdot, Pvis, Fq, nullptr, 0.0, 0);
+  else launch_residual_t<16, 48>(s, m, mat, v, fbuf, F, P, Fdot, Pvis, Fq, nullptr, 0.0, 0);
 }
 
 __global__ void fint_gather_kernel(int N, Incidence inc, const double* __restrict__ fbuf,
@@ -1472,18 +1472,19 @@ void launch_affine_pre(hipStream_t s, const ElemView& m, const AffineView& av, d
   hipLaunchKernelGGL(affine_pre_kernel, dim3((m.E + 127) / 128), dim3(128), 0, s, m, av, gvec, dev_max);
 }
 
-struct AffineCoef {  // per rule point in the kernel's order (q0, q_0 .. q_3): record offset and the point's weights
-  int rec[5];        // 16 + 16 q
+struct AffineCoef {  // per rule point in the kernel's order (q0, q_0 .. q_3 = the record slots the residual launch writes)
   double cA[5], cB[5], cC[5];  // w_q (h lambda + lamd), w_q (h mu + eta), w_q h mu   (x det J = A1, B1, C1)
 };
 
+template <int TIMING>
 __global__ __launch_bounds__(64, 2) void assemble_affine_kernel(RowGroups4 rg, AffineCoef ac,
                                                                 const double* __restrict__ gvec,
                                                                 const double* __restrict__ Fq16,
                                                                 const double* __restrict__ cmass, double mscale,
                                                                 const int* __restrict__ fixed_slot,
                                                                 const double* __restrict__ nw, double penalty,
-                                                                double* __restrict__ Hval, int store_mode) {
+                                                                double* __restrict__ Hval, int store_mode,
+                                                                unsigned long long* __restrict__ tdbg) {
   extern __shared__ __attribute__((aligned(16))) double lds_af[];
   double* stage = lds_af;                  // [kAfInst][kAfRec]
   double* cml = lds_af + kAfStage;         // [10][16] mass coefficients of (row node, vertex n, p) x rho / h
@@ -1497,12 +1498,20 @@ __global__ __launch_bounds__(64, 2) void assemble_affine_kernel(RowGroups4 rg, A
   const int k = lane >> 2, n = lane & 3;  // instance k of the pass, vertex n
   for (int t = lane; t < 160; t += 64) cml[t] = cmass[t] * mscale;
   const int last_inst = rg.n_inst - 1;
+  // The walk over the pass table is wave-uniform, but its loads inside the loop are VECTOR loads (every lane the same
+  // address, made opaque to the compiler by zl) read back with readfirstlane one pass later: a scalar load shares its
+  // counter with LDS, so that every LDS wait of a pass would also wait for the table entry fetched at its top.
+  const int zl = __builtin_amdgcn_mbcnt_lo(0u, 0u);  // 0 in every lane
+  auto uni4 = [](const int4& v) {
+    return make_int4(__builtin_amdgcn_readfirstlane(v.x), __builtin_amdgcn_readfirstlane(v.y),
+                     __builtin_amdgcn_readfirstlane(v.z), __builtin_amdgcn_readfirstlane(v.w));
+  };
   int lg = gbeg + (blockIdx.x >> 3);
   int lp = rg.g_pass_off[lg], lpe = rg.g_pass_off[lg + 1];
-  int np = 0, npe = 0;
+  int npx = 0, npy = 0;  // pass range of the wave's next group (vector registers, fetched one group ahead)
   if (lg + W < gend) {
-    np = rg.g_pass_off[lg + W];
-    npe = rg.g_pass_off[lg + W + 1];
+    npx = rg.g_pass_off[lg + W + zl];
+    npy = rg.g_pass_off[lg + W + 1 + zl];
   }
   bool lvalid = true;
   auto advance = [&]() {
@@ -1512,11 +1521,11 @@ __global__ __launch_bounds__(64, 2) void assemble_affine_kernel(RowGroups4 rg, A
     }
     lg += W;
     lvalid = lg < gend;
-    lp = np;
-    lpe = npe;
+    lp = __builtin_amdgcn_readfirstlane(npx);
+    lpe = __builtin_amdgcn_readfirstlane(npy);
     if (lg + W < gend) {
-      np = rg.g_pass_off[lg + W];
-      npe = rg.g_pass_off[lg + W + 1];
+      npx = rg.g_pass_off[lg + W + zl];
+      npy = rg.g_pass_off[lg + W + 1 + zl];
     }
   };
   // pass entries: current, +1, +2 (the lead cursor runs three passes ahead)
@@ -1557,11 +1566,20 @@ __global__ __launch_bounds__(64, 2) void assemble_affine_kernel(RowGroups4 rg, A
   };
   fetch(head);
 
+  // TIMING: shader-clock cycles per phase, summed over the wave's passes (tools only; perturbs the schedule a little)
+  unsigned long long tph[7] = {0, 0, 0, 0, 0, 0, 0}, tlast = 0, npass = 0;
+#define TLFEA_TICK(i)                                                     \
+  if (TIMING) {                                                           \
+    const unsigned long long tn = __builtin_readcyclecounter();           \
+    tph[i] += tn - tlast;                                                 \
+    tlast = tn;                                                           \
+  }
+  if (TIMING) tlast = __builtin_readcyclecounter();
   bool vcur = true;
 #pragma unroll 1
   while (vcur) {
     const bool vn3 = lvalid;
-    const int4 en3 = rg.pt[vn3 ? lp : 0];
+    const int4 en3v = rg.pt[(vn3 ? lp : 0) + zl];
     advance();
     const int cnt = ecur.y & 31, nrows = ecur.y >> 8;
     const bool first = (ecur.y & 32) != 0, last = (ecur.y & 64) != 0;
@@ -1585,6 +1603,7 @@ __global__ __launch_bounds__(64, 2) void assemble_affine_kernel(RowGroups4 rg, A
       }
     }
     if (vnxt && (enxt.y & 32) && lane < (enxt.y >> 8)) ri_n = rg.gr_info[enxt.z + lane];
+    TLFEA_TICK(0)  // pass table, index loads, accumulator clear
     wave_sync();  // the previous pass has read its records
     // ---- (3) this pass's records into LDS, the next pass's records into flight ------------------------------------
     {
@@ -1594,6 +1613,7 @@ __global__ __launch_bounds__(64, 2) void assemble_affine_kernel(RowGroups4 rg, A
       S2[28] = s5; S2[32] = s6; S2[36] = s7; S2[40] = s8; S2[44] = s9;
     }
     wave_sync();
+    TLFEA_TICK(1)  // records into LDS (waits for the loads of the previous pass)
     fetch(head_n);
     // ---- (4) the lane's five block evaluations --------------------------------------------------------------------
     // row node: vertex A (corner il) or edge (A, B) (mid-edge il) -- FEAT10Data.cu:143 packed 2 bits per entry
@@ -1617,8 +1637,13 @@ __global__ __launch_bounds__(64, 2) void assemble_affine_kernel(RowGroups4 rg, A
       const double2 c01 = cq[0], c23 = cq[1];
       cmv[0] = detJ * c01.x; cmv[1] = detJ * c01.y; cmv[2] = detJ * c23.x; cmv[3] = detJ * c23.y;
     }
+    TLFEA_TICK(2)  // next pass's loads issued, g / mass coefficients read
     double R0[9], D[4][9];
     auto block = [&](const int sdx, double (&out)[9]) __attribute__((always_inline)) {
+      const double2* R2 = reinterpret_cast<const double2*>(Sk + 16 + 16 * sdx);
+      const double2 r0 = R2[0], r1 = R2[1], r2 = R2[2], r3 = R2[3], r4 = R2[4], r5 = R2[5], r6 = R2[6], r7 = R2[7];
+      const double F0 = r0.x, F1 = r0.y, F2 = r1.x, F3 = r1.y, F4 = r2.x, F5 = r2.y, F6 = r3.x, F7 = r3.y, F8 = r4.x;
+      const double T00 = r4.y, T01 = r5.x, T02 = r5.y, T11 = r6.x, T12 = r6.y, T22 = r7.x, C0 = r7.y;
       if (store_mode & 512) {  // timing experiment: no block arithmetic
 #pragma unroll
         for (int t = 0; t < 9; t++) out[t] = 0.0;
@@ -1634,10 +1659,6 @@ __global__ __launch_bounds__(64, 2) void assemble_affine_kernel(RowGroups4 rg, A
         al = mid ? (B == p ? 2.0 : 2.0 / 3.0) : (A == p ? 1.0 : -1.0 / 3.0);
         be = mid ? (A == p ? 2.0 : 2.0 / 3.0) : 0.0;
       }
-      const double2* R2 = reinterpret_cast<const double2*>(Sk + ac.rec[sdx]);
-      const double2 r0 = R2[0], r1 = R2[1], r2 = R2[2], r3 = R2[3], r4 = R2[4], r5 = R2[5], r6 = R2[6], r7 = R2[7];
-      const double F0 = r0.x, F1 = r0.y, F2 = r1.x, F3 = r1.y, F4 = r2.x, F5 = r2.y, F6 = r3.x, F7 = r3.y, F8 = r4.x;
-      const double T00 = r4.y, T01 = r5.x, T02 = r5.y, T11 = r6.x, T12 = r6.y, T22 = r7.x, C0 = r7.y;
       const double h0 = al * gA[0] + be * gB[0], h1 = al * gA[1] + be * gB[1], h2 = al * gA[2] + be * gB[2];
       const double fi0 = F0 * h0 + F1 * h1 + F2 * h2, fi1 = F3 * h0 + F4 * h1 + F5 * h2, fi2 = F6 * h0 + F7 * h1 + F8 * h2;
       const double b0 = F0 * gn[0] + F1 * gn[1] + F2 * gn[2], b1 = F3 * gn[0] + F4 * gn[1] + F5 * gn[2],
@@ -1663,6 +1684,7 @@ __global__ __launch_bounds__(64, 2) void assemble_affine_kernel(RowGroups4 rg, A
     block(2, D[1]);
     block(3, D[2]);
     block(4, D[3]);
+    TLFEA_TICK(3)  // five block evaluations
     // ---- (5) the lane's four blocks into the row accumulator ------------------------------------------------------
     if (k < cnt && !(store_mode & 1024)) {
       const int stride = head.y;
@@ -1674,6 +1696,7 @@ __global__ __launch_bounds__(64, 2) void assemble_affine_kernel(RowGroups4 rg, A
       for (int p = 0; p < 4; p++) {
         const int word = ((p < 2 ? ent.x : ent.y) >> (16 * (p & 1))) & 0xffff;
         double* ap = acc + 3 * word;
+        if (store_mode & 4096) ap = acc + 3 * (lane + 64 * p);  // timing experiment: no two lanes add to one address
         const double ks = p == n ? -1.0 / 3.0 : 2.0 / 3.0, km = p == n ? 0.0 : 1.0;
 #pragma unroll
         for (int r = 0; r < 3; r++)
@@ -1685,6 +1708,7 @@ __global__ __launch_bounds__(64, 2) void assemble_affine_kernel(RowGroups4 rg, A
       }
 #undef TLFEA_LDS_ADD
     }
+    TLFEA_TICK(4)  // LDS adds
     // ---- (6) last pass of a group: h^2 rho J^T J on pinned rows (SyncedNewton.cu:292-341), rows stream out once ----
     if (last) {
       wave_sync();
@@ -1696,14 +1720,17 @@ __global__ __launch_bounds__(64, 2) void assemble_affine_kernel(RowGroups4 rg, A
       }
       wave_sync();
       for (int r = 0; r < ((store_mode & 2048) ? 0 : nrows); r++) {
-        const int a0 = __shfl(ri.x, r) & 0xffff, off0 = __shfl(ri.y, r), n9 = 9 * __shfl(ri.z, r);
+        const int a0 = __builtin_amdgcn_readlane(ri.x, r) & 0xffff, off0 = __builtin_amdgcn_readlane(ri.y, r),
+                  n9 = 9 * __builtin_amdgcn_readlane(ri.z, r);
         double* outp = Hval + (size_t)9 * off0;
         for (int t = lane; t < n9; t += 64) store_through(outp + t, acc[a0 + t], store_mode & 3);
       }
     }
+    TLFEA_TICK(5)  // rows out
+    npass++;
     ecur = enxt;
     enxt = en2;
-    en2 = en3;
+    en2 = uni4(en3v);
     vcur = vnxt;
     vnxt = vn2;
     vn2 = vn3;
@@ -1712,15 +1739,22 @@ __global__ __launch_bounds__(64, 2) void assemble_affine_kernel(RowGroups4 rg, A
     head_n = head_nn;
     ent_n = ent_nn;
   }
+  if (TIMING && lane == 0) {
+    for (int i = 0; i < 6; i++) atomicAdd(tdbg + i, tph[i]);
+    atomicAdd(tdbg + 6, npass);
+    atomicAdd(tdbg + 7, 1ULL);
+  }
+#undef TLFEA_TICK
 }
 
 void launch_assemble_affine(hipStream_t s, const ElemView& m, const Material& mat, double h, const RowGroups4& rg,
                             const AffineView& av, const double* Fq16, const double* cmass, double rho0,
                             const int* fixed_slot, const double* nw, double penalty, double* Hval) {
+  const void* fn = (const void*)assemble_affine_kernel<0>;
   const size_t lds = (size_t)(kAfStage + 160 + rg.acc_max) * sizeof(double);
   static size_t lds_attr = 0;
   if (lds > 64 * 1024 && lds > lds_attr) {
-    (void)hipFuncSetAttribute((const void*)assemble_affine_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     lds_attr = lds;
   }
   static int n_cu = 0;
@@ -1734,8 +1768,7 @@ void launch_assemble_affine(hipStream_t s, const ElemView& m, const Material& ma
   }
   if (occ_lds != lds) {
     int o = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, (const void*)assemble_affine_kernel, 64, lds) == hipSuccess && o > 0)
-      occ = o;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, fn, 64, lds) == hipSuccess && o > 0) occ = o;
     occ_lds = lds;
   }
   static const bool tune = std::getenv("TLFEA_AD_TUNE") != nullptr;
@@ -1750,13 +1783,28 @@ void launch_assemble_affine(hipStream_t s, const ElemView& m, const Material& ma
   AffineCoef ac;
   for (int sdx = 0; sdx < 5; sdx++) {
     const int q = sdx == 0 ? av.q0 : av.qv[sdx - 1];
-    ac.rec[sdx] = 16 + 16 * q;
     ac.cA[sdx] = m.qw[q] * (h * mat.lambda + mat.lamd);
     ac.cB[sdx] = m.qw[q] * (h * mat.mu + mat.eta);
     ac.cC[sdx] = m.qw[q] * h * mat.mu;
   }
-  hipLaunchKernelGGL(assemble_affine_kernel, dim3(8 * per_xcd), dim3(64), lds, s, rg, ac, av.gvec, Fq16, cmass, rho0 / h,
-                     fixed_slot, nw, penalty, Hval, store_mode);
+  static const bool timing = std::getenv("TLFEA_AF_TIMING") != nullptr;  // tools only: per-phase shader clocks on stderr
+  if (timing) {
+    static unsigned long long* d_t = nullptr;
+    if (!d_t && hipMalloc(&d_t, 8 * sizeof(unsigned long long)) != hipSuccess) return;
+    (void)hipMemsetAsync(d_t, 0, 8 * sizeof(unsigned long long), s);
+    hipLaunchKernelGGL(assemble_affine_kernel<1>, dim3(8 * per_xcd), dim3(64), lds, s, rg, ac, av.gvec, Fq16, cmass, rho0 / h,
+                       fixed_slot, nw, penalty, Hval, store_mode, d_t);
+    unsigned long long t[8];
+    (void)hipStreamSynchronize(s);
+    (void)hipMemcpy(t, d_t, sizeof(t), hipMemcpyDeviceToHost);
+    const double np = (double)std::max(1ULL, t[6]);
+    std::fprintf(stderr, "assemble_affine timing: %llu waves, %llu passes; cycles per pass: top %.0f | stage %.0f | g+issue %.0f | "
+                 "blocks %.0f | adds %.0f | rows out %.0f\n", t[7], t[6], t[0] / np, t[1] / np, t[2] / np, t[3] / np, t[4] / np,
+                 t[5] / np);
+    return;
+  }
+  hipLaunchKernelGGL(assemble_affine_kernel<0>, dim3(8 * per_xcd), dim3(64), lds, s, rg, ac, av.gvec, Fq16, cmass, rho0 / h,
+                     fixed_slot, nw, penalty, Hval, store_mode, nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -193,7 +193,7 @@ inline bool build_row_groups4(int N, int E, const int* conn, const int* off, con
                               const int* n2e, const double* x, const double* y, const double* z, RowGroups4Host& out) {
   constexpr int S = 10, kMaxRows = 16, kPassInst = 16;
   static const int kInstBudget = std::getenv("TLFEA_AF_INST") ? std::atoi(std::getenv("TLFEA_AF_INST")) : 32;
-  static const int kAccBudget = std::getenv("TLFEA_AF_ACC") ? std::atoi(std::getenv("TLFEA_AF_ACC")) : 640;  // doubles
+  static const int kAccBudget = std::getenv("TLFEA_AF_ACC") ? std::atoi(std::getenv("TLFEA_AF_ACC")) : 1024;  // doubles
   if (N <= 0 || E <= 0) return false;
   std::vector<std::pair<uint64_t, int>> key;
   morton_order(N, x, y, z, key);
@@ -209,17 +209,56 @@ inline bool build_row_groups4(int N, int E, const int* conn, const int* off, con
     out.g_inst_off.push_back(n_inst);
     open_rows = open_inst = open_acc = 0;
   };
-  for (int t = 0; t < N; t++) {
-    const int i = key[t].second;
-    const int ni = n2e_off[i + 1] - n2e_off[i], deg = off[i + 1] - off[i], ai = 9 * deg;
-    if (3 * deg >= 32768) return false;
-    if (open_rows && (open_inst + ni > kInstBudget || open_acc + ai > kAccBudget || open_rows >= kMaxRows)) close();
+  // Rows join the open group in curve order; when the next row does not fit, the following kLook rows are searched for
+  // one that does -- preferably one that brings the group to exactly 16 or 32 instances, i.e. full passes (tet meshes:
+  // mid-edge rows of 4-6 instances, vertex rows of ~24) -- and a group closes as soon as its passes are full.
+  constexpr int kLook = 16;
+  std::vector<char> used((size_t)N, 0);
+  auto add = [&](int i) {
+    const int ni = n2e_off[i + 1] - n2e_off[i], ai = 9 * (off[i + 1] - off[i]);
     out.gr_row.push_back(i);
     out.gr_acc.push_back(open_acc);
     open_rows++;
     open_inst += ni;
     open_acc += ai;
     n_inst += ni;
+  };
+  for (int t = 0; t < N; t++) {
+    if (3 * (off[key[t].second + 1] - off[key[t].second]) >= 32768) return false;
+  }
+  int head = 0;  // first row of the curve not yet in a group
+  while (head < N) {
+    if (used[head]) {
+      head++;
+      continue;
+    }
+    if (!open_rows) {  // a group starts with the next row of the curve, whatever its size
+      used[head] = 1;
+      add(key[head].second);
+      if (open_inst > 0 && open_inst % kPassInst == 0) close();
+      continue;
+    }
+    int best = -1, best_ni = -1;
+    bool exact = false;
+    for (int u = head, seen = 0; u < N && seen < kLook; u++) {
+      if (used[u]) continue;
+      seen++;
+      const int i = key[u].second, ni = n2e_off[i + 1] - n2e_off[i], ai = 9 * (off[i + 1] - off[i]);
+      if (open_inst + ni > kInstBudget || open_acc + ai > kAccBudget || open_rows >= kMaxRows) continue;
+      const bool ex = (open_inst + ni) % kPassInst == 0;
+      if ((ex && !exact) || (ex == exact && ni > best_ni)) {
+        best = u;
+        best_ni = ni;
+        exact = ex;
+      }
+    }
+    if (best < 0) {
+      close();
+      continue;
+    }
+    used[best] = 1;
+    add(key[best].second);
+    if (open_inst % kPassInst == 0 && open_inst > 0) close();
   }
   if (open_rows) close();
   if (out.acc_max >= 65536) return false;

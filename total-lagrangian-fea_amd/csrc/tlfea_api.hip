@@ -1572,6 +1572,15 @@ static bool use_direct(tlfea_newton_t s) {
   return s->rg_ok && s->asm_mode != 1 && s->d->kind == kT10 && s->d->mat.model == kSVK;
 }
 static double fq_h(tlfea_newton_t s) { return s->affine_ok ? s->prm.time_step : 0.0; }
+// record slots of the affine assembly: point q0 first, then the points where vertex 0, 1, 2, 3 has L = 1/2
+static int fq_slots(tlfea_newton_t s) {
+  int w = 0;
+  if (s->affine_ok) {
+    w |= 0 << (4 * s->av.q0);
+    for (int p = 0; p < 4; p++) w |= (p + 1) << (4 * s->av.qv[p]);
+  }
+  return w;
+}
 static void launch_fused(tlfea_newton_t s) {
   tlfea_t10_t d = s->d;
   const tlfea_newton_params& p = s->prm;
@@ -1619,7 +1628,7 @@ static int eval_gradient(tlfea_newton_t s, double* norm_g) {
     MassTerm mt{};
     if (mir) TRY(fill_mass_term(s, mt));
     launch_residual(s->stream, d->view(), d->mat, s->d_v, d->d_fbuf, nullptr, nullptr, nullptr, nullptr,
-                    (use_direct(s) && s->fq_in_residual) ? s->d_Fq : nullptr, mir ? &mt : nullptr, fq_h(s));
+                    (use_direct(s) && s->fq_in_residual) ? s->d_Fq : nullptr, mir ? &mt : nullptr, fq_h(s), fq_slots(s));
     d->fbuf_valid = !mir;
     t.stop();
   }
@@ -1661,7 +1670,7 @@ static int assemble(tlfea_newton_t s, bool fq_fresh = true) {
     StageTimer t(s, 3);
     if (!fq_fresh)
       launch_residual(s->stream, d->view(), d->mat, s->d_v, d->d_fbuf, nullptr, nullptr, nullptr, nullptr, s->d_Fq, nullptr,
-                      fq_h(s));
+                      fq_h(s), fq_slots(s));
     launch_fused(s);
     if (lincons_on(s))  // + h^2 rho J^T J  (SyncedNewton.cu:292-341)
       launch_lin_constraint_hessian(s->stream, 3 * s->N, d->d_jtoff, d->d_jtcol, d->d_jtval, d->d_joff, d->d_jcol,
@@ -2849,7 +2858,7 @@ extern "C" int tlfea_newton_time_kernels(tlfea_newton_t s, int reps, double* out
         const bool mir = mass_in_residual(s);
         if (mir) TRY(fill_mass_term(s, mt));
         launch_residual(s->stream, d->view(), d->mat, s->d_v, d->d_fbuf, nullptr, nullptr, nullptr, nullptr,
-                        use_direct(s) ? s->d_Fq : nullptr, mir ? &mt : nullptr, fq_h(s));
+                        use_direct(s) ? s->d_Fq : nullptr, mir ? &mt : nullptr, fq_h(s), fq_slots(s));
       }
       else if (k == 1) {
         if (use_direct(s)) break;  // no separate tangent launch on the fused path: out[1] = 0

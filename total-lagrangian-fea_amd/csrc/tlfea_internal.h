@@ -107,7 +107,8 @@ void launch_residual(hipStream_t s, const ElemView& m, const Material& mat, cons
                      double* fbuf /*[E][30]*/, double* F, double* P, double* Fdot, double* Pvis,
                      double* Fq = nullptr /*[E][Q][9] row-major F per point, for the fused assembly*/,
                      const MassTerm* mt = nullptr /*T10: also write the per-element inertia rows*/,
-                     double fq_h = 0.0 /*> 0: Fq holds [E][Q][16] records {F, B1 F F^T, C0} for this time step*/);
+                     double fq_h = 0.0 /*> 0: Fq holds [E][Q][16] records {F, B1 F F^T, C0} for this time step*/,
+                     int fq_slots = 0x43210 /*record slot of point q in bits 4q..4q+3 (the affine assembly's order)*/);
 // grad L without the mass CSR product (T10, inertia rows from the residual launch): 8 lanes per node
 void launch_grad_light(hipStream_t s, int N, int Epad, const Incidence& inc, const double* fbuf, const double* mbuf,
                        const double* f_ext, const double* x, const double* y, const double* z, const double* xt,
