@@ -1208,6 +1208,8 @@ extern "C" int tlfea_newton_analyze_hessian_sparsity(tlfea_newton_t s) {
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(d->stream));
         D2H(&s->affine_dev, d_dev, 1);
+        if (std::getenv("TLFEA_AF_VERBOSE"))
+          std::fprintf(stderr, "affine check: largest relative deviation of grad N / det J from the affine form %.3e\n", s->affine_dev);
         (void)hipFree(d_dev);
         RowGroups4Host rh;
         if (s->affine_dev <= 1e-12 &&
@@ -1572,6 +1574,13 @@ static bool use_direct(tlfea_newton_t s) {
   return s->rg_ok && s->asm_mode != 1 && s->d->kind == kT10 && s->d->mat.model == kSVK;
 }
 static double fq_h(tlfea_newton_t s) { return s->affine_ok ? s->prm.time_step : 0.0; }
+static int fq_slots(tlfea_newton_t s);
+// residual launch of the Newton path (the point records it leaves for the fused assembly follow the assembly's form)
+static void launch_residual_newton(tlfea_newton_t s, double* Fq, const MassTerm* mt) {
+  tlfea_t10_t d = s->d;
+  launch_residual(s->stream, d->view(), d->mat, s->d_v, d->d_fbuf, nullptr, nullptr, nullptr, nullptr, Fq, mt, fq_h(s),
+                  fq_slots(s));
+}
 // record slots of the affine assembly: point q0 first, then the points where vertex 0, 1, 2, 3 has L = 1/2
 static int fq_slots(tlfea_newton_t s) {
   int w = 0;
@@ -1627,8 +1636,7 @@ static int eval_gradient(tlfea_newton_t s, double* norm_g) {
     StageTimer t(s, 0);
     MassTerm mt{};
     if (mir) TRY(fill_mass_term(s, mt));
-    launch_residual(s->stream, d->view(), d->mat, s->d_v, d->d_fbuf, nullptr, nullptr, nullptr, nullptr,
-                    (use_direct(s) && s->fq_in_residual) ? s->d_Fq : nullptr, mir ? &mt : nullptr, fq_h(s), fq_slots(s));
+    launch_residual_newton(s, (use_direct(s) && s->fq_in_residual) ? s->d_Fq : nullptr, mir ? &mt : nullptr);
     d->fbuf_valid = !mir;
     t.stop();
   }
@@ -1669,8 +1677,7 @@ static int assemble(tlfea_newton_t s, bool fq_fresh = true) {
   if (use_direct(s)) {
     StageTimer t(s, 3);
     if (!fq_fresh)
-      launch_residual(s->stream, d->view(), d->mat, s->d_v, d->d_fbuf, nullptr, nullptr, nullptr, nullptr, s->d_Fq, nullptr,
-                      fq_h(s), fq_slots(s));
+      launch_residual_newton(s, s->d_Fq, nullptr);
     launch_fused(s);
     if (lincons_on(s))  // + h^2 rho J^T J  (SyncedNewton.cu:292-341)
       launch_lin_constraint_hessian(s->stream, 3 * s->N, d->d_jtoff, d->d_jtcol, d->d_jtval, d->d_joff, d->d_jcol,
@@ -2857,8 +2864,7 @@ extern "C" int tlfea_newton_time_kernels(tlfea_newton_t s, int reps, double* out
         MassTerm mt{};
         const bool mir = mass_in_residual(s);
         if (mir) TRY(fill_mass_term(s, mt));
-        launch_residual(s->stream, d->view(), d->mat, s->d_v, d->d_fbuf, nullptr, nullptr, nullptr, nullptr,
-                        use_direct(s) ? s->d_Fq : nullptr, mir ? &mt : nullptr, fq_h(s), fq_slots(s));
+        launch_residual_newton(s, use_direct(s) ? s->d_Fq : nullptr, mir ? &mt : nullptr);
       }
       else if (k == 1) {
         if (use_direct(s)) break;  // no separate tangent launch on the fused path: out[1] = 0
