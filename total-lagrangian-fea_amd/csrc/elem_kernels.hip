@@ -240,6 +240,17 @@ void launch_dndu_pre(hipStream_t s, int E, int Epad, const int* conn, const doub
                      qz, gradN, gradN_t, detJ);
 }
 
+// Wave-private LDS hand-offs (the fused assembly kernels' workgroup is ONE wavefront; the residual launch transposes its
+// stores inside each wavefront's own slice): a wavefront's LDS instructions execute in program order, so data written by one
+// lane is visible to the lanes of every later LDS instruction without a barrier.  What remains of __syncthreads() is the
+// compiler-level ordering -- and NOT its s_waitcnt vmcnt(0), which would drain the prefetched index loads and the H row
+// stores at every one of the 3-5 synchronisation points of a pass.
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // ------------------------------------------------------------------------------------------------
 // residual: fused compute_p + compute_internal_force (FEAT10DataFunc.cuh:85-293,397-458)
 // thread per element; fbuf[e][a][d] = sum_q (P_q grad N_a) detJ_q w_q
@@ -250,8 +261,19 @@ __global__ __launch_bounds__(128) void residual_kernel(ElemView m, Material mat,
                                                       double* __restrict__ Po, double* __restrict__ Fdo,
                                                       double* __restrict__ Pvo, double* __restrict__ Fq, MassTerm mt,
                                                       double fq_h, int fq_slots) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= m.E) return;
+  // T10 on the solver path (no F/P buffers kept): the point records of the affine assembly and the {force | inertia} rows
+  // go through a wave-private LDS transpose, so that every store instruction writes whole 128-byte lines (thread-per-
+  // element stores of 128-byte / 48-byte records leave each line to eight / six separate instructions: WRITE_SIZE 1.8x)
+  constexpr bool kTr = (S == kNN) && !STORE;
+  __shared__ __attribute__((aligned(16))) double tr_all[kTr ? 2 * 64 * 18 : 2];
+  double* tr = tr_all + (kTr ? (threadIdx.x >> 6) * (64 * 18) : 0);  // this wavefront's 64 records, row stride 18 doubles
+  const int lane = threadIdx.x & 63;
+  const int e0 = blockIdx.x * blockDim.x + (threadIdx.x & ~63);  // first element of this wavefront
+  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= m.E) {
+    if (!kTr) return;
+    e = m.E - 1;  // lanes past the end stay for the transposes: they recompute the last element and store its values again
+  }
   const bool damp = (v != nullptr) && (mat.eta != 0.0 || mat.lamd != 0.0);  // FEAT10DataFunc.cuh:137
   int gn[S];
   double xn[S][3];
@@ -265,38 +287,25 @@ __global__ __launch_bounds__(128) void residual_kernel(ElemView m, Material mat,
   double f[S][3];
 #pragma unroll
   for (int a = 0; a < S; a++) f[a][0] = f[a][1] = f[a][2] = 0.0;
+  // inertia rows M_e (v - v_prev) / h:  rows_a = rho/h sum_q N_a(q) dV_q sum_b N_b(q) (v - v_prev)_b.  The per-point
+  // sums Wq = sum_b N_b(q) (v - v_prev)_b and factors cq = rho/h dV_q wait here for the force rows (written together)
+  double Wq[MASS ? kNQ : 1][3], cq[MASS ? kNQ : 1];
   if (MASS) {
-    // inertia rows M_e (v - v_prev) / h:  rows_a = rho/h sum_q N_a(q) dV_q sum_b N_b(q) (v - v_prev)_b
-    double dv[S][3], mr[S][3];
+    double dv[S][3];
 #pragma unroll
     for (int a = 0; a < S; a++)
 #pragma unroll
-      for (int i = 0; i < 3; i++) {
-        dv[a][i] = v[3 * gn[a] + i] - mt.vprev[3 * gn[a] + i];
-        mr[a][i] = 0.0;
-      }
+      for (int i = 0; i < 3; i++) dv[a][i] = v[3 * gn[a] + i] - mt.vprev[3 * gn[a] + i];
 #pragma unroll
-    for (int q = 0; q < (MASS ? Q : 0); q++) {
+    for (int q = 0; q < (MASS ? kNQ : 0); q++) {
       double w[3] = {0.0, 0.0, 0.0};
 #pragma unroll
       for (int a = 0; a < S; a++)
 #pragma unroll
-        for (int i = 0; i < 3; i++) w[i] += mt.Nq[q < kNQ ? q : 0][a < kNN ? a : 0] * dv[a][i];
-      const double c = mt.rho_inv_h * m.detJ[(size_t)e * Q + q] * m.qw[q];
+        for (int i = 0; i < 3; i++) w[i] += mt.Nq[q][a < kNN ? a : 0] * dv[a][i];
+      cq[q] = mt.rho_inv_h * m.detJ[(size_t)e * Q + q] * m.qw[q];
 #pragma unroll
-      for (int a = 0; a < S; a++) {
-        const double ca = c * mt.Nq[q < kNQ ? q : 0][a < kNN ? a : 0];
-#pragma unroll
-        for (int i = 0; i < 3; i++) mr[a][i] += ca * w[i];
-      }
-    }
-    // [a][Epad][6]: force row (written below) | inertia row -- node-major, so that the lanes of a store (consecutive
-    // elements) write consecutive 48-byte records
-#pragma unroll
-    for (int a = 0; a < S; a++) {
-      double* mo = mt.mbuf + ((size_t)a * m.Epad + e) * 6 + 3;
-#pragma unroll
-      for (int i = 0; i < 3; i++) mo[i] = mr[a][i];
+      for (int i = 0; i < 3; i++) Wq[q][i] = w[i];
     }
   }
 
@@ -327,7 +336,9 @@ __global__ __launch_bounds__(128) void residual_kernel(ElemView m, Material mat,
       const double trE = 0.5 * (T00 + T11 + T22 - 3.0);
       const double dVq = m.detJ[(size_t)e * Q + q] * m.qw[q];
       const double B1 = dVq * (fq_h * mat.mu + mat.eta), C0 = dVq * fq_h * (mat.lambda * trE - mat.mu);
-      double2* fo = reinterpret_cast<double2*>(Fq + ((size_t)e * Q + ((fq_slots >> (4 * q)) & 15)) * 16);
+      const int slot = (fq_slots >> (4 * q)) & 15;
+      double2* fo = kTr ? reinterpret_cast<double2*>(tr + lane * 18)
+                        : reinterpret_cast<double2*>(Fq + ((size_t)e * Q + slot) * 16);
       fo[0] = make_double2(F[0][0], F[0][1]);
       fo[1] = make_double2(F[0][2], F[1][0]);
       fo[2] = make_double2(F[1][1], F[1][2]);
@@ -336,6 +347,16 @@ __global__ __launch_bounds__(128) void residual_kernel(ElemView m, Material mat,
       fo[5] = make_double2(B1 * T01, B1 * T02);
       fo[6] = make_double2(B1 * T11, B1 * T12);
       fo[7] = make_double2(B1 * T22, C0);
+      if (kTr) {  // 8 lanes store one 128-byte record
+        wave_sync();
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+          const int el = 8 * j + (lane >> 3), c = lane & 7;
+          const double2 val = reinterpret_cast<const double2*>(tr + el * 18)[c];
+          if (e0 + el < m.E) reinterpret_cast<double2*>(Fq + ((size_t)(e0 + el) * Q + slot) * 16)[c] = val;
+        }
+        wave_sync();
+      }
     } else if (Fq) {  // row-major F per (element, point): what the fused assembly stages instead of rebuilding F
       double* fo = Fq + ((size_t)e * Q + q) * 9;
 #pragma unroll
@@ -407,12 +428,29 @@ __global__ __launch_bounds__(128) void residual_kernel(ElemView m, Material mat,
         f[a][i] += c * dV;
       }
   }
-  if (MASS) {  // one 48-byte record per (element, node) for the gather of grad_light_kernel
+  if (MASS) {
+    // one 48-byte record {force row | inertia row} per (node, element) for the gather of grad_light_kernel, [a][Epad][6]
+    // node-major: a wavefront's 64 records of local node a are 3 072 contiguous bytes (Epad is a multiple of 64), stored
+    // as three whole-wave 16-byte-per-lane instructions
 #pragma unroll
     for (int a = 0; a < S; a++) {
-      double* out = mt.mbuf + ((size_t)a * m.Epad + e) * 6;
+      double mr[3] = {0.0, 0.0, 0.0};
 #pragma unroll
-      for (int i = 0; i < 3; i++) out[i] = f[a][i];
+      for (int q = 0; q < (MASS ? kNQ : 0); q++) {
+        const double ca = cq[q] * mt.Nq[q][a < kNN ? a : 0];
+#pragma unroll
+        for (int i = 0; i < 3; i++) mr[i] += ca * Wq[q][i];
+      }
+      double2* my = reinterpret_cast<double2*>(tr + lane * 6);
+      my[0] = make_double2(f[a][0], f[a][1]);
+      my[1] = make_double2(f[a][2], mr[0]);
+      my[2] = make_double2(mr[1], mr[2]);
+      wave_sync();
+      double2* out = reinterpret_cast<double2*>(mt.mbuf + ((size_t)a * m.Epad + e0) * 6);
+#pragma unroll
+      for (int j = 0; j < 3; j++)
+        if (e0 < m.E) out[lane + 64 * j] = reinterpret_cast<const double2*>(tr)[lane + 64 * j];  // records past E: padding
+      wave_sync();
     }
     return;
   }
@@ -1101,16 +1139,6 @@ __device__ __forceinline__ void store_through(double* p, double v, int mode) {
     __builtin_nontemporal_store(v, p);
   else
     *p = v;
-}
-
-// The fused kernel's workgroup is ONE wavefront: its LDS instructions execute in program order, so data written by one
-// lane is visible to the lanes of every later LDS instruction without a barrier.  What remains of __syncthreads() is the
-// compiler-level ordering -- and NOT its s_waitcnt vmcnt(0), which would drain the prefetched index loads and the H row
-// stores at every one of the 3-5 synchronisation points of a pass.
-__device__ __forceinline__ void wave_sync() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 template <int ROLLED>  // 0: points unrolled (234 VGPRs, 2 waves per SIMD), 1: rolled (168 VGPRs, 3 waves per SIMD)
