@@ -727,6 +727,14 @@ void launch_grad_light(hipStream_t s, int N, int Epad, const Incidence& inc, con
 // ------------------------------------------------------------------------------------------------
 __host__ __device__ __forceinline__ int pair_index(int S, int i, int j) { return i * S - (i * (i - 1)) / 2 + (j - i); }
 
+// one lane's double as a wave-uniform value (two v_readlane_b32; `l` must be wave-uniform)
+__device__ __forceinline__ double read_lane_f64(double v, int l) {
+  const long long b = __double_as_longlong(v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b & 0xffffffffLL), l);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)((unsigned long long)b >> 32), l);
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
 // lane -> (i,j) of pair p for S shape functions (row-major upper triangle)
 __device__ __forceinline__ void pair_of(int S, int p, int& i, int& j) {
   int row = 0, rem = p;
@@ -750,7 +758,8 @@ struct TangentLds {
   static constexpr int kUsize = (MODEL == kSVK) ? (QC * 6 * S + QC * 6 + QC * 4) : (QC * 64 + QC * 81);
   static constexpr int kPairs = S * (S + 1) / 2;
   static constexpr int kRaw = (kU + kUsize > kPairs * 9) ? (kU + kUsize) : (kPairs * 9);
-  static constexpr int kTotal = ((kRaw + 1) / 2) * 2;  // even: every wave's slice stays 16-byte aligned
+  static constexpr int kDV = ((kRaw + 1) / 2) * 2;                // dV[Q] = det J w of every point, loaded once per element
+  static constexpr int kTotal = kDV + ((Q + 1) / 2) * 2;          // even: every wave's slice stays 16-byte aligned
 };
 
 // WPB wavefronts per workgroup, one element each (own LDS slice); all waves run the same barrier sequence, so
@@ -772,30 +781,72 @@ __global__ __launch_bounds__(64 * WPB) void tangent_blocks_kernel(ElemView m, Ma
   const bool live = e_raw < E;
   const int e = live ? e_raw : E - 1;  // idle waves shadow the last element (they must still hit every barrier)
   const int lane = threadIdx.x & 63;
+  // one wavefront per workgroup: LDS hand-offs need program order only (wave_sync), not s_barrier + s_waitcnt vmcnt(0) --
+  // which would also drain the next chunk's gradient loads issued ahead of the pair loop
+  auto sync = [] {
+    if (WPB == 1) wave_sync();
+    else __syncthreads();
+  };
 
+  double* dVs = lds + LD::kDV;
+  // det J w of all Q points up front (one global round trip per element instead of one per chunk in front of the pair loop)
+  for (int t = lane; t < Q; t += 64) dVs[t] = m.detJ[(size_t)e * Q + t] * m.qw[t];
   for (int t = lane; t < 3 * S; t += 64) {
     const int a = t % S, d = t / S;
     const int g = m.conn[(size_t)a * E + e];
     const double* src = (d == 0) ? m.x : ((d == 1) ? m.y : m.z);
     xs[d * S + a] = src[g];
   }
-  int pi[NPL], pj[NPL];
+  // The lane's node pairs: (pi, pj0 + n), n < pcnt -- all in ONE block row of the element matrix.  With one pair per lane
+  // (T10, ANCF-3243) that is pair `lane` of the row-major upper triangle.  With several (ANCF-3443: 136 pairs, 3 per lane)
+  // row i is cut into runs of NPL consecutive columns, one lane per run (51 lanes busy): a point's record of node i, its
+  // scalars and F F^T are read from LDS once per lane and point instead of once per pair -- the pair loop of the shell is
+  // bound by LDS instruction issue, not by its fp64 operations.
+  int pi = 0, pj0 = 0, pcnt = 0;
+  if (NPL == 1) {
+    if (lane < P) {
+      pair_of(S, lane, pi, pj0);
+      pcnt = 1;
+    }
+  } else {
+    int base = 0;
+#pragma unroll 1
+    for (int i = 0; i < S; i++) {
+      const int nl = (S - i + NPL - 1) / NPL;
+      if (lane >= base && lane < base + nl) {
+        pi = i;
+        pj0 = i + NPL * (lane - base);
+        pcnt = min(NPL, S - pj0);
+      }
+      base += nl;
+    }
+  }
   double acc[NPL][9];
 #pragma unroll
-  for (int n = 0; n < NPL; n++) {
-    const int p = lane + 64 * n;
-    pi[n] = pj[n] = 0;
-    if (p < P) pair_of(S, p, pi[n], pj[n]);
+  for (int n = 0; n < NPL; n++)
 #pragma unroll
     for (int k = 0; k < 9; k++) acc[n][k] = 0.0;
-  }
 
+  constexpr int kPre = (QC * 3 * S + 63) / 64;
+  double pre[kPre];
+  {
+    const double* gsrc = m.gradN + (size_t)e * Q * (3 * S);
+#pragma unroll
+    for (int r = 0; r < kPre; r++) pre[r] = (lane + 64 * r < QC * 3 * S) ? gsrc[lane + 64 * r] : 0.0;
+  }
 #pragma unroll 1
   for (int q0 = 0; q0 < Q; q0 += QC) {
-    __syncthreads();  // previous chunk fully consumed (also orders the xs stage)
-    const double* gsrc = m.gradN + ((size_t)e * Q + q0) * (3 * S);
-    for (int t = lane; t < QC * 3 * S; t += 64) hs[t] = gsrc[t];
-    __syncthreads();
+    sync();  // previous chunk fully consumed (also orders the xs stage)
+#pragma unroll
+    for (int r = 0; r < kPre; r++)
+      if (lane + 64 * r < QC * 3 * S) hs[lane + 64 * r] = pre[r];
+    if (q0 + QC < Q) {  // the next chunk's gradients travel while this chunk computes
+      const double* gsrc = m.gradN + ((size_t)e * Q + q0 + QC) * (3 * S);
+#pragma unroll
+      for (int r = 0; r < kPre; r++)
+        if (lane + 64 * r < QC * 3 * S) pre[r] = gsrc[lane + 64 * r];
+    }
+    sync();
     for (int t = lane; t < QC * 9; t += 64) {  // F_q[r][c] = sum_a x_a[r] h_a^q[c]
       const int q = t / 9, r = (t % 9) / 3, c = t % 3;
       double s = 0.0;
@@ -803,12 +854,10 @@ __global__ __launch_bounds__(64 * WPB) void tangent_blocks_kernel(ElemView m, Ma
       for (int a = 0; a < S; a++) s += xs[r * S + a] * hs[q * 3 * S + c * S + a];
       Fs[t] = s;
     }
-    __syncthreads();
+    sync();
 
     if (MODEL == kSVK) {
       double* G = U;                  // [QC][S][6]: h_a (3), F h_a (3), 16-byte aligned records
-      double* FFT = U + QC * 6 * S;   // [QC][6]  (00,01,02,11,12,22)
-      double* sc = FFT + QC * 6;      // [QC][4]
       for (int t = lane; t < QC * S; t += 64) {  // Fh_a^q[r] = sum_c F_q[r][c] h_a^q[c]
         const int q = t / S, a = t - q * S;
         const double* hq = hs + q * 3 * S;
@@ -822,60 +871,67 @@ __global__ __launch_bounds__(64 * WPB) void tangent_blocks_kernel(ElemView m, Ma
         g[4] = F[3] * h0 + F[4] * h1 + F[5] * h2;
         g[5] = F[6] * h0 + F[7] * h1 + F[8] * h2;
       }
-      for (int t = lane; t < QC * 6; t += 64) {
-        const int q = t / 6, k = t % 6;
-        const int i = (k < 3) ? 0 : ((k < 5) ? 1 : 2);
-        const int j = (k < 3) ? k : ((k < 5) ? k - 2 : 2);
-        const double* F = Fs + q * 9;
-        FFT[t] = F[i * 3 + 0] * F[j * 3 + 0] + F[i * 3 + 1] * F[j * 3 + 1] + F[i * 3 + 2] * F[j * 3 + 2];
-      }
+      // The point's scalars and F F^T are the same for every lane: lane q of the chunk keeps them in registers and the
+      // pair loop fetches them with v_readlane into scalar registers -- five 16-byte LDS reads per (lane, point) less in a
+      // loop that is bound by LDS instruction issue.
+      double pt[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // A1, B1, C0, C1, FF^T (00, 01, 02, 11, 12, 22)
       if (lane < QC) {
         const int q = lane;
         const double* F = Fs + q * 9;
+        double Fl[9];
+#pragma unroll
+        for (int k = 0; k < 9; k++) Fl[k] = F[k];
         double trC = 0.0;
 #pragma unroll
-        for (int k = 0; k < 9; k++) trC += F[k] * F[k];
+        for (int k = 0; k < 9; k++) trC += Fl[k] * Fl[k];
         const double trE = 0.5 * (trC - 3.0);
-        const double dV = m.detJ[(size_t)e * Q + q0 + q] * m.qw[q0 + q];
+        const double dV = dVs[q0 + q];
         // h*K (SVK.cuh:35-55) + C_vis (FEAT10DataFunc.cuh:695-762) share their rank-1 structure:
-        sc[q * 4 + 0] = dV * (h * mat.lambda + mat.lamd);      // * Fh_i (x) Fh_j
-        sc[q * 4 + 1] = dV * (h * mat.mu + mat.eta);           // * Fh_j (x) Fh_i  and  * (h_i.h_j) FF^T
-        sc[q * 4 + 2] = dV * h * (mat.lambda * trE - mat.mu);  // * (h_i.h_j) I
-        sc[q * 4 + 3] = dV * h * mat.mu;                       // * (Fh_i.Fh_j) I
-      }
-      __syncthreads();
+        pt[0] = dV * (h * mat.lambda + mat.lamd);      // * Fh_i (x) Fh_j
+        pt[1] = dV * (h * mat.mu + mat.eta);           // * Fh_j (x) Fh_i  and  * (h_i.h_j) FF^T
+        pt[2] = dV * h * (mat.lambda * trE - mat.mu);  // * (h_i.h_j) I
+        pt[3] = dV * h * mat.mu;                       // * (Fh_i.Fh_j) I
+        int k = 4;
 #pragma unroll
-      for (int n = 0; n < NPL; n++) {
-        if (lane + 64 * n >= P) continue;
-        const int i = pi[n], j = pj[n];
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+          for (int j = i; j < 3; j++, k++)
+            pt[k] = Fl[i * 3 + 0] * Fl[j * 3 + 0] + Fl[i * 3 + 1] * Fl[j * 3 + 1] + Fl[i * 3 + 2] * Fl[j * 3 + 2];
+      }
+      sync();
+      if (pcnt > 0) {
 #pragma unroll 1
         for (int q = 0; q < QC; q++) {
-          const double2* gi = reinterpret_cast<const double2*>(G + ((size_t)q * S + i) * 6);
-          const double2* gj = reinterpret_cast<const double2*>(G + ((size_t)q * S + j) * 6);
-          const double2 i01 = gi[0], i23 = gi[1], i45 = gi[2], j01 = gj[0], j23 = gj[1], j45 = gj[2];
+          // per (lane, point): the row node's record, the point's scalars and F F^T
+          const double2* gi = reinterpret_cast<const double2*>(G + ((size_t)q * S + pi) * 6);
+          const double2 i01 = gi[0], i23 = gi[1], i45 = gi[2];
           const double hi0 = i01.x, hi1 = i01.y, hi2 = i23.x, fi0 = i23.y, fi1 = i45.x, fi2 = i45.y;
-          const double hj0 = j01.x, hj1 = j01.y, hj2 = j23.x, fj0 = j23.y, fj1 = j45.x, fj2 = j45.y;
-          const double2* scq = reinterpret_cast<const double2*>(sc + q * 4);
-          const double2 s01 = scq[0], s23 = scq[1];
-          const double A1 = s01.x, B1 = s01.y, C0 = s23.x, C1 = s23.y;
-          const double s = hi0 * hj0 + hi1 * hj1 + hi2 * hj2;
-          const double t = fi0 * fj0 + fi1 * fj1 + fi2 * fj2;
-          const double bs = B1 * s;
-          const double cd = C0 * s + C1 * t;
+          const double A1 = read_lane_f64(pt[0], q), B1 = read_lane_f64(pt[1], q), C0 = read_lane_f64(pt[2], q),
+                       C1 = read_lane_f64(pt[3], q);
           const double u0 = A1 * fi0, u1 = A1 * fi1, u2 = A1 * fi2;
-          const double w0 = B1 * fj0, w1 = B1 * fj1, w2 = B1 * fj2;
-          const double2* Tq = reinterpret_cast<const double2*>(FFT + q * 6);
-          const double2 t01 = Tq[0], t23 = Tq[1], t45 = Tq[2];
-          const double T[6] = {t01.x, t01.y, t23.x, t23.y, t45.x, t45.y};
-          acc[n][0] += u0 * fj0 + w0 * fi0 + bs * T[0] + cd;
-          acc[n][1] += u0 * fj1 + w0 * fi1 + bs * T[1];
-          acc[n][2] += u0 * fj2 + w0 * fi2 + bs * T[2];
-          acc[n][3] += u1 * fj0 + w1 * fi0 + bs * T[1];
-          acc[n][4] += u1 * fj1 + w1 * fi1 + bs * T[3] + cd;
-          acc[n][5] += u1 * fj2 + w1 * fi2 + bs * T[4];
-          acc[n][6] += u2 * fj0 + w2 * fi0 + bs * T[2];
-          acc[n][7] += u2 * fj1 + w2 * fi1 + bs * T[4];
-          acc[n][8] += u2 * fj2 + w2 * fi2 + bs * T[5] + cd;
+          const double T[6] = {read_lane_f64(pt[4], q), read_lane_f64(pt[5], q), read_lane_f64(pt[6], q),
+                               read_lane_f64(pt[7], q), read_lane_f64(pt[8], q), read_lane_f64(pt[9], q)};
+#pragma unroll
+          for (int n = 0; n < NPL; n++) {
+            if (n >= pcnt) continue;
+            const double2* gj = reinterpret_cast<const double2*>(G + ((size_t)q * S + pj0 + n) * 6);
+            const double2 j01 = gj[0], j23 = gj[1], j45 = gj[2];
+            const double hj0 = j01.x, hj1 = j01.y, hj2 = j23.x, fj0 = j23.y, fj1 = j45.x, fj2 = j45.y;
+            const double s = hi0 * hj0 + hi1 * hj1 + hi2 * hj2;
+            const double t = fi0 * fj0 + fi1 * fj1 + fi2 * fj2;
+            const double bs = B1 * s;
+            const double cd = C0 * s + C1 * t;
+            const double w0 = B1 * fj0, w1 = B1 * fj1, w2 = B1 * fj2;
+            acc[n][0] += u0 * fj0 + w0 * fi0 + bs * T[0] + cd;
+            acc[n][1] += u0 * fj1 + w0 * fi1 + bs * T[1];
+            acc[n][2] += u0 * fj2 + w0 * fi2 + bs * T[2];
+            acc[n][3] += u1 * fj0 + w1 * fi0 + bs * T[1];
+            acc[n][4] += u1 * fj1 + w1 * fi1 + bs * T[3] + cd;
+            acc[n][5] += u1 * fj2 + w1 * fi2 + bs * T[4];
+            acc[n][6] += u2 * fj0 + w2 * fi0 + bs * T[2];
+            acc[n][7] += u2 * fj1 + w2 * fi1 + bs * T[4];
+            acc[n][8] += u2 * fj2 + w2 * fi2 + bs * T[5] + cd;
+          }
         }
       }
     } else {
@@ -911,9 +967,9 @@ __global__ __launch_bounds__(64 * WPB) void tangent_blocks_kernel(ElemView m, Ma
         o[57] = ms.t2;
         o[58] = ms.t3;
         o[59] = mat.kappa * (2.0 * ms.J - 1.0) * ms.J;
-        o[60] = m.detJ[(size_t)e * Q + q0 + q] * m.qw[q0 + q];
+        o[60] = dVs[q0 + q];
       }
-      __syncthreads();
+      sync();
       for (int n = lane; n < QC * 81; n += 64) {
         const int q = n / 81, r = n % 81;
         const int i = r / 27, j = (r / 9) % 3, k = (r / 3) % 3, l = r % 3;
@@ -941,43 +997,68 @@ __global__ __launch_bounds__(64 * WPB) void tangent_blocks_kernel(ElemView m, Ma
                             mat.lamd * F[i * 3 + j] * F[k * 3 + l];
         At[n] = dV * (h * Ael + Avis);
       }
-      __syncthreads();
-#pragma unroll
-      for (int n = 0; n < NPL; n++) {
-        if (lane + 64 * n >= P) continue;
-        const int i = pi[n], j = pj[n];
+      sync();
+      if (pcnt > 0) {
 #pragma unroll 1
         for (int q = 0; q < QC; q++) {
           const double* hq = hs + q * 3 * S;
-          const double hi[3] = {hq[i], hq[S + i], hq[2 * S + i]};
-          const double hj[3] = {hq[j], hq[S + j], hq[2 * S + j]};
+          const double hi[3] = {hq[pi], hq[S + pi], hq[2 * S + pi]};
           const double* A = At + q * 81;
+          if (NPL == 1) {
+            const int j = pj0;
+            const double hj[3] = {hq[j], hq[S + j], hq[2 * S + j]};
 #pragma unroll
-          for (int d = 0; d < 3; d++)
+            for (int d = 0; d < 3; d++)
 #pragma unroll
-            for (int ee = 0; ee < 3; ee++) {
-              double sm = 0.0;
+              for (int ee = 0; ee < 3; ee++) {
+                double sm = 0.0;
 #pragma unroll
-              for (int J = 0; J < 3; J++) {
-                const double* a = A + ((d * 3 + J) * 3 + ee) * 3;
-                sm += hi[J] * (a[0] * hj[0] + a[1] * hj[1] + a[2] * hj[2]);
+                for (int J = 0; J < 3; J++) {
+                  const double* a = A + ((d * 3 + J) * 3 + ee) * 3;
+                  sm += hi[J] * (a[0] * hj[0] + a[1] * hj[1] + a[2] * hj[2]);
+                }
+                acc[0][d * 3 + ee] += sm;
               }
-              acc[n][d * 3 + ee] += sm;
+          } else {
+            // several pairs in one block row: contract the tangent tensor with h_i once per (lane, point)
+            double Bh[3][3][3];
+#pragma unroll
+            for (int d = 0; d < 3; d++)
+#pragma unroll
+              for (int ee = 0; ee < 3; ee++)
+#pragma unroll
+                for (int L = 0; L < 3; L++) {
+                  double b = 0.0;
+#pragma unroll
+                  for (int J = 0; J < 3; J++) b += hi[J] * A[((d * 3 + J) * 3 + ee) * 3 + L];
+                  Bh[d][ee][L] = b;
+                }
+#pragma unroll
+            for (int n = 0; n < NPL; n++) {
+              if (n >= pcnt) continue;
+              const int j = pj0 + n;
+              const double hj[3] = {hq[j], hq[S + j], hq[2 * S + j]};
+#pragma unroll
+              for (int d = 0; d < 3; d++)
+#pragma unroll
+                for (int ee = 0; ee < 3; ee++)
+                  acc[n][d * 3 + ee] += Bh[d][ee][0] * hj[0] + Bh[d][ee][1] * hj[1] + Bh[d][ee][2] * hj[2];
             }
+          }
         }
       }
     }
   }
-  __syncthreads();  // everyone is done reading the staged inputs: reuse LDS as the write-out stage
+  sync();  // everyone is done reading the staged inputs: reuse LDS as the write-out stage
 #pragma unroll
   for (int n = 0; n < NPL; n++) {
-    const int p = lane + 64 * n;
-    if (p < P) {
+    if (n < pcnt) {
+      const int p = pair_index(S, pi, pj0 + n);
 #pragma unroll
       for (int k = 0; k < 9; k++) lds[p * 9 + k] = acc[n][k];
     }
   }
-  __syncthreads();
+  sync();
   double* out = Kbuf + (size_t)e * (P * 9);
   if (live)
     for (int t = lane; t < P * 9; t += 64) out[t] = lds[t];
