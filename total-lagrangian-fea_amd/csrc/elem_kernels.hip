@@ -821,11 +821,20 @@ __global__ __launch_bounds__(64 * WPB) void tangent_blocks_kernel(ElemView m, Ma
       base += nl;
     }
   }
-  double acc[NPL][9];
+  // SVK accumulates three q-sums per pair instead of the block itself (the ratio of the two rank-1 coefficients does not
+  // depend on the point): O = sum dV Fh_i (x) Fh_j (acc), TT = sum B1 (h_i.h_j) F F^T (6 unique), cd = the diagonal term:
+  // 24 fp64 operations per (pair, point) instead of 42
+  double acc[NPL][9], accT[MODEL == kSVK ? NPL : 1][6], accD[MODEL == kSVK ? NPL : 1];
 #pragma unroll
-  for (int n = 0; n < NPL; n++)
+  for (int n = 0; n < NPL; n++) {
 #pragma unroll
     for (int k = 0; k < 9; k++) acc[n][k] = 0.0;
+    if (MODEL == kSVK) {
+#pragma unroll
+      for (int k = 0; k < 6; k++) accT[n][k] = 0.0;
+      accD[n] = 0.0;
+    }
+  }
 
   constexpr int kPre = (QC * 3 * S + 63) / 64;
   double pre[kPre];
@@ -874,29 +883,36 @@ __global__ __launch_bounds__(64 * WPB) void tangent_blocks_kernel(ElemView m, Ma
       // The point's scalars and F F^T are the same for every lane: lane q of the chunk keeps them in registers and the
       // pair loop fetches them with v_readlane into scalar registers -- five 16-byte LDS reads per (lane, point) less in a
       // loop that is bound by LDS instruction issue.
-      double pt[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // A1, B1, C0, C1, FF^T (00, 01, 02, 11, 12, 22)
-      if (lane < QC) {
-        const int q = lane;
+      static_assert(10 * QC <= 64, "one lane per (point of the chunk, value)");
+      // value k of point q lives in lane 10 q + k: dV, B1, C0, C1, FF^T (00, 01, 02, 11, 12, 22)
+      double ptv = 0.0;
+      if (lane < 10 * QC) {
+        const int q = lane / 10, k = lane - 10 * q;
         const double* F = Fs + q * 9;
         double Fl[9];
 #pragma unroll
-        for (int k = 0; k < 9; k++) Fl[k] = F[k];
+        for (int t = 0; t < 9; t++) Fl[t] = F[t];
         double trC = 0.0;
 #pragma unroll
-        for (int k = 0; k < 9; k++) trC += Fl[k] * Fl[k];
+        for (int t = 0; t < 9; t++) trC += Fl[t] * Fl[t];
         const double trE = 0.5 * (trC - 3.0);
         const double dV = dVs[q0 + q];
         // h*K (SVK.cuh:35-55) + C_vis (FEAT10DataFunc.cuh:695-762) share their rank-1 structure:
-        pt[0] = dV * (h * mat.lambda + mat.lamd);      // * Fh_i (x) Fh_j
-        pt[1] = dV * (h * mat.mu + mat.eta);           // * Fh_j (x) Fh_i  and  * (h_i.h_j) FF^T
-        pt[2] = dV * h * (mat.lambda * trE - mat.mu);  // * (h_i.h_j) I
-        pt[3] = dV * h * mat.mu;                       // * (Fh_i.Fh_j) I
-        int k = 4;
+        //   dV (h lambda + lamd) Fh_i (x) Fh_j + dV (h mu + eta) Fh_j (x) Fh_i : one sum O = sum_q dV Fh_i (x) Fh_j,
+        //   combined as (h lambda + lamd) O + (h mu + eta) O^T when the block is written
+        double val[10];
+        val[0] = dV;
+        val[1] = dV * (h * mat.mu + mat.eta);           // * (h_i.h_j) FF^T
+        val[2] = dV * h * (mat.lambda * trE - mat.mu);  // * (h_i.h_j) I
+        val[3] = dV * h * mat.mu;                       // * (Fh_i.Fh_j) I
+        int kk = 4;
 #pragma unroll
         for (int i = 0; i < 3; i++)
 #pragma unroll
-          for (int j = i; j < 3; j++, k++)
-            pt[k] = Fl[i * 3 + 0] * Fl[j * 3 + 0] + Fl[i * 3 + 1] * Fl[j * 3 + 1] + Fl[i * 3 + 2] * Fl[j * 3 + 2];
+          for (int j = i; j < 3; j++, kk++)
+            val[kk] = Fl[i * 3 + 0] * Fl[j * 3 + 0] + Fl[i * 3 + 1] * Fl[j * 3 + 1] + Fl[i * 3 + 2] * Fl[j * 3 + 2];
+#pragma unroll
+        for (int t = 0; t < 10; t++) ptv = (k == t) ? val[t] : ptv;
       }
       sync();
       if (pcnt > 0) {
@@ -906,11 +922,12 @@ __global__ __launch_bounds__(64 * WPB) void tangent_blocks_kernel(ElemView m, Ma
           const double2* gi = reinterpret_cast<const double2*>(G + ((size_t)q * S + pi) * 6);
           const double2 i01 = gi[0], i23 = gi[1], i45 = gi[2];
           const double hi0 = i01.x, hi1 = i01.y, hi2 = i23.x, fi0 = i23.y, fi1 = i45.x, fi2 = i45.y;
-          const double A1 = read_lane_f64(pt[0], q), B1 = read_lane_f64(pt[1], q), C0 = read_lane_f64(pt[2], q),
-                       C1 = read_lane_f64(pt[3], q);
-          const double u0 = A1 * fi0, u1 = A1 * fi1, u2 = A1 * fi2;
-          const double T[6] = {read_lane_f64(pt[4], q), read_lane_f64(pt[5], q), read_lane_f64(pt[6], q),
-                               read_lane_f64(pt[7], q), read_lane_f64(pt[8], q), read_lane_f64(pt[9], q)};
+          const int l0 = 10 * q;
+          const double dVq = read_lane_f64(ptv, l0), B1 = read_lane_f64(ptv, l0 + 1), C0 = read_lane_f64(ptv, l0 + 2),
+                       C1 = read_lane_f64(ptv, l0 + 3);
+          const double u0 = dVq * fi0, u1 = dVq * fi1, u2 = dVq * fi2;
+          const double T[6] = {read_lane_f64(ptv, l0 + 4), read_lane_f64(ptv, l0 + 5), read_lane_f64(ptv, l0 + 6),
+                               read_lane_f64(ptv, l0 + 7), read_lane_f64(ptv, l0 + 8), read_lane_f64(ptv, l0 + 9)};
 #pragma unroll
           for (int n = 0; n < NPL; n++) {
             if (n >= pcnt) continue;
@@ -920,17 +937,18 @@ __global__ __launch_bounds__(64 * WPB) void tangent_blocks_kernel(ElemView m, Ma
             const double s = hi0 * hj0 + hi1 * hj1 + hi2 * hj2;
             const double t = fi0 * fj0 + fi1 * fj1 + fi2 * fj2;
             const double bs = B1 * s;
-            const double cd = C0 * s + C1 * t;
-            const double w0 = B1 * fj0, w1 = B1 * fj1, w2 = B1 * fj2;
-            acc[n][0] += u0 * fj0 + w0 * fi0 + bs * T[0] + cd;
-            acc[n][1] += u0 * fj1 + w0 * fi1 + bs * T[1];
-            acc[n][2] += u0 * fj2 + w0 * fi2 + bs * T[2];
-            acc[n][3] += u1 * fj0 + w1 * fi0 + bs * T[1];
-            acc[n][4] += u1 * fj1 + w1 * fi1 + bs * T[3] + cd;
-            acc[n][5] += u1 * fj2 + w1 * fi2 + bs * T[4];
-            acc[n][6] += u2 * fj0 + w2 * fi0 + bs * T[2];
-            acc[n][7] += u2 * fj1 + w2 * fi1 + bs * T[4];
-            acc[n][8] += u2 * fj2 + w2 * fi2 + bs * T[5] + cd;
+            accD[n] += C0 * s + C1 * t;
+            acc[n][0] += u0 * fj0;
+            acc[n][1] += u0 * fj1;
+            acc[n][2] += u0 * fj2;
+            acc[n][3] += u1 * fj0;
+            acc[n][4] += u1 * fj1;
+            acc[n][5] += u1 * fj2;
+            acc[n][6] += u2 * fj0;
+            acc[n][7] += u2 * fj1;
+            acc[n][8] += u2 * fj2;
+#pragma unroll
+            for (int k = 0; k < 6; k++) accT[n][k] += bs * T[k];
           }
         }
       }
@@ -1054,8 +1072,19 @@ __global__ __launch_bounds__(64 * WPB) void tangent_blocks_kernel(ElemView m, Ma
   for (int n = 0; n < NPL; n++) {
     if (n < pcnt) {
       const int p = pair_index(S, pi, pj0 + n);
+      if (MODEL == kSVK) {
+        const double ca = h * mat.lambda + mat.lamd, cb = h * mat.mu + mat.eta;
+        const int tix[9] = {0, 1, 2, 1, 3, 4, 2, 4, 5};
 #pragma unroll
-      for (int k = 0; k < 9; k++) lds[p * 9 + k] = acc[n][k];
+        for (int r = 0; r < 3; r++)
+#pragma unroll
+          for (int c = 0; c < 3; c++)
+            lds[p * 9 + 3 * r + c] = ca * acc[n][3 * r + c] + cb * acc[n][3 * c + r] + accT[n][tix[3 * r + c]] +
+                                     (r == c ? accD[n] : 0.0);
+      } else {
+#pragma unroll
+        for (int k = 0; k < 9; k++) lds[p * 9 + k] = acc[n][k];
+      }
     }
   }
   sync();
