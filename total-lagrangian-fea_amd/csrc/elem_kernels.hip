@@ -753,9 +753,9 @@ struct TangentLds {
   static constexpr int kX = 0;                                   // xs[3][S]
   static constexpr int kH = ((3 * S + 1) / 2) * 2;               // hs[QC][3][S]  (global order)
   static constexpr int kF = kH + ((QC * 3 * S + 1) / 2) * 2;     // Fs[QC][9]
-  static constexpr int kU = kF + ((QC * 9 + 1) / 2) * 2;         // SVK: Fh | FFT | sc ; MR: st | At
+  static constexpr int kU = kF + ((QC * 9 + 1) / 2) * 2;         // SVK: per (point, node) records ; MR: st | At
   // SVK: per (point, node) the packed record {h0,h1,h2,Fh0,Fh1,Fh2} (three 16-byte LDS reads per node in the pair loop)
-  static constexpr int kUsize = (MODEL == kSVK) ? (QC * 6 * S + QC * 6 + QC * 4) : (QC * 64 + QC * 81);
+  static constexpr int kUsize = (MODEL == kSVK) ? (QC * 6 * S) : (QC * 64 + QC * 81);  // SVK: point scalars live in lanes
   static constexpr int kPairs = S * (S + 1) / 2;
   static constexpr int kRaw = (kU + kUsize > kPairs * 9) ? (kU + kUsize) : (kPairs * 9);
   static constexpr int kDV = ((kRaw + 1) / 2) * 2;                // dV[Q] = det J w of every point, loaded once per element
