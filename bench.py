@@ -45,10 +45,10 @@ def alg_bytes(E, N, nnz_coef, S=10, Q=5, cheb_bits=64, cheb_vec_bits=64):
         # fused tangent + assembly (T10, SVK): grad N + det J + per-point F in (each once: the re-reads by the owners of
         # an element's other rows are L2 traffic), instance map (code + S packed words), mass in, H out once
         "assemble_direct": E * (24 * S * Q + 8 * Q + 72 * Q) + E * S * (4 + 4 * S) + nnz_coef * 8 + nnz_coef * 72,
-        # affine-element form (straight-sided T10): the element's 128-byte vertex-gradient record and Q 128-byte point
-        # records {F, B1 F F^T, C0} in (each once), instance map (8-byte header + four 8-byte words), H out once; grad N,
-        # det J and the mass values are not read
-        "assemble_affine": E * (128 + 128 * Q) + E * S * (8 + 32) + nnz_coef * 72,
+        # affine-element form (straight-sided T10): the element's 128-byte vertex-gradient record and 80 bytes of F per
+        # point in (each once), instance map (8-byte header + four 8-byte words), H out once; grad N, det J and the
+        # mass values are not read
+        "assemble_affine": E * (128 + 80 * Q) + E * S * (8 + 32) + nnz_coef * 72,
         # H values + node-level columns + z,p_old in, p_new,q out
         "spmv": nnz_coef * 72 + nnz_coef * 4 + N * 96,
         # Chebyshev step: matrix (9 entries per block at cheb_bits: H itself or its scaled fp32/fp16 copy) + columns +
@@ -224,8 +224,8 @@ def main():
     ab = alg_bytes(E, N, nnz_coef, d.S, d.Q, bits_eff, vec_bits)
     fused = s.GetAssemblyMode() >= 2  # one fused tangent + assembly launch instead of tangent_blocks + assemble_rows
     fkey = "assemble_affine" if s.GetAssemblyMode() == 3 else "assemble_direct"
-    if fused:   # the residual launch also writes the per-point records the fused assembly stages (F | F, B1 F F^T, C0)
-        ab["residual"] += E * (128 if fkey == "assemble_affine" else 72) * d.Q
+    if fused:   # the residual launch also writes what the fused assembly stages: F at every point
+        ab["residual"] += E * (80 if fkey == "assemble_affine" else 72) * d.Q   # (general form: 72 B, affine form: 80 B per point)
     # mean launch duration: `reps` back-to-back launches per kernel between one hipEvent pair on the launch stream
     # (kernel time + same-stream boundary; agrees with rocprofv3 --kernel-trace, profiles/*kernel_stats.csv)
     kt = s.TimeKernels(reps=40 if E < 200000 else 10)

@@ -1,4 +1,4 @@
 mkdir -p gpurun_out/s2
-python3 bench.py > gpurun_out/s2/r02_bench_configC.json 2> gpurun_out/s2/bench_C.err; echo "C rc=$?"; cut -c1-200 gpurun_out/s2/r02_bench_configC.json
-python3 bench.py --config B > gpurun_out/s2/r02_bench_configB.json 2> gpurun_out/s2/bench_B.err; echo "B rc=$?"; cut -c1-200 gpurun_out/s2/r02_bench_configB.json
-python3 bench.py --config D --no-cpu-baseline --steps 6 --warmup 2 --max-pcg 300 > gpurun_out/s2/r02_bench_configD.json 2> gpurun_out/s2/bench_D.err; echo "D rc=$?"; cut -c1-200 gpurun_out/s2/r02_bench_configD.json
+timeout -k 10 500 python -m pytest tests/test_gpu_parity.py tests/test_gpu_hardening.py -x -q -m gpu > gpurun_out/s2/parity.log 2>&1; echo "parity rc=$?"; tail -4 gpurun_out/s2/parity.log
+TLFEA_TUNE_QUICK=1 timeout -k 10 240 python3 tools/tune_assemble.py C > gpurun_out/s2/tune.log 2>&1; tail -2 gpurun_out/s2/tune.log
+TLFEA_AF_TIMING=1 TLFEA_TUNE_QUICK=1 timeout -k 10 240 python3 tools/tune_assemble.py C 2>&1 | grep "assemble_affine timing" | tail -1

@@ -265,8 +265,9 @@ __global__ __launch_bounds__(128) void residual_kernel(ElemView m, Material mat,
   // go through a wave-private LDS transpose, so that every store instruction writes whole 128-byte lines (thread-per-
   // element stores of 128-byte / 48-byte records leave each line to eight / six separate instructions: WRITE_SIZE 1.8x)
   constexpr bool kTr = (S == kNN) && !STORE;
-  __shared__ __attribute__((aligned(16))) double tr_all[kTr ? 2 * 64 * 18 : 2];
-  double* tr = tr_all + (kTr ? (threadIdx.x >> 6) * (64 * 18) : 0);  // this wavefront's 64 records, row stride 18 doubles
+  constexpr int kTrRow = 54;  // doubles per lane: the five 10-double F records of an element + pad (432 B, 16-byte aligned)
+  __shared__ __attribute__((aligned(16))) double tr_all[kTr ? 2 * 64 * kTrRow : 2];
+  double* tr = tr_all + (kTr ? (threadIdx.x >> 6) * (64 * kTrRow) : 0);  // this wavefront's slice
   const int lane = threadIdx.x & 63;
   const int e0 = blockIdx.x * blockDim.x + (threadIdx.x & ~63);  // first element of this wavefront
   int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -324,39 +325,17 @@ __global__ __launch_bounds__(128) void residual_kernel(ElemView m, Material mat,
 #pragma unroll
         for (int j = 0; j < 3; j++) F[i][j] += xn[a][i] * hq[a][j];
     if (Fq && fq_h > 0.0) {
-      // affine form of the fused assembly: one 128-byte record per (element, point) = F row-major, B1 F F^T (upper
-      // triangle), C0 -- the point's share of h K + C_vis that does not depend on the node pair (SVK.cuh:35-55,
-      // FEAT10DataFunc.cuh:695-762)
-      const double T00 = F[0][0] * F[0][0] + F[0][1] * F[0][1] + F[0][2] * F[0][2],
-                   T01 = F[0][0] * F[1][0] + F[0][1] * F[1][1] + F[0][2] * F[1][2],
-                   T02 = F[0][0] * F[2][0] + F[0][1] * F[2][1] + F[0][2] * F[2][2],
-                   T11 = F[1][0] * F[1][0] + F[1][1] * F[1][1] + F[1][2] * F[1][2],
-                   T12 = F[1][0] * F[2][0] + F[1][1] * F[2][1] + F[1][2] * F[2][2],
-                   T22 = F[2][0] * F[2][0] + F[2][1] * F[2][1] + F[2][2] * F[2][2];
-      const double trE = 0.5 * (T00 + T11 + T22 - 3.0);
-      const double dVq = m.detJ[(size_t)e * Q + q] * m.qw[q];
-      const double B1 = dVq * (fq_h * mat.mu + mat.eta), C0 = dVq * fq_h * (mat.lambda * trE - mat.mu);
+      // affine form of the fused assembly: F (row-major, 10 doubles) per point, [E][5][10] with the centroid point in slot 0
+      // and the point where vertex p has L = 1/2 in slot p + 1; everything else of the point (F F^T, tr E) is formed by
+      // the assembly's lanes.  Collected in LDS, written after the loop.
       const int slot = (fq_slots >> (4 * q)) & 15;
-      double2* fo = kTr ? reinterpret_cast<double2*>(tr + lane * 18)
-                        : reinterpret_cast<double2*>(Fq + ((size_t)e * Q + slot) * 16);
+      double2* fo = kTr ? reinterpret_cast<double2*>(tr + lane * kTrRow + slot * 10)
+                        : reinterpret_cast<double2*>(Fq + ((size_t)e * kNQ + slot) * 10);
       fo[0] = make_double2(F[0][0], F[0][1]);
       fo[1] = make_double2(F[0][2], F[1][0]);
       fo[2] = make_double2(F[1][1], F[1][2]);
       fo[3] = make_double2(F[2][0], F[2][1]);
-      fo[4] = make_double2(F[2][2], B1 * T00);
-      fo[5] = make_double2(B1 * T01, B1 * T02);
-      fo[6] = make_double2(B1 * T11, B1 * T12);
-      fo[7] = make_double2(B1 * T22, C0);
-      if (kTr) {  // 8 lanes store one 128-byte record
-        wave_sync();
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-          const int el = 8 * j + (lane >> 3), c = lane & 7;
-          const double2 val = reinterpret_cast<const double2*>(tr + el * 18)[c];
-          if (e0 + el < m.E) reinterpret_cast<double2*>(Fq + ((size_t)(e0 + el) * Q + slot) * 16)[c] = val;
-        }
-        wave_sync();
-      }
+      fo[4] = make_double2(F[2][2], 0.0);
     } else if (Fq) {  // row-major F per (element, point): what the fused assembly stages instead of rebuilding F
       double* fo = Fq + ((size_t)e * Q + q) * 9;
 #pragma unroll
@@ -427,6 +406,18 @@ __global__ __launch_bounds__(128) void residual_kernel(ElemView m, Material mat,
         const double c = P[i][0] * hq[a][0] + P[i][1] * hq[a][1] + P[i][2] * hq[a][2];
         f[a][i] += c * dV;
       }
+  }
+  if (kTr && Fq && fq_h > 0.0) {
+    // the wavefront's 64 x 5 F records are 25 600 contiguous bytes: whole-line stores, 16 bytes per lane
+    wave_sync();
+    double2* out = reinterpret_cast<double2*>(Fq + (size_t)e0 * 50);
+#pragma unroll 5
+    for (int j = 0; j < 25; j++) {
+      const int idx = lane + 64 * j, el = idx / 25, c = idx - 25 * el;
+      const double2 val = reinterpret_cast<const double2*>(tr + el * kTrRow)[c];
+      if (e0 + el < m.E) out[idx] = val;
+    }
+    wave_sync();
   }
   if (MASS) {
     // one 48-byte record {force row | inertia row} per (node, element) for the gather of grad_light_kernel, [a][Epad][6]
@@ -1549,9 +1540,9 @@ void launch_assemble_direct(hipStream_t s, const ElemView& m, const Material& ma
 //     column "mid-edge (n,p)": 4/3 D_p + 2/3 S + R_n(q0)        (the share of vertex n; vertex p adds the mirror image)
 // One lane per (instance, vertex n): 5 block evaluations and four 3x3 results instead of ten lanes x 5 evaluations --
 // 2.2x fewer fp64 operations and 2.5x less LDS traffic per element than assemble_direct_kernel, and grad N (1 200 B per
-// element) is never read: the kernel stages per instance the element's 128-byte g record and the five 128-byte point
-// records {F, B1 F F^T, C0} the residual launch leaves behind.
-//   pass  = up to 16 instances x 4 lanes; records of the pass in LDS (104 doubles per instance: stride = 16 banks)
+// element) is never read: the kernel stages per instance the element's 128-byte g record and the 400 bytes the residual
+// launch leaves behind -- F at the five points of the rule; F F^T and tr E are formed per lane.
+//   pass  = up to 16 instances x 4 lanes; records of the pass in LDS (66 doubles per instance: stride = 4 banks)
 //   sum   = ds_add_f64 into the group's row accumulators (H layout) as in assemble_direct_kernel; M/h and the pinned
 //           rows' penalty are added while a finished group streams out
 // Used when launch_affine_pre finds every element affine and the rule of the expected form (tlfea_api.hip); curved
@@ -1559,8 +1550,8 @@ void launch_assemble_direct(hipStream_t s, const ElemView& m, const Material& ma
 // ------------------------------------------------------------------------------------------------
 namespace {
 constexpr int kAfInst = 16;                 // instances per pass
-constexpr int kAfRec = 104;                 // doubles per staged instance: 16 (g, det J) + 5 x 16 (points) + pad
-constexpr int kAfStage = kAfInst * kAfRec;  // 1 664 doubles = 13 KiB
+constexpr int kAfRec = 66;                  // doubles per staged instance: 16 (g, det J) + 5 x 10 (F at the points)
+constexpr int kAfStage = kAfInst * kAfRec;  // 1 056 doubles = 8.25 KiB
 }  // namespace
 
 __global__ void affine_pre_kernel(ElemView m, AffineView av, double* __restrict__ gvec, double* __restrict__ dev_max) {
@@ -1610,8 +1601,8 @@ void launch_affine_pre(hipStream_t s, const ElemView& m, const AffineView& av, d
   hipLaunchKernelGGL(affine_pre_kernel, dim3((m.E + 127) / 128), dim3(128), 0, s, m, av, gvec, dev_max);
 }
 
-struct AffineCoef {  // per rule point in the kernel's order (q0, q_0 .. q_3 = the record slots the residual launch writes)
-  double cA[5], cB[5], cC[5];  // w_q (h lambda + lamd), w_q (h mu + eta), w_q h mu   (x det J = A1, B1, C1)
+struct AffineCoef {  // per rule point in the kernel's order (q0, then q_0 .. q_3 = the record slots the residual launch writes)
+  double cA[5], cB[5], cC[5], cL[5];  // w_q (h lambda + lamd), w_q (h mu + eta), w_q h mu, w_q h lambda   (x det J)
 };
 
 template <int TIMING>
@@ -1691,16 +1682,16 @@ __global__ __launch_bounds__(64, 2) void assemble_affine_kernel(RowGroups4 rg, A
   int fs = -1;
   double wv = 1.0;
   double* Sk = stage + k * kAfRec;
-  // records in flight: the four lanes of an instance fetch its 768 bytes (g record + five point records) 16 at a time;
-  // the loads of pass t + 1 are issued before pass t computes, so that a pass never waits for a round trip to memory
-  double2 sa, sb, s0, s1, s2, s3, s4, s5, s6, s7, s8, s9;
+  // records in flight: the four lanes of an instance fetch its 528 bytes (g record + F at the five points) 16 at a
+  // time, one pass ahead of the pass that computes, so that a pass never waits for a round trip to memory
+  double2 sa, sb, s0, s1, s2, s3, s4, s5, s6 = make_double2(0.0, 0.0);
   auto fetch = [&](const int2& hd) __attribute__((always_inline)) {
     const int e = (store_mode & 256) ? 0 : hd.x / kNN;
     const double2* gp = reinterpret_cast<const double2*>(gvec + (size_t)e * 16) + n;
-    const double2* fp = reinterpret_cast<const double2*>(Fq16 + (size_t)e * (kNQ * 16)) + n;
+    const double2* fp = reinterpret_cast<const double2*>(Fq16 + (size_t)e * 50) + n;
     sa = gp[0]; sb = gp[4];
-    s0 = fp[0]; s1 = fp[4]; s2 = fp[8]; s3 = fp[12]; s4 = fp[16];
-    s5 = fp[20]; s6 = fp[24]; s7 = fp[28]; s8 = fp[32]; s9 = fp[36];
+    s0 = fp[0]; s1 = fp[4]; s2 = fp[8]; s3 = fp[12]; s4 = fp[16]; s5 = fp[20];
+    if (n == 0) s6 = fp[24];  // 25 16-byte pieces: the last one has one taker
   };
   fetch(head);
 
@@ -1747,12 +1738,11 @@ __global__ __launch_bounds__(64, 2) void assemble_affine_kernel(RowGroups4 rg, A
     {
       double2* S2 = reinterpret_cast<double2*>(Sk) + n;
       S2[0] = sa; S2[4] = sb;
-      S2[8] = s0; S2[12] = s1; S2[16] = s2; S2[20] = s3; S2[24] = s4;
-      S2[28] = s5; S2[32] = s6; S2[36] = s7; S2[40] = s8; S2[44] = s9;
+      S2[8] = s0; S2[12] = s1; S2[16] = s2; S2[20] = s3; S2[24] = s4; S2[28] = s5;
+      if (n == 0) S2[32] = s6;
     }
     wave_sync();
     TLFEA_TICK(1)  // records into LDS (waits for the loads of the previous pass)
-    fetch(head_n);
     // ---- (4) the lane's five block evaluations --------------------------------------------------------------------
     // row node: vertex A (corner il) or edge (A, B) (mid-edge il) -- FEAT10Data.cu:143 packed 2 bits per entry
     const int A = (0x904e4 >> (2 * il)) & 3;   // {0,1,2,3,0,1,0,0,1,2}
@@ -1767,26 +1757,22 @@ __global__ __launch_bounds__(64, 2) void assemble_affine_kernel(RowGroups4 rg, A
       gn[0] = n01.x; gn[1] = n01.y; gn[2] = Sk[4 * n + 2];
       detJ = Sk[3];
     }
-    // M/h (SyncedNewton.cu:214-259): on an affine element M_e(i, j) = rho det J sum_q w_q N_i N_j (FEAT10Data.cu:206-278)
-    // is det J times a constant of the rule; the two lanes of a mid-edge column add half of it each
-    double cmv[4];
-    {
-      const double2* cq = reinterpret_cast<const double2*>(cml + il * 16 + 4 * n);
-      const double2 c01 = cq[0], c23 = cq[1];
-      cmv[0] = detJ * c01.x; cmv[1] = detJ * c01.y; cmv[2] = detJ * c23.x; cmv[3] = detJ * c23.y;
-    }
     TLFEA_TICK(2)  // next pass's loads issued, g / mass coefficients read
     double R0[9], D[4][9];
+    // F of the point comes from the staged record; F F^T, tr E and with them B1 F F^T and C0 are formed here: 24 operations
+    // per point instead of three more 16-byte reads and 48 more staged bytes per point and instance.
     auto block = [&](const int sdx, double (&out)[9]) __attribute__((always_inline)) {
-      const double2* R2 = reinterpret_cast<const double2*>(Sk + 16 + 16 * sdx);
-      const double2 r0 = R2[0], r1 = R2[1], r2 = R2[2], r3 = R2[3], r4 = R2[4], r5 = R2[5], r6 = R2[6], r7 = R2[7];
+      const double2* R2 = reinterpret_cast<const double2*>(Sk + 16 + 10 * sdx);
+      const double2 r0 = R2[0], r1 = R2[1], r2 = R2[2], r3 = R2[3], r4 = R2[4];
       const double F0 = r0.x, F1 = r0.y, F2 = r1.x, F3 = r1.y, F4 = r2.x, F5 = r2.y, F6 = r3.x, F7 = r3.y, F8 = r4.x;
-      const double T00 = r4.y, T01 = r5.x, T02 = r5.y, T11 = r6.x, T12 = r6.y, T22 = r7.x, C0 = r7.y;
       if (store_mode & 512) {  // timing experiment: no block arithmetic
 #pragma unroll
         for (int t = 0; t < 9; t++) out[t] = 0.0;
         return;
       }
+      const double T00 = F0 * F0 + F1 * F1 + F2 * F2, T01 = F0 * F3 + F1 * F4 + F2 * F5, T02 = F0 * F6 + F1 * F7 + F2 * F8,
+                   T11 = F3 * F3 + F4 * F4 + F5 * F5, T12 = F3 * F6 + F4 * F7 + F5 * F8, T22 = F6 * F6 + F7 * F7 + F8 * F8;
+      const double trE = 0.5 * (T00 + T11 + T22 - 3.0);
       // grad N_i at this point = al g_A + be g_B
       double al, be;
       if (sdx == 0) {
@@ -1804,24 +1790,37 @@ __global__ __launch_bounds__(64, 2) void assemble_affine_kernel(RowGroups4 rg, A
       const double sv = h0 * gn[0] + h1 * gn[1] + h2 * gn[2];  // grad N_i . g_n
       const double tv = fi0 * b0 + fi1 * b1 + fi2 * b2;        // F grad N_i . F g_n
       const double A1 = detJ * ac.cA[sdx], B1 = detJ * ac.cB[sdx], C1 = detJ * ac.cC[sdx];
+      const double C0 = detJ * ac.cL[sdx] * trE - C1;          // dV h (lambda tr E - mu)   (SVK.cuh:35-55)
       const double cd = C0 * sv + C1 * tv;
+      const double sb1 = sv * B1;                              // (grad N_i . g_n) B1 F F^T
       const double u0 = A1 * fi0, u1 = A1 * fi1, u2 = A1 * fi2;
       const double w0 = B1 * b0, w1 = B1 * b1, w2 = B1 * b2;
-      out[0] = u0 * b0 + w0 * fi0 + sv * T00 + cd;
-      out[1] = u0 * b1 + w0 * fi1 + sv * T01;
-      out[2] = u0 * b2 + w0 * fi2 + sv * T02;
-      out[3] = u1 * b0 + w1 * fi0 + sv * T01;
-      out[4] = u1 * b1 + w1 * fi1 + sv * T11 + cd;
-      out[5] = u1 * b2 + w1 * fi2 + sv * T12;
-      out[6] = u2 * b0 + w2 * fi0 + sv * T02;
-      out[7] = u2 * b1 + w2 * fi1 + sv * T12;
-      out[8] = u2 * b2 + w2 * fi2 + sv * T22 + cd;
+      out[0] = u0 * b0 + w0 * fi0 + sb1 * T00 + cd;
+      out[1] = u0 * b1 + w0 * fi1 + sb1 * T01;
+      out[2] = u0 * b2 + w0 * fi2 + sb1 * T02;
+      out[3] = u1 * b0 + w1 * fi0 + sb1 * T01;
+      out[4] = u1 * b1 + w1 * fi1 + sb1 * T11 + cd;
+      out[5] = u1 * b2 + w1 * fi2 + sb1 * T12;
+      out[6] = u2 * b0 + w2 * fi0 + sb1 * T02;
+      out[7] = u2 * b1 + w2 * fi1 + sb1 * T12;
+      out[8] = u2 * b2 + w2 * fi2 + sb1 * T22 + cd;
     };
     block(0, R0);
     block(1, D[0]);
     block(2, D[1]);
     block(3, D[2]);
     block(4, D[3]);
+    // the next pass's records: issued after the block evaluations (36 registers less while they run; measured no slower
+    // than before them): the adds, the rows streaming out and the next pass's top cover the round trip
+    fetch(head_n);
+    // M/h (SyncedNewton.cu:214-259): on an affine element M_e(i, j) = rho det J sum_q w_q N_i N_j (FEAT10Data.cu:206-278)
+    // is det J times a constant of the rule; the two lanes of a mid-edge column add half of it each
+    double cmv[4];
+    {
+      const double2* cq = reinterpret_cast<const double2*>(cml + il * 16 + 4 * n);
+      const double2 c01 = cq[0], c23 = cq[1];
+      cmv[0] = detJ * c01.x; cmv[1] = detJ * c01.y; cmv[2] = detJ * c23.x; cmv[3] = detJ * c23.y;
+    }
     TLFEA_TICK(3)  // five block evaluations
     // ---- (5) the lane's four blocks into the row accumulator ------------------------------------------------------
     if (k < cnt && !(store_mode & 1024)) {
@@ -1924,6 +1923,7 @@ void launch_assemble_affine(hipStream_t s, const ElemView& m, const Material& ma
     ac.cA[sdx] = m.qw[q] * (h * mat.lambda + mat.lamd);
     ac.cB[sdx] = m.qw[q] * (h * mat.mu + mat.eta);
     ac.cC[sdx] = m.qw[q] * h * mat.mu;
+    ac.cL[sdx] = m.qw[q] * h * mat.lambda;
   }
   static const bool timing = std::getenv("TLFEA_AF_TIMING") != nullptr;  // tools only: per-phase shader clocks on stderr
   if (timing) {

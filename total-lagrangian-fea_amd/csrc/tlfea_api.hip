@@ -966,7 +966,7 @@ struct tlfea_newton_s {
   int asm_mode = 0;
   double* d_Fq = nullptr;
   // affine-element form of the fused kernel (straight-sided elements + the 5-point Keast rule): its work lists, the
-  // per-element vertex gradients; d_Fq then holds 16-double point records.  TLFEA_ASSEMBLE=general keeps the general form.
+  // per-element vertex gradients; d_Fq then holds F per point, [E][5][10].  TLFEA_ASSEMBLE=general keeps the general form.
   RowGroups4 rg4{0, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr};
   int* d_rg4[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   AffineView av{nullptr, 0, {0, 0, 0, 0}};
@@ -1243,7 +1243,7 @@ extern "C" int tlfea_newton_analyze_hessian_sparsity(tlfea_newton_t s) {
             TRY(dmalloc(&s->d_cmass, 160));
             HIP_TRY(hipMemcpy(s->d_cmass, cm, sizeof(cm), hipMemcpyHostToDevice));
           }
-          TRY(dmalloc(&s->d_Fq, (size_t)d->E * d->Q * 16));
+          TRY(dmalloc(&s->d_Fq, (size_t)d->Epad * 50));  // [E][5][10]: F per point, centroid point first
           s->rg_ok = s->affine_ok = affine = true;
         } else {
           (void)hipFree(s->d_gvec);

@@ -107,7 +107,7 @@ void launch_residual(hipStream_t s, const ElemView& m, const Material& mat, cons
                      double* fbuf /*[E][30]*/, double* F, double* P, double* Fdot, double* Pvis,
                      double* Fq = nullptr /*[E][Q][9] row-major F per point, for the fused assembly*/,
                      const MassTerm* mt = nullptr /*T10: also write the per-element inertia rows*/,
-                     double fq_h = 0.0 /*> 0: Fq holds [E][Q][16] records {F, B1 F F^T, C0} for this time step*/,
+                     double fq_h = 0.0 /*> 0: affine form, Fq holds [E][5][10] = F per point (centroid point first)*/,
                      int fq_slots = 0x43210 /*record slot of point q in bits 4q..4q+3 (the affine assembly's order)*/);
 // grad L without the mass CSR product (T10, inertia rows from the residual launch): 8 lanes per node
 void launch_grad_light(hipStream_t s, int N, int Epad, const Incidence& inc, const double* fbuf, const double* mbuf,
@@ -121,7 +121,7 @@ void launch_assemble_direct(hipStream_t s, const ElemView& m, const Material& ma
 // affine-element set-up: gvec from grad N / det J, and the largest relative deviation of the stored grad N / det J from
 // the affine form (dev_max: one double on the device, zeroed by the caller)
 void launch_affine_pre(hipStream_t s, const ElemView& m, const AffineView& av, double* gvec, double* dev_max);
-// fused tangent + row assembly, affine elements: Fq16 = [E][5][16] records {F, B1 F F^T, C0} of the last residual launch
+// fused tangent + row assembly, affine elements: Fq16 = [E][5][10], F per point, centroid point first (last residual launch)
 void launch_assemble_affine(hipStream_t s, const ElemView& m, const Material& mat, double h, const RowGroups4& rg,
                             const AffineView& av, const double* Fq16,
                             const double* cmass /*[10][16] sum_q w_q N_i N_j per (row node, vertex n, p); mid-edge columns halved*/,
