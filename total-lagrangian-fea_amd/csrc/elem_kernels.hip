@@ -310,13 +310,37 @@ __global__ __launch_bounds__(128) void residual_kernel(ElemView m, Material mat,
     }
   }
 
-#pragma unroll 1
-  for (int q = 0; q < Q; q++) {
-    double hq[S][3];
+  // T10 solver path: the launch runs one wavefront per SIMD (its registers hold x, f and a point's 30 gradients), so
+  // nothing but the wavefront itself hides the round trip of the gradient loads: the next point's gradients are in
+  // flight while this point computes
+  constexpr bool kPre = kTr;
+  double hn[kPre ? S : 1][3];
+  if (kPre) {
 #pragma unroll
     for (int d = 0; d < 3; d++)
 #pragma unroll
-      for (int a = 0; a < S; a++) hq[a][d] = m.gradN_t[((size_t)(q * 3 + d) * S + a) * m.Epad + e];
+      for (int a = 0; a < (kPre ? S : 0); a++) hn[a][d] = m.gradN_t[((size_t)d * S + a) * m.Epad + e];
+  }
+#pragma unroll 1
+  for (int q = 0; q < Q; q++) {
+    double hq[S][3];
+    if (kPre) {
+#pragma unroll
+      for (int a = 0; a < (kPre ? S : 0); a++)
+#pragma unroll
+        for (int d = 0; d < 3; d++) hq[a][d] = hn[a][d];
+      if (q + 1 < Q) {
+#pragma unroll
+        for (int d = 0; d < 3; d++)
+#pragma unroll
+          for (int a = 0; a < (kPre ? S : 0); a++) hn[a][d] = m.gradN_t[((size_t)((q + 1) * 3 + d) * S + a) * m.Epad + e];
+      }
+    } else {
+#pragma unroll
+      for (int d = 0; d < 3; d++)
+#pragma unroll
+        for (int a = 0; a < S; a++) hq[a][d] = m.gradN_t[((size_t)(q * 3 + d) * S + a) * m.Epad + e];
+    }
     double F[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
 #pragma unroll
     for (int a = 0; a < S; a++)
