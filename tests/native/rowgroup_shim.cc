@@ -68,3 +68,11 @@ extern "C" void dh_fetch(int* perm, int* ptrT, int* indT) {
   std::copy(g_dh.ptrT.begin(), g_dh.ptrT.end(), ptrT);
   std::copy(g_dh.indT.begin(), g_dh.indT.end(), indT);
 }
+
+// ---- lane -> node-pair runs of tangent_blocks_kernel (csrc/pair_runs.h) ----------------------------------------------------
+#include "../../total-lagrangian-fea_amd/csrc/pair_runs.h"
+extern "C" int pair_runs(int S, int npl, int* i, int* j0, int* cnt) {  // 64 lanes each; returns the lanes the runs occupy
+  for (int lane = 0; lane < 64; lane++) tlfea::lane_pair_run(S, npl, lane, i[lane], j0[lane], cnt[lane]);
+  return tlfea::lane_pair_run_lanes(S, npl);
+}
+extern "C" int pair_index_of(int S, int i, int j) { return tlfea::pair_index(S, i, j); }

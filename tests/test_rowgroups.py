@@ -244,3 +244,32 @@ def test_direct_solver_symbolic_factor(shim, mesh):
             expect = np.concatenate([(3 * js[:, None] + np.arange(3)[None, :]).reshape(-1), 3 * k + np.arange(r + 1)])
             assert np.array_equal(row, expect), (k, r)
     assert ptrT[-1] == nnzT
+
+
+@pytest.mark.parametrize("S", [10, 8, 16])
+def test_tangent_lane_pair_runs(shim, S):
+    """tangent_blocks_kernel's lane -> node-pair assignment (csrc/pair_runs.h): every pair (i <= j) of the element matrix
+    is owned by exactly one (lane, slot), a lane's pairs are consecutive columns of ONE block row, the runs fit into the
+    64 lanes of a wavefront (T10: 55 pairs / ANCF-3243: 36, one per lane; ANCF-3443: 136 pairs, three per lane)."""
+    P = S * (S + 1) // 2
+    npl = (P + 63) // 64
+    i = np.zeros(64, dtype=np.int32)
+    j0 = np.zeros(64, dtype=np.int32)
+    cnt = np.zeros(64, dtype=np.int32)
+    ip = C.POINTER(C.c_int)
+    lanes = shim.pair_runs(S, npl, i.ctypes.data_as(ip), j0.ctypes.data_as(ip), cnt.ctypes.data_as(ip))
+    assert lanes <= 64
+    assert (cnt[lanes:] == 0).all() and (cnt[:lanes] >= 1).all() and (cnt <= npl).all()
+    owner = np.full(P, -1)
+    for lane in range(64):
+        for n in range(cnt[lane]):
+            a, b = int(i[lane]), int(j0[lane]) + n
+            assert 0 <= a <= b < S
+            p = shim.pair_index_of(S, a, b)
+            assert 0 <= p < P and owner[p] == -1
+            owner[p] = lane
+    assert (owner >= 0).all()
+    # the buffer layout: row-major upper triangle
+    assert [shim.pair_index_of(S, a, b) for a in range(S) for b in range(a, S)] == list(range(P))
+    if S == 16:
+        assert npl == 3 and lanes == 51

@@ -20,6 +20,7 @@
 //
 // Math follows SVK.cuh:14-55, MooneyRivlin.cuh:17-225, FEAT10Data.cu:97-278 (cited inline).
 #include "tlfea_internal.h"
+#include "pair_runs.h"
 
 #include <cstdlib>
 
@@ -740,7 +741,6 @@ void launch_grad_light(hipStream_t s, int N, int Epad, const Incidence& inc, con
 // ------------------------------------------------------------------------------------------------
 // tangent: one element per wavefront; lane p (+64, +128) owns the node-pair blocks (i <= j)
 // ------------------------------------------------------------------------------------------------
-__host__ __device__ __forceinline__ int pair_index(int S, int i, int j) { return i * S - (i * (i - 1)) / 2 + (j - i); }
 
 // one lane's double as a wave-uniform value (two v_readlane_b32; `l` must be wave-uniform)
 __device__ __forceinline__ double read_lane_f64(double v, int l) {
@@ -748,17 +748,6 @@ __device__ __forceinline__ double read_lane_f64(double v, int l) {
   const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b & 0xffffffffLL), l);
   const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)((unsigned long long)b >> 32), l);
   return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
-}
-
-// lane -> (i,j) of pair p for S shape functions (row-major upper triangle)
-__device__ __forceinline__ void pair_of(int S, int p, int& i, int& j) {
-  int row = 0, rem = p;
-  while (rem >= S - row) {
-    rem -= S - row;
-    row++;
-  }
-  i = row;
-  j = row + rem;
 }
 
 // One 64-thread workgroup == one wavefront, so __syncthreads() is a wave-local fence.  The Q points are staged
@@ -818,24 +807,8 @@ __global__ __launch_bounds__(64 * WPB) void tangent_blocks_kernel(ElemView m, Ma
   // scalars and F F^T are read from LDS once per lane and point instead of once per pair -- the pair loop of the shell is
   // bound by LDS instruction issue, not by its fp64 operations.
   int pi = 0, pj0 = 0, pcnt = 0;
-  if (NPL == 1) {
-    if (lane < P) {
-      pair_of(S, lane, pi, pj0);
-      pcnt = 1;
-    }
-  } else {
-    int base = 0;
-#pragma unroll 1
-    for (int i = 0; i < S; i++) {
-      const int nl = (S - i + NPL - 1) / NPL;
-      if (lane >= base && lane < base + nl) {
-        pi = i;
-        pj0 = i + NPL * (lane - base);
-        pcnt = min(NPL, S - pj0);
-      }
-      base += nl;
-    }
-  }
+  static_assert(lane_pair_run_lanes(S, NPL) <= 64, "the pair runs of an element must fit into one wavefront");
+  lane_pair_run(S, NPL, lane, pi, pj0, pcnt);  // pair_runs.h
   // SVK accumulates three q-sums per pair instead of the block itself (the ratio of the two rank-1 coefficients does not
   // depend on the point): O = sum dV Fh_i (x) Fh_j (acc), TT = sum B1 (h_i.h_j) F F^T (6 unique), cd = the diagonal term:
   // 24 fp64 operations per (pair, point) instead of 42
