@@ -769,7 +769,7 @@ struct TangentLds {
 // WPB wavefronts per workgroup, one element each (own LDS slice); all waves run the same barrier sequence, so
 // __syncthreads() stays legal; WPB > 1 cuts the workgroup dispatch count (972k single-wave groups at config C).
 template <int S, int Q, int QC, int MODEL, int WPB>
-__global__ __launch_bounds__(64 * WPB) void tangent_blocks_kernel(ElemView m, Material mat, double h,
+__global__ __launch_bounds__(64 * WPB, (S == 16 && MODEL == kSVK && WPB == 1) ? 3 : 1) void tangent_blocks_kernel(ElemView m, Material mat, double h,
                                                                  double* __restrict__ Kbuf) {
   using LD = TangentLds<S, Q, QC, MODEL>;
   constexpr int P = LD::kPairs;
@@ -810,9 +810,9 @@ __global__ __launch_bounds__(64 * WPB) void tangent_blocks_kernel(ElemView m, Ma
   static_assert(lane_pair_run_lanes(S, NPL) <= 64, "the pair runs of an element must fit into one wavefront");
   lane_pair_run(S, NPL, lane, pi, pj0, pcnt);  // pair_runs.h
   // SVK accumulates three q-sums per pair instead of the block itself (the ratio of the two rank-1 coefficients does not
-  // depend on the point): O = sum dV Fh_i (x) Fh_j (acc), TT = sum B1 (h_i.h_j) F F^T (6 unique), cd = the diagonal term:
-  // 24 fp64 operations per (pair, point) instead of 42
-  double acc[NPL][9], accT[MODEL == kSVK ? NPL : 1][6], accD[MODEL == kSVK ? NPL : 1];
+  // depend on the point): O = sum dV Fh_i (x) Fh_j (acc) and TT = sum B1 (h_i.h_j) F F^T + the diagonal term (6 unique):
+  // 26 fp64 operations per (pair, point) instead of 42
+  double acc[NPL][9], accT[MODEL == kSVK ? NPL : 1][6];
 #pragma unroll
   for (int n = 0; n < NPL; n++) {
 #pragma unroll
@@ -820,7 +820,6 @@ __global__ __launch_bounds__(64 * WPB) void tangent_blocks_kernel(ElemView m, Ma
     if (MODEL == kSVK) {
 #pragma unroll
       for (int k = 0; k < 6; k++) accT[n][k] = 0.0;
-      accD[n] = 0.0;
     }
   }
 
@@ -925,7 +924,7 @@ __global__ __launch_bounds__(64 * WPB) void tangent_blocks_kernel(ElemView m, Ma
             const double s = hi0 * hj0 + hi1 * hj1 + hi2 * hj2;
             const double t = fi0 * fj0 + fi1 * fj1 + fi2 * fj2;
             const double bs = B1 * s;
-            accD[n] += C0 * s + C1 * t;
+            const double cd = C0 * s + C1 * t;  // the diagonal term rides on the diagonal entries of the F F^T sum
             acc[n][0] += u0 * fj0;
             acc[n][1] += u0 * fj1;
             acc[n][2] += u0 * fj2;
@@ -935,8 +934,12 @@ __global__ __launch_bounds__(64 * WPB) void tangent_blocks_kernel(ElemView m, Ma
             acc[n][6] += u2 * fj0;
             acc[n][7] += u2 * fj1;
             acc[n][8] += u2 * fj2;
-#pragma unroll
-            for (int k = 0; k < 6; k++) accT[n][k] += bs * T[k];
+            accT[n][0] += bs * T[0] + cd;
+            accT[n][1] += bs * T[1];
+            accT[n][2] += bs * T[2];
+            accT[n][3] += bs * T[3] + cd;
+            accT[n][4] += bs * T[4];
+            accT[n][5] += bs * T[5] + cd;
           }
         }
       }
@@ -1067,8 +1070,7 @@ __global__ __launch_bounds__(64 * WPB) void tangent_blocks_kernel(ElemView m, Ma
         for (int r = 0; r < 3; r++)
 #pragma unroll
           for (int c = 0; c < 3; c++)
-            lds[p * 9 + 3 * r + c] = ca * acc[n][3 * r + c] + cb * acc[n][3 * c + r] + accT[n][tix[3 * r + c]] +
-                                     (r == c ? accD[n] : 0.0);
+            lds[p * 9 + 3 * r + c] = ca * acc[n][3 * r + c] + cb * acc[n][3 * c + r] + accT[n][tix[3 * r + c]];
       } else {
 #pragma unroll
         for (int k = 0; k < 9; k++) lds[p * 9 + k] = acc[n][k];
