@@ -39,8 +39,10 @@ typedef struct {
 } tlfea_newton_params;
 
 /* Linear-solve options.  The reference calls cuDSS (sparse Cholesky, SyncedNewton.cu:995-1029,
- * 1103-1114); this engine solves the same SPD system H dv = -g with a block-Jacobi preconditioned
- * CG on the device.  rel_tol is on ||r||/||b||. */
+ * 1103-1114); this engine solves the same SPD system H dv = -g on the device: by default with CG in fp64 on H,
+ * preconditioned by a two-level p-multigrid cycle (T10) or a Chebyshev polynomial of the block-Jacobi-scaled
+ * operator (all kinds), both streaming a scaled fp16 copy of H with fp32 work vectors; method = 1 selects a sparse
+ * direct solve (rocSOLVER re-factorisation).  rel_tol is on ||r||/||b|| of the fp64 system. */
 typedef struct {
   double rel_tol;    /* default 1e-12 */
   int max_iter;      /* default 20000 (outer CG iterations) */

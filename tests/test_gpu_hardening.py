@@ -137,3 +137,88 @@ def test_vbd_graph_follows_material_and_fixed_set():
     assert np.array_equal(g[0], e[0])
     assert np.array_equal(g[1], e[1])          # a stale graph would replay E = 7e8 on a freed fixed-slot buffer
     assert np.max(np.abs(g[1] - g[0])) > 0
+
+
+def test_rereferenced_geometry_refreshes_the_affine_cache():
+    """CalcDnDuPre after the solver analysed the sparsity (re-referencing, which the reference API permits): the affine
+    assembly's cached vertex gradients / det J and its 'all elements straight-sided' decision must follow.  First a
+    straight re-reference (scaled mesh: the affine form stays, with new gradients), then a curved one (one displaced
+    mid-edge node: the general form takes over).  H equals the oracle's built on the same reference each time."""
+    from tests.helpers import make_oracle, perturbed_state
+    X, conn = load_mesh("res2")
+    m = MATERIALS["svk"]
+    fixed = fixed_x0(X)
+    h, rho = 1e-3, 1e12
+    d = make_gpu(X, conn, m, fixed)
+    s = tl.SyncedNewtonSolver(d, d.get_n_constraint())
+    s.SetParameters(tl.SyncedNewtonParams(1e-4, 1e-4, 1e-4, rho, 5, 10, h))
+    s.AnalyzeHessianSparsity()
+    s.AssembleHessian()
+    assert s.GetAssemblyMode() == 3
+
+    def check(Xref, mode):
+        d.UpdatePositions(Xref[:, 0], Xref[:, 1], Xref[:, 2])
+        d.CalcDnDuPre()
+        d.CalcMassMatrix()
+        o = make_oracle(Xref, conn, m, fixed)
+        x, _ = perturbed_state(Xref)
+        o.x, o.y, o.z = x[:, 0].copy(), x[:, 1].copy(), x[:, 2].copy()
+        d.UpdatePositions(x[:, 0], x[:, 1], x[:, 2])
+        s.AssembleHessian()
+        assert s.GetAssemblyMode() == mode
+        ro, ci, val = s.RetrieveHessianCSRToCPU()
+        ro_o, ci_o, val_o = o.assemble_hessian(h, rho)
+        assert np.array_equal(ro, ro_o) and np.array_equal(ci, ci_o)
+        err = float(np.max(np.abs(val - val_o)) / np.max(np.abs(val_o)))
+        assert err < 1e-12, (mode, err)
+
+    check(X * np.array([1.3, 0.8, 1.1]), 3)
+    Xc = X.copy()
+    mid = int(conn[0, 4])
+    Xc[mid] += 0.03 * np.linalg.norm(X[conn[0, 0]] - X[conn[0, 1]]) * np.array([0.3, -0.5, 0.8])
+    check(Xc, 2)
+    check(X, 3)                       # and back to the straight mesh: the affine form again
+    del s
+    d.Destroy()
+
+
+def test_linear_solve_failing_in_a_later_iteration_rolls_the_step_back():
+    """max_iter enough for the first Newton iteration's solve but not for a later, harder one (the tolerance is tightened
+    between the calls through the options, the iteration budget is not): the call fails, v / x / v_prev / lambda are those
+    at the start of the step, the stats say what ran, and a retry with a sufficient budget gives the same step as a
+    solver that never failed."""
+    X, _, d = beam()
+    s = newton(d)
+    s.Solve()                                             # one good step: non-trivial v, lambda
+    x0 = np.stack(d.RetrievePositionToCPU(), axis=1)
+    v0, lam0 = s.RetrieveVelocityToCPU(), s.RetrieveLambdaToCPU()
+    # budget search: the largest max_iter at which the step fails AFTER at least one Newton iteration succeeded
+    failed_late = False
+    for max_iter in (12, 16, 20, 24, 28, 32, 40, 48):
+        s.SetLinSolveOpts(tl.LinSolveOpts(1e-13, max_iter, 1))
+        try:
+            s.Solve()
+        except TlfeaError:
+            st = s.GetStats()
+            assert np.array_equal(np.stack(d.RetrievePositionToCPU(), axis=1), x0)
+            assert np.array_equal(s.RetrieveVelocityToCPU(), v0) and np.array_equal(s.RetrieveLambdaToCPU(), lam0)
+            if st["newton"] >= 1:
+                failed_late = True
+                break
+            continue
+        break
+    if not failed_late:
+        pytest.skip("no iteration budget separates the Newton iterations of this step on this build")
+    s.SetLinSolveOpts(tl.LinSolveOpts(1e-13, 20000, 10))
+    s.Solve()
+    xa = np.stack(d.RetrievePositionToCPU(), axis=1)
+    _, _, d2 = beam()
+    s2 = newton(d2)
+    s2.Solve()
+    s2.Solve()
+    xb = np.stack(d2.RetrievePositionToCPU(), axis=1)
+    disp = np.max(np.abs(xb - x0))
+    assert disp > 0 and np.max(np.abs(xa - xb)) <= 1e-10 * disp + 8 * np.finfo(float).eps * np.max(np.abs(xb))
+    del s, s2
+    d.Destroy()
+    d2.Destroy()

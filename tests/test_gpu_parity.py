@@ -186,7 +186,7 @@ def test_hessian_affine_and_general_forms(tag, mat, monkeypatch):
 
 
 @pytest.mark.parametrize("tag", ["beam_3x2x1", "res2", "res4"])
-def test_linear_solve_pmg_vs_chebyshev_vs_direct(tag):
+def test_linear_solve_pmg_vs_chebyshev(tag):
     """The same fp64 solution with the Chebyshev polynomial and with the two-level p-multigrid preconditioner."""
     X, conn = load_mesh(tag)
     fixed = fixed_x0(X)

@@ -5,18 +5,27 @@
 // What the reference does with four kernels, HBM round trips of F/P and ~4500 double atomics +
 // binary searches per element (FEAT10DataFunc.cuh:85-293,397-458,513-791) is done here as
 //
-//   residual : t10_residual_kernel   thread per element (coalesced element-fastest grad-N copy):
-//                                    F -> P (SVK | Mooney-Rivlin, + Kelvin-Voigt) -> 30 nodal force
-//                                    components, written element-major; no F/P round trip, no atomics
-//              grad_kernel           thread per node: gathers its elements' force rows, adds
-//                                    M(v-v_prev)/h - f_ext + h J^T(lam + rho c)   (SyncedNewton.cu:344-407)
-//   tangent  : t10_tangent_blocks    one element per wavefront, x / grad-N / F / F*h staged in LDS,
-//                                    lane p<55 owns the 3x3 node-pair block (i<=j) and sums its 5 QPs
-//                                    in registers (h*K + C_vis fused) -> element-major block buffer
-//              assemble_rows_kernel  one node row per wavefront: sums the contributions of the
-//                                    row's elements in LDS in a fixed order, adds M/h and
-//                                    h^2*rho*J^T J, streams the 3 CSR rows out once (no memset, no
-//                                    atomics, bitwise reproducible).
+//   residual : residual_kernel<S,Q>   thread per element (coalesced element-fastest grad-N copy):
+//                                     F -> P (SVK | Mooney-Rivlin, + Kelvin-Voigt) -> 3S nodal force
+//                                     components; no F/P round trip, no atomics.  T10 on the solver path also
+//                                     leaves the per-point F records the fused assembly stages and the element's
+//                                     inertia rows M_e (v - v_prev)/h, both through wave-private LDS transposes
+//              grad_light_kernel      8 lanes per node (T10): gathers the node's (force | inertia) records, adds
+//              / grad_kernel          - f_ext + h J^T(lam + rho c)   (SyncedNewton.cu:344-407); grad_kernel is the
+//                                     mass-CSR form of the ANCF kinds
+//   tangent + assembly, T10 + St.Venant-Kirchhoff: ONE launch, no element-block buffer
+//              assemble_affine_kernel straight-sided elements (the default where it applies): 4 lanes per
+//                                     (row, element) instance evaluate the blocks from the four vertex gradients,
+//                                     rows accumulate in LDS in H's own layout and stream out once
+//              assemble_direct_kernel curved elements: one wavefront per group of node rows, lane per
+//                                     (instance, column node), stored grad N
+//   tangent + assembly, Mooney-Rivlin and the ANCF kinds: two launches through the element-block buffer
+//              tangent_blocks_kernel  one element per wavefront, x / grad-N / F / F*h (or the tangent tensor)
+//                                     staged in LDS, a lane owns node-pair block(s) (i<=j) and sums the points
+//                                     in registers (h*K + C_vis fused)
+//              assemble_rows_kernel   one node row per wavefront: sums the contributions of the row's elements
+//                                     in LDS in a fixed order, adds M/h and h^2*rho on pinned rows, streams the
+//                                     3 CSR rows out once (no memset, no atomics, bitwise reproducible).
 //
 // Math follows SVK.cuh:14-55, MooneyRivlin.cuh:17-225, FEAT10Data.cu:97-278 (cited inline).
 #include "tlfea_internal.h"
@@ -1241,13 +1250,16 @@ __device__ __forceinline__ void store_through(double* p, double v, int mode) {
     *p = v;
 }
 
-template <int ROLLED>  // 0: points unrolled (234 VGPRs, 2 waves per SIMD), 1: rolled (168 VGPRs, 3 waves per SIMD)
+// EXP (tools/tune_assemble.py only): honours the work-skipping experiment bits of store_mode; the shipping instantiation
+// (EXP = 0) keeps the store flavour (bits 0-1) and nothing else, so no environment variable can change what H holds
+template <int ROLLED, int EXP>  // ROLLED 0: points unrolled (234 VGPRs, 2 waves per SIMD), 1: rolled (168 VGPRs, 3 waves per SIMD)
 __global__ __launch_bounds__(64, ROLLED ? 3 : 2) void assemble_direct_kernel(ElemView m, Material mat, double h, RowGroups rg,
                                                                const double* __restrict__ Fq,
                                                                const double* __restrict__ mval, double inv_h,
                                                                const int* __restrict__ fixed_slot,
                                                                const double* __restrict__ nw, double penalty,
-                                                               double* __restrict__ Hval, int store_mode) {
+                                                               double* __restrict__ Hval, int store_mode_arg) {
+  const int store_mode = EXP ? store_mode_arg : (store_mode_arg & 3);
   extern __shared__ __attribute__((aligned(16))) double lds_ad[];
   double* rec = lds_ad;                          // [kAdInst][kNQ][kAdRec]
   double* hraw = lds_ad + kAdRecTotal;           // [kAdInst][kNQ][4]: h_i of the pass's instances
@@ -1483,8 +1495,9 @@ void launch_assemble_direct(hipStream_t s, const ElemView& m, const Material& ma
   const size_t lds = (size_t)(kAdRecTotal + kAdHraw + rg.acc_max) * sizeof(double);
   static size_t lds_attr = 0;
   if (lds > 64 * 1024 && lds > lds_attr) {
-    (void)hipFuncSetAttribute((const void*)assemble_direct_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute((const void*)assemble_direct_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    for (const void* f : {(const void*)assemble_direct_kernel<1, 0>, (const void*)assemble_direct_kernel<0, 0>,
+                          (const void*)assemble_direct_kernel<1, 1>, (const void*)assemble_direct_kernel<0, 1>})
+      (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     lds_attr = lds;
   }
   // persistent grid: as many single-wave workgroups as the chip holds at once (8 XCDs x 32 CUs x resident waves per CU),
@@ -1500,7 +1513,7 @@ void launch_assemble_direct(hipStream_t s, const ElemView& m, const Material& ma
   }
   if (occ_lds != lds) {
     int o = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, (const void*)assemble_direct_kernel<1>, 64, lds) == hipSuccess && o > 0)
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, (const void*)assemble_direct_kernel<1, 0>, 64, lds) == hipSuccess && o > 0)
       occ = o;
     occ_lds = lds;
   }
@@ -1519,12 +1532,16 @@ void launch_assemble_direct(hipStream_t s, const ElemView& m, const Material& ma
   // LDS), 8 of the unrolled one; more workgroups than fit leave a tail
   const int occ_eff = occ_env > 0 ? occ_env : std::min(occ, rolled ? 12 : 8);
   const int per_xcd = std::max(1, std::min((n_cu / 8) * occ_eff, (rg.G + 7) / 8));
-  if (rolled)
-    hipLaunchKernelGGL(assemble_direct_kernel<1>, dim3(8 * per_xcd), dim3(64), lds, s, m, mat, h, rg, Fq, mval, 1.0 / h,
-                       fixed_slot, nw, penalty, Hval, store_mode);
-  else
-    hipLaunchKernelGGL(assemble_direct_kernel<0>, dim3(8 * per_xcd), dim3(64), lds, s, m, mat, h, rg, Fq, mval, 1.0 / h,
-                       fixed_slot, nw, penalty, Hval, store_mode);
+  const bool expm = tune && (store_mode & ~3);  // work-skipping experiments: tools only (TLFEA_AD_TUNE), own instantiation
+#define TLFEA_AD_LAUNCH(R, X)                                                                                              \
+  hipLaunchKernelGGL((assemble_direct_kernel<R, X>), dim3(8 * per_xcd), dim3(64), lds, s, m, mat, h, rg, Fq, mval, 1.0 / h, \
+                     fixed_slot, nw, penalty, Hval, store_mode)
+  if (expm) {
+    if (rolled) TLFEA_AD_LAUNCH(1, 1); else TLFEA_AD_LAUNCH(0, 1);
+  } else {
+    if (rolled) TLFEA_AD_LAUNCH(1, 0); else TLFEA_AD_LAUNCH(0, 0);
+  }
+#undef TLFEA_AD_LAUNCH
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1604,15 +1621,16 @@ struct AffineCoef {  // per rule point in the kernel's order (q0, then q_0 .. q_
   double cA[5], cB[5], cC[5], cL[5];  // w_q (h lambda + lamd), w_q (h mu + eta), w_q h mu, w_q h lambda   (x det J)
 };
 
-template <int TIMING>
+template <int TIMING, int EXP>  // EXP: as assemble_direct_kernel (experiment bits honoured by the tools-only instantiation)
 __global__ __launch_bounds__(64, 2) void assemble_affine_kernel(RowGroups4 rg, AffineCoef ac,
                                                                 const double* __restrict__ gvec,
                                                                 const double* __restrict__ Fq16,
                                                                 const double* __restrict__ cmass, double mscale,
                                                                 const int* __restrict__ fixed_slot,
                                                                 const double* __restrict__ nw, double penalty,
-                                                                double* __restrict__ Hval, int store_mode,
+                                                                double* __restrict__ Hval, int store_mode_arg,
                                                                 unsigned long long* __restrict__ tdbg) {
+  const int store_mode = EXP ? store_mode_arg : (store_mode_arg & 3);
   extern __shared__ __attribute__((aligned(16))) double lds_af[];
   double* stage = lds_af;                  // [kAfInst][kAfRec]
   double* cml = lds_af + kAfStage;         // [10][16] mass coefficients of (row node, vertex n, p) x rho / h
@@ -1886,11 +1904,12 @@ __global__ __launch_bounds__(64, 2) void assemble_affine_kernel(RowGroups4 rg, A
 void launch_assemble_affine(hipStream_t s, const ElemView& m, const Material& mat, double h, const RowGroups4& rg,
                             const AffineView& av, const double* Fq16, const double* cmass, double rho0,
                             const int* fixed_slot, const double* nw, double penalty, double* Hval) {
-  const void* fn = (const void*)assemble_affine_kernel<0>;
+  const void* fn = (const void*)assemble_affine_kernel<0, 0>;
   const size_t lds = (size_t)(kAfStage + 160 + rg.acc_max) * sizeof(double);
   static size_t lds_attr = 0;
   if (lds > 64 * 1024 && lds > lds_attr) {
-    (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    for (const void* f : {fn, (const void*)assemble_affine_kernel<0, 1>, (const void*)assemble_affine_kernel<1, 1>})
+      (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     lds_attr = lds;
   }
   static int n_cu = 0;
@@ -1929,7 +1948,7 @@ void launch_assemble_affine(hipStream_t s, const ElemView& m, const Material& ma
     static unsigned long long* d_t = nullptr;
     if (!d_t && hipMalloc(&d_t, 8 * sizeof(unsigned long long)) != hipSuccess) return;
     (void)hipMemsetAsync(d_t, 0, 8 * sizeof(unsigned long long), s);
-    hipLaunchKernelGGL(assemble_affine_kernel<1>, dim3(8 * per_xcd), dim3(64), lds, s, rg, ac, av.gvec, Fq16, cmass, rho0 / h,
+    hipLaunchKernelGGL((assemble_affine_kernel<1, 1>), dim3(8 * per_xcd), dim3(64), lds, s, rg, ac, av.gvec, Fq16, cmass, rho0 / h,
                        fixed_slot, nw, penalty, Hval, store_mode, d_t);
     unsigned long long t[8];
     (void)hipStreamSynchronize(s);
@@ -1940,8 +1959,12 @@ void launch_assemble_affine(hipStream_t s, const ElemView& m, const Material& ma
                  t[5] / np);
     return;
   }
-  hipLaunchKernelGGL(assemble_affine_kernel<0>, dim3(8 * per_xcd), dim3(64), lds, s, rg, ac, av.gvec, Fq16, cmass, rho0 / h,
-                     fixed_slot, nw, penalty, Hval, store_mode, nullptr);
+  if (tune && (store_mode & ~3))  // work-skipping experiments: tools only (TLFEA_AD_TUNE), own instantiation
+    hipLaunchKernelGGL((assemble_affine_kernel<0, 1>), dim3(8 * per_xcd), dim3(64), lds, s, rg, ac, av.gvec, Fq16, cmass,
+                       rho0 / h, fixed_slot, nw, penalty, Hval, store_mode, nullptr);
+  else
+    hipLaunchKernelGGL((assemble_affine_kernel<0, 0>), dim3(8 * per_xcd), dim3(64), lds, s, rg, ac, av.gvec, Fq16, cmass,
+                       rho0 / h, fixed_slot, nw, penalty, Hval, store_mode, nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------

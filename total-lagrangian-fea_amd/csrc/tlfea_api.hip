@@ -104,6 +104,9 @@ struct tlfea_t10_s {  // any element type; the name is kept for the ABI's first 
   // bumped by every setter that changes what a captured launch has baked in (material scalars travel by value, the
   // fixed-node buffers are re-allocated by UpdateNodalFixed): cached hipGraphs carry the value they were captured at
   long gen = 0;
+  // bumped by CalcDnDuPre: the solver's affine-form cache (vertex gradients, det J, the 'all elements straight-sided'
+  // decision) was derived from the grad N / det J of one call and must follow a re-referencing
+  long geom_gen = 0;
   bool is_setup = false, is_constraints_setup = false, is_csr_setup = false, is_j_csr_setup = false,
        is_cj_csr_setup = false, have_dndu = false;
 
@@ -408,6 +411,7 @@ extern "C" int tlfea_t10_calc_dndu_pre(tlfea_t10_t h) {
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipDeviceSynchronize());
   h->have_dndu = true;
+  h->geom_gen++;
   return 0;
 }
 
@@ -952,6 +956,8 @@ struct tlfea_newton_s {
   hipStream_t stream = nullptr, stream_own = nullptr;
   double *d_v = nullptr, *d_vprev = nullptr, *d_lam = nullptr, *d_g = nullptr, *d_dv = nullptr, *d_r = nullptr,
          *d_b = nullptr;
+  double *d_step0 = nullptr, *d_lam0 = nullptr;  // v | v_prev and lambda at the start of the running step (roll-back)
+  int lam0_cap = 0;
   bool profiling = false;
   int pcg_fused = -1;  // -1 auto (fused direction update below 200k nodes), 0/1 forced (TLFEA_PCG_FUSED)
   bool spmv_nt = false; // non-temporal loads of H in the SpMV (TLFEA_SPMV_NT): measured slower at config C  // per-stage hipEvent timing (adds a host sync per stage)
@@ -973,6 +979,7 @@ struct tlfea_newton_s {
   double* d_gvec = nullptr;
   double* d_cmass = nullptr;  // [10][16] element mass coefficients in the kernel's (row node, vertex n, p) order
   bool affine_ok = false;
+  long geom_gen_seen = -1;   // data->geom_gen the affine cache (gvec, affine_ok) was built from
   double affine_dev = -1.0;  // largest relative deviation from the affine form found at set-up (-1: not checked)
   // sparse direct solve (lin.method == 1): rocSOLVER re-factorisation on a host-computed ordering + factor pattern
   struct Direct {
@@ -1068,7 +1075,7 @@ static void direct_destroy(tlfea_newton_t s);
 extern "C" int tlfea_newton_destroy(tlfea_newton_t s) {
   if (!s) return 0;
   void* ptrs[] = {s->d_v, s->d_vprev, s->d_lam, s->d_g, s->d_dv, s->d_r, s->d_b, s->d_eigv, s->d_cd, s->d_cd2, s->d_cres, s->d_xp, s->d_yp, s->d_zp, s->d_H,
-                  s->d_Kbuf, s->d_Dinv, s->d_p, s->d_p2, s->d_q, s->d_zv, s->d_parts, s->d_scal, s->d_if_node, s->d_if_slot, s->d_ibuf, s->d_w, s->d_nw, s->d_wc, s->d_D, s->d_B8, s->d_B1, s->d_sc, s->d_Dinv_s, s->d_cz, s->d_cz2, s->d_cres2, s->d_f32, s->d_own, s->d_sc_mask};
+                  s->d_Kbuf, s->d_Dinv, s->d_p, s->d_p2, s->d_q, s->d_zv, s->d_parts, s->d_scal, s->d_if_node, s->d_if_slot, s->d_ibuf, s->d_w, s->d_nw, s->d_wc, s->d_D, s->d_B8, s->d_B1, s->d_sc, s->d_Dinv_s, s->d_cz, s->d_cz2, s->d_cres2, s->d_f32, s->d_own, s->d_sc_mask, s->d_step0, s->d_lam0};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   for (int* p : s->d_rg)
@@ -1152,6 +1159,131 @@ extern "C" int tlfea_newton_set_profiling(tlfea_newton_t s, int on) {
 extern "C" double* tlfea_newton_velocity_guess_device_ptr(tlfea_newton_t s) { return s->d_v; }
 
 // DOF-level CSR pattern from the coefficient adjacency (SyncedNewton.cu:163-205,830-897)
+
+// ---- work lists of the fused tangent + assembly kernel (T10) -------------------------------------------------------------
+// Both functions can run again after CalcDnDuPre re-referenced the mesh (refresh_geometry): the affine form's vertex
+// gradients, det J and its 'every element is straight-sided' decision are derived from the grad N / det J of ONE call.
+static void free_ints(int** p, int n) {
+  for (int k = 0; k < n; k++)
+    if (p[k]) {
+      (void)hipFree(p[k]);
+      p[k] = nullptr;
+    }
+}
+// Affine form: every element straight-sided (checked on the device against the stored grad N / det J) and the rule the
+// 5-point Keast rule (L = 1/4 at one point, one vertex at 1/2 and three at 1/6 at the others).
+static int setup_affine_form(tlfea_newton_t s, bool* affine_out) {
+  tlfea_t10_t d = s->d;
+  const int N = s->N;
+  *affine_out = false;
+  s->affine_ok = false;
+  if (!(s->asm_mode == 0 && d->have_dndu)) return 0;
+  AffineView av{nullptr, -1, {-1, -1, -1, -1}};
+  bool rule_ok = true;
+  for (int q = 0; q < kNQ && rule_ok; q++) {
+    const double L[4] = {1.0 - d->h_q[0][q] - d->h_q[1][q] - d->h_q[2][q], d->h_q[0][q], d->h_q[1][q], d->h_q[2][q]};
+    int n4 = 0, n2 = 0, n6 = 0, v2 = -1;
+    for (int k = 0; k < 4; k++) {
+      if (std::fabs(L[k] - 0.25) < 1e-14) n4++;
+      else if (std::fabs(L[k] - 0.5) < 1e-14) n2++, v2 = k;
+      else if (std::fabs(L[k] - 1.0 / 6.0) < 1e-14) n6++;
+    }
+    if (n4 == 4 && av.q0 < 0) av.q0 = q;
+    else if (n2 == 1 && n6 == 3 && av.qv[v2] < 0) av.qv[v2] = q;
+    else rule_ok = false;
+  }
+  if (!rule_ok) return 0;
+  double* d_dev = nullptr;
+  if (!s->d_gvec) TRY(dmalloc(&s->d_gvec, (size_t)d->E * 16));
+  TRY(dmalloc(&d_dev, 1));
+  HIP_TRY(hipMemsetAsync(d_dev, 0, sizeof(double), d->stream));
+  av.gvec = s->d_gvec;
+  launch_affine_pre(d->stream, d->view(), av, s->d_gvec, d_dev);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(d->stream));
+  D2H(&s->affine_dev, d_dev, 1);
+  if (std::getenv("TLFEA_AF_VERBOSE"))
+    std::fprintf(stderr, "affine check: largest relative deviation of grad N / det J from the affine form %.3e\n", s->affine_dev);
+  (void)hipFree(d_dev);
+  if (!(s->affine_dev <= 1e-12)) return 0;
+  if (!s->d_rg4[0]) {  // the work lists depend on the connectivity only: built once
+    RowGroups4Host rh;
+    if (!build_row_groups4(N, d->E, d->h_conn.data(), d->h_off.data(), d->h_cols.data(), d->h_n2e_off.data(),
+                           d->h_n2e.data(), d->h_X0.data(), d->h_X0.data() + N, d->h_X0.data() + 2 * (size_t)N, rh))
+      return 0;
+    const std::vector<int>* src[5] = {&rh.g_pass_off, &rh.pt, &rh.gr_info, &rh.gi_head, &rh.gi_ent};
+    for (int k = 0; k < 5; k++) {
+      TRY(dmalloc(&s->d_rg4[k], src[k]->size() + 4));
+      HIP_TRY(hipMemcpy(s->d_rg4[k], src[k]->data(), src[k]->size() * sizeof(int), hipMemcpyHostToDevice));
+    }
+    s->rg4 = RowGroups4{rh.G(), d->E * d->S, rh.acc_max, s->d_rg4[0], reinterpret_cast<const int4*>(s->d_rg4[1]),
+                        reinterpret_cast<const int4*>(s->d_rg4[2]), reinterpret_cast<const int2*>(s->d_rg4[3]),
+                        reinterpret_cast<const int2*>(s->d_rg4[4])};
+  }
+  s->av = av;
+  if (!s->d_cmass) {  // element mass coefficients C_ij = sum_q w_q N_i(q) N_j(q) (the rule of FEAT10Data.cu:206-278)
+    const int edges[6][2] = {{0, 1}, {1, 2}, {0, 2}, {0, 3}, {1, 3}, {2, 3}};  // FEAT10Data.cu:143
+    double Nq[kNQ][kNN], cm[160];
+    for (int q = 0; q < kNQ; q++) {
+      const double L[4] = {1.0 - d->h_q[0][q] - d->h_q[1][q] - d->h_q[2][q], d->h_q[0][q], d->h_q[1][q], d->h_q[2][q]};
+      for (int k = 0; k < 4; k++) Nq[q][k] = L[k] * (2.0 * L[k] - 1.0);
+      for (int k = 0; k < 6; k++) Nq[q][k + 4] = 4.0 * L[edges[k][0]] * L[edges[k][1]];
+    }
+    for (int il = 0; il < kNN; il++)
+      for (int n = 0; n < 4; n++)
+        for (int p = 0; p < 4; p++) {
+          const int j = p == n ? n : t10_mid_of(n, p);
+          double c = 0.0;
+          for (int q = 0; q < kNQ; q++) c += d->h_qw[q] * Nq[q][il] * Nq[q][j];
+          cm[il * 16 + 4 * n + p] = p == n ? c : 0.5 * c;
+        }
+    TRY(dmalloc(&s->d_cmass, 160));
+    HIP_TRY(hipMemcpy(s->d_cmass, cm, sizeof(cm), hipMemcpyHostToDevice));
+  }
+  if (s->d_Fq) (void)hipFree(s->d_Fq);
+  s->d_Fq = nullptr;
+  TRY(dmalloc(&s->d_Fq, (size_t)d->Epad * 50));  // [E][5][10]: F per point, centroid point first
+  s->rg_ok = s->affine_ok = *affine_out = true;
+  return 0;
+}
+// General form (curved elements, other rules): reads the stored grad N itself, nothing to refresh.
+static int setup_general_form(tlfea_newton_t s) {
+  tlfea_t10_t d = s->d;
+  const int N = s->N;
+  s->rg_ok = false;
+  if (!s->d_rg[0]) {
+    RowGroupsHost rh;
+    if (!build_row_groups(N, d->E, d->S, d->h_conn.data(), d->h_off.data(), d->h_cols.data(), d->h_n2e_off.data(),
+                          d->h_n2e.data(), d->h_X0.data(), d->h_X0.data() + N, d->h_X0.data() + 2 * (size_t)N, rh))
+      return 0;
+    const std::vector<int>* src[6] = {&rh.g_pass_off, &rh.pt, &rh.gr_info, &rh.gi_code, &rh.gi_mb, &rh.gi_pack};
+    for (int k = 0; k < 6; k++) {
+      TRY(dmalloc(&s->d_rg[k], src[k]->size() + 4));
+      HIP_TRY(hipMemcpy(s->d_rg[k], src[k]->data(), src[k]->size() * sizeof(int), hipMemcpyHostToDevice));
+    }
+    s->rg = RowGroups{rh.G(), d->E * d->S, rh.acc_max, s->d_rg[0], reinterpret_cast<const int4*>(s->d_rg[1]),
+                      reinterpret_cast<const int4*>(s->d_rg[2]), s->d_rg[3], s->d_rg[4], s->d_rg[5]};
+  }
+  if (s->d_Fq) (void)hipFree(s->d_Fq);
+  s->d_Fq = nullptr;
+  TRY(dmalloc(&s->d_Fq, (size_t)d->E * d->Q * 9));
+  s->rg_ok = true;
+  return 0;
+}
+// CalcDnDuPre ran again since the work lists were built (re-referencing after UpdatePositions, which the reference
+// API permits): redo the affine extraction and the straight-sidedness check from the new grad N / det J, and fall
+// back to the general form if the new reference configuration is curved.
+static int refresh_geometry(tlfea_newton_t s) {
+  tlfea_t10_t d = s->d;
+  if (!s->sparsity_done || s->geom_gen_seen < 0 || d->geom_gen == s->geom_gen_seen) return 0;
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  bool affine = false;
+  TRY(setup_affine_form(s, &affine));
+  if (!affine) TRY(setup_general_form(s));
+  s->geom_gen_seen = d->geom_gen;
+  return 0;
+}
+
 extern "C" int tlfea_newton_analyze_hessian_sparsity(tlfea_newton_t s) {
   if (s->sparsity_done) return 0;
   tlfea_t10_t d = s->d;
@@ -1179,92 +1311,11 @@ extern "C" int tlfea_newton_analyze_hessian_sparsity(tlfea_newton_t s) {
   TRY(dmalloc(&s->d_H, (size_t)s->h_nnz));
   if (d->kind == kT10 && s->asm_mode != 1 && d->h_X0.size() == 3 * (size_t)N) {
     // row groups of the fused tangent + assembly kernel (the element-block buffer Kbuf is then never allocated
-    // unless the material is switched to Mooney-Rivlin: ensure_kbuf)
-    // affine form first: every element straight-sided (checked on the device against the stored grad N / det J) and the
-    // rule the 5-point Keast rule (L = 1/4 at one point, one vertex at 1/2 and three at 1/6 at the others)
+    // unless the material is switched to Mooney-Rivlin: ensure_kbuf): the affine form where it applies, else the general one
     bool affine = false;
-    if (s->asm_mode == 0 && d->have_dndu) {
-      AffineView av{nullptr, -1, {-1, -1, -1, -1}};
-      bool rule_ok = true;
-      for (int q = 0; q < kNQ && rule_ok; q++) {
-        const double L[4] = {1.0 - d->h_q[0][q] - d->h_q[1][q] - d->h_q[2][q], d->h_q[0][q], d->h_q[1][q], d->h_q[2][q]};
-        int n4 = 0, n2 = 0, n6 = 0, v2 = -1;
-        for (int k = 0; k < 4; k++) {
-          if (std::fabs(L[k] - 0.25) < 1e-14) n4++;
-          else if (std::fabs(L[k] - 0.5) < 1e-14) n2++, v2 = k;
-          else if (std::fabs(L[k] - 1.0 / 6.0) < 1e-14) n6++;
-        }
-        if (n4 == 4 && av.q0 < 0) av.q0 = q;
-        else if (n2 == 1 && n6 == 3 && av.qv[v2] < 0) av.qv[v2] = q;
-        else rule_ok = false;
-      }
-      if (rule_ok) {
-        double* d_dev = nullptr;
-        TRY(dmalloc(&s->d_gvec, (size_t)d->E * 16));
-        TRY(dmalloc(&d_dev, 1));
-        HIP_TRY(hipMemsetAsync(d_dev, 0, sizeof(double), d->stream));
-        av.gvec = s->d_gvec;
-        launch_affine_pre(d->stream, d->view(), av, s->d_gvec, d_dev);
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipStreamSynchronize(d->stream));
-        D2H(&s->affine_dev, d_dev, 1);
-        if (std::getenv("TLFEA_AF_VERBOSE"))
-          std::fprintf(stderr, "affine check: largest relative deviation of grad N / det J from the affine form %.3e\n", s->affine_dev);
-        (void)hipFree(d_dev);
-        RowGroups4Host rh;
-        if (s->affine_dev <= 1e-12 &&
-            build_row_groups4(N, d->E, d->h_conn.data(), d->h_off.data(), d->h_cols.data(), d->h_n2e_off.data(),
-                              d->h_n2e.data(), d->h_X0.data(), d->h_X0.data() + N, d->h_X0.data() + 2 * (size_t)N, rh)) {
-          const std::vector<int>* src[5] = {&rh.g_pass_off, &rh.pt, &rh.gr_info, &rh.gi_head, &rh.gi_ent};
-          for (int k = 0; k < 5; k++) {
-            TRY(dmalloc(&s->d_rg4[k], src[k]->size() + 4));
-            HIP_TRY(hipMemcpy(s->d_rg4[k], src[k]->data(), src[k]->size() * sizeof(int), hipMemcpyHostToDevice));
-          }
-          s->rg4 = RowGroups4{rh.G(), d->E * d->S, rh.acc_max, s->d_rg4[0], reinterpret_cast<const int4*>(s->d_rg4[1]),
-                              reinterpret_cast<const int4*>(s->d_rg4[2]), reinterpret_cast<const int2*>(s->d_rg4[3]),
-                              reinterpret_cast<const int2*>(s->d_rg4[4])};
-          s->av = av;
-          {  // element mass coefficients C_ij = sum_q w_q N_i(q) N_j(q) (the rule of FEAT10Data.cu:206-278)
-            const int edges[6][2] = {{0, 1}, {1, 2}, {0, 2}, {0, 3}, {1, 3}, {2, 3}};  // FEAT10Data.cu:143
-            double Nq[kNQ][kNN], cm[160];
-            for (int q = 0; q < kNQ; q++) {
-              const double L[4] = {1.0 - d->h_q[0][q] - d->h_q[1][q] - d->h_q[2][q], d->h_q[0][q], d->h_q[1][q], d->h_q[2][q]};
-              for (int k = 0; k < 4; k++) Nq[q][k] = L[k] * (2.0 * L[k] - 1.0);
-              for (int k = 0; k < 6; k++) Nq[q][k + 4] = 4.0 * L[edges[k][0]] * L[edges[k][1]];
-            }
-            for (int il = 0; il < kNN; il++)
-              for (int n = 0; n < 4; n++)
-                for (int p = 0; p < 4; p++) {
-                  const int j = p == n ? n : t10_mid_of(n, p);
-                  double c = 0.0;
-                  for (int q = 0; q < kNQ; q++) c += d->h_qw[q] * Nq[q][il] * Nq[q][j];
-                  cm[il * 16 + 4 * n + p] = p == n ? c : 0.5 * c;
-                }
-            TRY(dmalloc(&s->d_cmass, 160));
-            HIP_TRY(hipMemcpy(s->d_cmass, cm, sizeof(cm), hipMemcpyHostToDevice));
-          }
-          TRY(dmalloc(&s->d_Fq, (size_t)d->Epad * 50));  // [E][5][10]: F per point, centroid point first
-          s->rg_ok = s->affine_ok = affine = true;
-        } else {
-          (void)hipFree(s->d_gvec);
-          s->d_gvec = nullptr;
-        }
-      }
-    }
-    RowGroupsHost rh;
-    if (!affine &&
-        build_row_groups(N, d->E, d->S, d->h_conn.data(), d->h_off.data(), d->h_cols.data(), d->h_n2e_off.data(),
-                         d->h_n2e.data(), d->h_X0.data(), d->h_X0.data() + N, d->h_X0.data() + 2 * (size_t)N, rh)) {
-      const std::vector<int>* src[6] = {&rh.g_pass_off, &rh.pt, &rh.gr_info, &rh.gi_code, &rh.gi_mb, &rh.gi_pack};
-      for (int k = 0; k < 6; k++) {
-        TRY(dmalloc(&s->d_rg[k], src[k]->size() + 4));
-        HIP_TRY(hipMemcpy(s->d_rg[k], src[k]->data(), src[k]->size() * sizeof(int), hipMemcpyHostToDevice));
-      }
-      s->rg = RowGroups{rh.G(), d->E * d->S, rh.acc_max, s->d_rg[0], reinterpret_cast<const int4*>(s->d_rg[1]),
-                        reinterpret_cast<const int4*>(s->d_rg[2]), s->d_rg[3], s->d_rg[4], s->d_rg[5]};
-      TRY(dmalloc(&s->d_Fq, (size_t)d->E * d->Q * 9));
-      s->rg_ok = true;
-    }
+    TRY(setup_affine_form(s, &affine));
+    if (!affine) TRY(setup_general_form(s));
+    s->geom_gen_seen = d->geom_gen;
   }
   s->sparsity_done = true;
   if (s->verbose)
@@ -1288,6 +1339,22 @@ extern "C" int tlfea_newton_retrieve_hessian_csr(tlfea_newton_t s, int* ro, int*
 extern "C" int tlfea_newton_set_interface(tlfea_newton_t s, const int* iface_nodes, const int* iface_slots,
                                           int n_local, int n_global, const double* node_weight,
                                           tlfea_allreduce_fn fn, void* user, int sync_before_callback) {
+  // every rejection comes before anything is released: a caller that catches the error keeps a working solver
+  if (!s) return fail("tlfea_newton_set_interface: null solver");
+  if (s->pmg.tried)
+    return fail("tlfea_newton_set_interface: set the interface before the first linear solve (the p-multigrid hierarchy "
+                "is partitioned with it)");
+  if (fn) {
+    if (s->d->cons_mode == 2)
+      return fail("tlfea_newton_set_interface: general linear constraints are not supported on the multi-GPU path");
+    if (n_local < 0 || n_global < 0 || (n_local > 0 && (!iface_nodes || !iface_slots)) || !node_weight)
+      return fail("tlfea_newton_set_interface: null / negative argument");
+    for (int k = 0; k < n_local; k++)
+      if (iface_nodes[k] < 0 || iface_nodes[k] >= s->N || iface_slots[k] < 0 || iface_slots[k] >= n_global)
+        return fail("tlfea_newton_set_interface: index out of range");
+  }
+  HIP_TRY(hipStreamSynchronize(s->stream));  // launches that read the old lists may still be in flight
+  HIP_TRY(hipDeviceSynchronize());
   void** ptrs[] = {(void**)&s->d_if_node, (void**)&s->d_if_slot, (void**)&s->d_ibuf, (void**)&s->d_w,
                    (void**)&s->d_nw, (void**)&s->d_wc};
   for (void** p : ptrs)
@@ -1295,29 +1362,23 @@ extern "C" int tlfea_newton_set_interface(tlfea_newton_t s, const int* iface_nod
       (void)hipFree(*p);
       *p = nullptr;
     }
-  if (s->pmg.tried)
-    return fail("tlfea_newton_set_interface: set the interface before the first linear solve (the p-multigrid hierarchy "
-                "is partitioned with it)");
   s->n_if_loc = n_local;
   s->n_if_glob = n_global;
   s->ar = fn;
   s->ar_user = user;
   s->sync_before_cb = sync_before_callback != 0;
   s->n_constraints_global = s->n_constraints;
-  HIP_TRY(hipStreamSynchronize(s->stream));
   s->stream = fn ? nullptr : s->stream_own;
   if (s->d_own) {
     (void)hipFree(s->d_own);
     s->d_own = nullptr;
   }
-  if (!fn) return 0;
+  if (!fn) {
+    s->n_if_loc = s->n_if_glob = 0;
+    return 0;
+  }
   tlfea_t10_t d = s->d;
-  if (d->cons_mode == 2)
-    return fail("tlfea_newton_set_interface: general linear constraints are not supported on the multi-GPU path");
   const size_t N = s->N;
-  for (int k = 0; k < n_local; k++)
-    if (iface_nodes[k] < 0 || iface_nodes[k] >= s->N || iface_slots[k] < 0 || iface_slots[k] >= n_global)
-      return fail("tlfea_newton_set_interface: index out of range");
   TRY(dmalloc(&s->d_if_node, (size_t)std::max(1, n_local)));
   TRY(dmalloc(&s->d_if_slot, (size_t)std::max(1, n_local)));
   TRY(dmalloc(&s->d_ibuf, (size_t)9 * std::max(1, n_global) + 2 * kNPart));
@@ -1558,9 +1619,28 @@ static int sync_constraints(tlfea_newton_t s) {
   HIP_TRY(hipStreamSynchronize(s->stream));
   if (s->d_lam) (void)hipFree(s->d_lam);
   s->n_constraints = d->n_constraint;
-  if (!s->ar) s->n_constraints_global = s->n_constraints;
   TRY(dmalloc(&s->d_lam, (size_t)std::max(1, s->n_constraints)));
   HIP_TRY(hipMemset(s->d_lam, 0, (size_t)std::max(1, s->n_constraints) * sizeof(double)));
+  if (!s->ar) {
+    s->n_constraints_global = s->n_constraints;
+    return 0;
+  }
+  // multi-GPU: the constraint weights follow the new fixed set, and the ranks re-agree on the global count (every rank
+  // reaches this point in the same call: UpdateNodalFixed is a collective operation on a partitioned mesh)
+  if (s->d_wc) (void)hipFree(s->d_wc);
+  s->d_wc = nullptr;
+  if (d->n_constraint > 0) {
+    std::vector<double> wc((size_t)d->n_constraint);
+    for (int k = 0; k < d->n_constraint; k++) wc[k] = s->h_nw[d->h_fixed[k / 3]];
+    TRY(dmalloc(&s->d_wc, wc.size()));
+    HIP_TRY(hipMemcpy(s->d_wc, wc.data(), wc.size() * sizeof(double), hipMemcpyHostToDevice));
+  }
+  double cnt = d->n_constraint;
+  HIP_TRY(hipMemcpy(s->d_ibuf, &cnt, sizeof(double), hipMemcpyHostToDevice));
+  TRY(call_allreduce(s, s->d_ibuf, 1));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  HIP_TRY(hipMemcpy(&cnt, s->d_ibuf, sizeof(double), hipMemcpyDeviceToHost));
+  s->n_constraints_global = (int)(cnt + 0.5);
   return 0;
 }
 static bool pinned_on(tlfea_newton_t s) {
@@ -1630,6 +1710,7 @@ static int fill_mass_term(tlfea_newton_t s, MassTerm& mt) {
 
 static int eval_gradient(tlfea_newton_t s, double* norm_g) {
   tlfea_t10_t d = s->d;
+  TRY(refresh_geometry(s));
   const tlfea_newton_params& p = s->prm;
   const bool mir = mass_in_residual(s);
   {
@@ -1672,6 +1753,11 @@ static int eval_gradient(tlfea_newton_t s, double* norm_g) {
 // how the Newton loop calls it); a stand-alone assembly refreshes it with a residual launch first
 static int assemble(tlfea_newton_t s, bool fq_fresh = true) {
   tlfea_t10_t d = s->d;
+  {
+    const long seen = s->geom_gen_seen;
+    TRY(refresh_geometry(s));
+    if (seen != s->geom_gen_seen) fq_fresh = false;  // the point records follow the assembly's form: rewrite them
+  }
   const tlfea_newton_params& p = s->prm;
   const bool pinned = pinned_on(s);
   if (use_direct(s)) {
@@ -2998,39 +3084,74 @@ extern "C" int tlfea_newton_solve(tlfea_newton_t s) {
   const int n = 3 * s->N;
   hipEvent_t e0 = s->ev[2], e1 = s->ev[3];
   HIP_TRY(hipEventRecord(e0, s->stream));
+  // state at the start of the step: a linear solve that fails in a LATER Newton iteration must not leave the step half
+  // advanced (v, x moved by the earlier iterations, v_prev / lambda by earlier outer iterations)
+  if (!s->d_step0) TRY(dmalloc(&s->d_step0, 2 * (size_t)n));
+  if (s->n_constraints > s->lam0_cap) {
+    if (s->d_lam0) (void)hipFree(s->d_lam0);
+    s->d_lam0 = nullptr;
+    TRY(dmalloc(&s->d_lam0, (size_t)s->n_constraints));
+    s->lam0_cap = s->n_constraints;
+  }
+  HIP_TRY(hipMemcpyAsync(s->d_step0, s->d_v, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
+  HIP_TRY(hipMemcpyAsync(s->d_step0 + n, s->d_vprev, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
+  if (s->n_constraints > 0)
+    HIP_TRY(hipMemcpyAsync(s->d_lam0, s->d_lam, (size_t)s->n_constraints * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
   TRY(begin_step(s));
   int n_outer = 0, n_newton = 0, pcg_total = 0;
   double norm_g = 0.0, norm_c = 0.0;
-  for (int outer = 0; outer < p.max_outer; ++outer) {
-    n_outer++;
-    double norm_g0 = -1.0;
-    for (int it = 0; it < p.max_inner; ++it) {
-      TRY(eval_gradient(s, &norm_g));
-      if (s->verbose) std::printf("  outer %d newton %d ||g|| = %.6e\n", outer, it, norm_g);
-      if (norm_g0 < 0.0) norm_g0 = norm_g;
-      if (norm_g < p.inner_atol || (p.inner_rtol > 0.0 && norm_g0 > 0.0 && norm_g <= p.inner_rtol * norm_g0)) break;
-      launch_axpy_neg(s->stream, n, s->d_g, s->d_b);                       // r = -g  (:494-502)
-      TRY(assemble(s));                                                    // (:1080-1097)
-      int iters = 0;
-      TRY(pcg(s, s->d_b, s->d_dv, &iters, nullptr));                       // cuDSS factor+solve (:1103-1114)
-      pcg_total += iters;
-      n_newton++;
-      TRY(newton_update(s));                                               // v += dv ; x = x_prev + h v (:1116-1119)
+  auto run = [&]() -> int {
+    for (int outer = 0; outer < p.max_outer; ++outer) {
+      n_outer++;
+      double norm_g0 = -1.0;
+      for (int it = 0; it < p.max_inner; ++it) {
+        TRY(eval_gradient(s, &norm_g));
+        if (s->verbose) std::printf("  outer %d newton %d ||g|| = %.6e\n", outer, it, norm_g);
+        if (norm_g0 < 0.0) norm_g0 = norm_g;
+        if (norm_g < p.inner_atol || (p.inner_rtol > 0.0 && norm_g0 > 0.0 && norm_g <= p.inner_rtol * norm_g0)) break;
+        launch_axpy_neg(s->stream, n, s->d_g, s->d_b);                       // r = -g  (:494-502)
+        TRY(assemble(s));                                                    // (:1080-1097)
+        int iters = 0;
+        const int rc = pcg(s, s->d_b, s->d_dv, &iters, nullptr);             // cuDSS factor+solve (:1103-1114)
+        pcg_total += iters;
+        if (rc) return rc;
+        n_newton++;
+        TRY(newton_update(s));                                               // v += dv ; x = x_prev + h v (:1116-1119)
+      }
+      HIP_TRY(hipMemcpyAsync(s->d_vprev, s->d_v, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice,
+                             s->stream));                                    // every OUTER iteration (:1122)
+      if (s->n_constraints_global > 0) {
+        if (d->cons_mode == 2)
+          launch_lin_constraint(s->stream, d->n_constraint, d->d_joff, d->d_jcol, d->d_jval, d->d_rhs, d->d_x, d->d_y,
+                                d->d_z, d->d_cons);
+        else
+          launch_constraint(s->stream, d->n_fixed, d->d_fixed, d->d_x, d->d_y, d->d_z, d->d_xt, d->d_yt, d->d_zt,
+                            d->d_cons);
+        launch_dual_update(s->stream, s->n_constraints, d->d_cons, p.rho, s->d_lam);  // lambda += rho c (:470-481)
+        TRY(device_norm(s, d->d_cons, s->d_wc, s->n_constraints, &norm_c));  // replicated rows weigh 1/multiplicity
+        if (s->verbose) std::printf("  outer %d ||c|| = %.6e\n", outer, norm_c);
+        if (norm_c < p.outer_tol) break;
+      }
     }
-    HIP_TRY(hipMemcpyAsync(s->d_vprev, s->d_v, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice,
-                           s->stream));                                    // every OUTER iteration (:1122)
-    if (s->n_constraints_global > 0) {
-      if (d->cons_mode == 2)
-        launch_lin_constraint(s->stream, d->n_constraint, d->d_joff, d->d_jcol, d->d_jval, d->d_rhs, d->d_x, d->d_y,
-                              d->d_z, d->d_cons);
-      else
-        launch_constraint(s->stream, d->n_fixed, d->d_fixed, d->d_x, d->d_y, d->d_z, d->d_xt, d->d_yt, d->d_zt,
-                          d->d_cons);
-      launch_dual_update(s->stream, s->n_constraints, d->d_cons, p.rho, s->d_lam);  // lambda += rho c (:470-481)
-      TRY(device_norm(s, d->d_cons, s->d_wc, s->n_constraints, &norm_c));  // replicated rows weigh 1/multiplicity
-      if (s->verbose) std::printf("  outer %d ||c|| = %.6e\n", outer, norm_c);
-      if (norm_c < p.outer_tol) break;
-    }
+    return 0;
+  };
+  const int rc_step = run();
+  if (rc_step) {
+    // put the state back to the start of the step (x = x_prev, v, v_prev, lambda as they came in) and report what ran
+    const std::string why = g_err;
+    const size_t nb = (size_t)s->N * sizeof(double);
+    (void)hipMemcpyAsync(s->d_v, s->d_step0, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, s->stream);
+    (void)hipMemcpyAsync(s->d_vprev, s->d_step0 + n, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, s->stream);
+    if (s->n_constraints > 0)
+      (void)hipMemcpyAsync(s->d_lam, s->d_lam0, (size_t)s->n_constraints * sizeof(double), hipMemcpyDeviceToDevice, s->stream);
+    (void)hipMemcpyAsync(d->d_x, s->d_xp, nb, hipMemcpyDeviceToDevice, s->stream);
+    (void)hipMemcpyAsync(d->d_y, s->d_yp, nb, hipMemcpyDeviceToDevice, s->stream);
+    (void)hipMemcpyAsync(d->d_z, s->d_zp, nb, hipMemcpyDeviceToDevice, s->stream);
+    (void)hipStreamSynchronize(s->stream);
+    s->stats[0] = n_outer; s->stats[1] = n_newton; s->stats[2] = norm_g; s->stats[3] = norm_c;
+    s->stats[4] = pcg_total; s->stats[5] = 0.0;
+    g_err = why;
+    return rc_step;
   }
   HIP_TRY(hipEventRecord(e1, s->stream));
   HIP_TRY(hipEventSynchronize(e1));
