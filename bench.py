@@ -77,6 +77,12 @@ def main():
                     help="multi-GPU: exchange through the torch.distributed callback (~15-29 us of host time per collective) "
                          "instead of the engine's built-in RCCL all-reduce (enqueued from C++ on the solver's stream, ~1.6 us; "
                          "the default with the nccl backend; falls back to the callback if its communicator cannot be built)")
+    ap.add_argument("--boundary-sums", action="store_true",
+                    help="multi-GPU: the round-2 exchange (boundary rows summed over a global interface list, ~60 all-reduces "
+                         "per CG iteration) instead of the overlapping partition (owner-computes with ghost layers, neighbour "
+                         "exchanges: <= 12 per CG iteration)")
+    ap.add_argument("--halo-depth", type=int, default=int(os.environ.get("TLFEA_HALO_DEPTH", "12")),
+                    help="multi-GPU: ghost layers of the overlapping partition (coarse steps per neighbour exchange)")
     ap.add_argument("--precond", type=int, default=0, choices=(0, 1, 2),
                     help="0 auto, 1 Chebyshev polynomial, 2 two-level p-multigrid (T10, one GPU)")
     ap.add_argument("--cheb-kappa", type=float, default=0.0, help="polynomial interval [lmax/kappa, lmax] (0 = default)")
@@ -129,9 +135,14 @@ def main():
         raise SystemExit("ANCF configs are single-GPU workloads")
     nx = 0 if is_ancf else cfg["cells"][0]
     # weak scaling: every rank owns one full-size x-slab of a bar `world` times as long
-    w = wl.build(args.config) if is_ancf else wl.build(args.config, cells=cfg["cells"], x_offset_cells=rank * nx)
-    part = None
-    if world > 1:
+    part = hp = None
+    halo = world > 1 and not args.boundary_sums
+    if halo:
+        # overlapping partition: the slab plus `halo_depth` ghost layers towards each neighbour, built rank-locally
+        w, hp = par.halo_slab_structured(wl, args.config, rank, world, args.halo_depth)
+    else:
+        w = wl.build(args.config) if is_ancf else wl.build(args.config, cells=cfg["cells"], x_offset_cells=rank * nx)
+    if world > 1 and not halo:
         par.restrict_bcs_to_global_ends(w, rank, world, cfg)
         lx = cfg["size"][0]
         part = par.slab_partition_structured(w["X"], lx * rank, lx * (rank + 1), rank, world)
@@ -143,9 +154,10 @@ def main():
     if world > 1:
         comm = None
         if backend == "nccl" and not args.torch_collectives and not os.environ.get("TLFEA_BENCH_TORCH_COLLECTIVES"):
-            # every rank must take the same path: agree on whether ALL ranks built their communicator
-            # (probe first -- resolving RCCL inside the engine -- so that no rank waits in ncclCommInitRank for a peer that
-            # never joins)
+            # every rank must take the same path: agree on whether ALL ranks can resolve RCCL inside the engine BEFORE any
+            # rank enters ncclCommInitRank (decided here, never after: a rank waiting in the init for a peer that went
+            # the other way would hang).  From then on a watchdog guards the init and a known-answer all-reduce + ring
+            # send/recv: a rank that does not get the right answers within the limit prints why and exits non-zero.
             try:
                 import ctypes
                 binding = import_module("total-lagrangian-fea_amd.binding")
@@ -155,13 +167,19 @@ def main():
             okf = torch.tensor([1 if probe_ok else 0], device="cuda")
             dist.all_reduce(okf, op=dist.ReduceOp.MIN)
             if int(okf.item()) == 1:
-                comm = par.rccl_communicator(dist, rank, world)
+                comm = par.rccl_communicator(dist, rank, world, timeout_s=float(os.environ.get("TLFEA_RCCL_TIMEOUT", "120")))
             elif rank == 0:
                 print("built-in RCCL exchange unavailable on some rank, using the torch.distributed callback", file=sys.stderr)
         exchange_path = "built-in RCCL (C++)" if comm is not None else f"torch.distributed callback ({backend})"
-        par.attach(s, part, torch, dist, local_preconditioner=args.local_precond, native_rccl=comm)
+        if halo:
+            par.attach_halo(s, hp, torch, dist, native_rccl=comm)
+        else:
+            par.attach(s, part, torch, dist, local_preconditioner=args.local_precond, native_rccl=comm)
     d.UpdatePositions(w["x0"][:, 0], w["x0"][:, 1], w["x0"][:, 2])
     E, N = w["conn"].shape[0], w["X"].shape[0]
+    E_local = E
+    if halo:   # throughput counts the slab's own elements; the overlap is redundant work
+        E = int(np.prod(cfg["cells"])) * 6
     nnz_coef = int(d.RetrieveMassCSRToCPU()[0][-1])
 
     step_ms = []
@@ -198,11 +216,13 @@ def main():
     run(args.warmup)
     barrier()
     c0 = s.Collectives()
+    cs0 = s.GetCommStats()
     t0 = time.perf_counter()
     pcg_its = run(args.steps, args.warmup)
     barrier()
     dt = time.perf_counter() - t0
     n_coll = s.Collectives() - c0
+    cs1 = s.GetCommStats()
     lin_status = s.GetLinSolveStatus()
     if world > 1:
         t = torch.tensor([dt], device="cuda" if backend == "nccl" else "cpu", dtype=torch.float64)
@@ -216,16 +236,18 @@ def main():
     s.SetProfiling(True)
     s.GetStageMs(reset=True)
     nprof = max(3, min(args.steps, 9))
+    cs_prof0 = s.GetCommStats()
     run(nprof, args.warmup + args.steps)
     torch.cuda.synchronize()
+    cs_prof1 = s.GetCommStats()
     st = s.GetStageMs(reset=True)
     s.SetProfiling(False)
     deg_eff, bits_eff, vec_bits = s.GetLinSolveInfo()
-    ab = alg_bytes(E, N, nnz_coef, d.S, d.Q, bits_eff, vec_bits)
+    ab = alg_bytes(E_local, N, nnz_coef, d.S, d.Q, bits_eff, vec_bits)
     fused = s.GetAssemblyMode() >= 2  # one fused tangent + assembly launch instead of tangent_blocks + assemble_rows
     fkey = "assemble_affine" if s.GetAssemblyMode() == 3 else "assemble_direct"
     if fused:   # the residual launch also writes what the fused assembly stages: F at every point
-        ab["residual"] += E * (80 if fkey == "assemble_affine" else 72) * d.Q   # (general form: 72 B, affine form: 80 B per point)
+        ab["residual"] += E_local * (80 if fkey == "assemble_affine" else 72) * d.Q   # (general form: 72 B, affine form: 80 B per point)
     # mean launch duration: `reps` back-to-back launches per kernel between one hipEvent pair on the launch stream
     # (kernel time + same-stream boundary; agrees with rocprofv3 --kernel-trace, profiles/*kernel_stats.csv)
     kt = s.TimeKernels(reps=40 if E < 200000 else 10)
@@ -279,6 +301,28 @@ def main():
     b_alg = 4 * d.S + 24 * d.S * d.Q + 8 * d.Q + 24 * d.S + 72.0 * nnz_coef / E + 24.0 * N / E
     stage_share = {k: round(st[k][0] / nprof, 4) for k in elem_keys + ("pcg", "update")}
 
+    comm_report = {}
+    if world > 1:
+        n_cg = max(1, cs1["cg_iterations"] - cs0["cg_iterations"]) if halo else max(1, int(np.sum(pcg_its)))
+        dx, da = cs1["exchanges"] - cs0["exchanges"], cs1["allreduces"] - cs0["allreduces"]
+        comm_report = {
+            "partition": (f"overlapping: owner-computes with {args.halo_depth} ghost layers per cut ({E_local - E} redundant "
+                          f"elements on this rank), neighbour refreshes + 2 fixed-size all-reduces per CG iteration" if halo else
+                          "boundary sums over the global interface list (one all-reduce per polynomial step)"),
+            "neighbour_exchanges_per_cg_iteration": round((cs1["exchanges_in_cg"] - cs0["exchanges_in_cg"]) / n_cg, 2),
+            "allreduces_per_cg_iteration": round((cs1["allreduces_in_cg"] - cs0["allreduces_in_cg"]) / n_cg, 2) if halo
+            else round(n_coll / n_cg, 2),
+            "exchanges_per_newton_iteration_outside_cg": round((dx + da - (cs1["exchanges_in_cg"] - cs0["exchanges_in_cg"]) -
+                                                                (cs1["allreduces_in_cg"] - cs0["allreduces_in_cg"])) / args.steps, 2),
+            "bytes_per_neighbour_exchange": round((cs1["bytes_exchanged"] - cs0["bytes_exchanged"]) / max(1, dx), 1),
+            "bytes_per_allreduce": round((cs1["bytes_allreduced"] - cs0["bytes_allreduced"]) / max(1, da), 1),
+            # profiling pass (eager launches, hipEvent pair around every exchange / all-reduce on the launch stream, rank 0)
+            "comm_ms_per_step": round((cs_prof1["comm_ms"] - cs_prof0["comm_ms"]) / nprof, 4),
+            "comm_note": "comm_ms_per_step: device time inside neighbour exchanges and all-reduces per Newton iteration on "
+                         "rank 0, eager profiling pass; the timed region replays them inside hipGraphs with the built-in "
+                         "RCCL exchange",
+        }
+
     out = {
         "metric": "T10-tet element-updates/sec per Newton step", "value": round(value, 1), "unit": "element-updates/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
@@ -289,6 +333,7 @@ def main():
                    "pcg_outer_iters_per_step": round(float(np.mean(pcg_its)), 1),
                    **({"exchange": exchange_path, "collectives_per_cg_iteration":
                        round(n_coll / max(1.0, float(np.sum(pcg_its))), 1)} if world > 1 else {}),
+                   **(comm_report if world > 1 else {}),
                    "last_solve_rel_residual": float(lin_status["rel_res"]), "last_solve_converged": lin_status["converged"],
                    "preconditioner": ("block-Jacobi (3x3)" if deg_eff <= 1 else
                                       (f"two-level p-multigrid V-cycle (T10 -> vertex mesh, {pmg[0]} coarse nodes, Galerkin "

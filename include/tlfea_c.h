@@ -277,6 +277,53 @@ tlfea_allreduce_fn tlfea_rccl_allreduce_fn(void);
  * polynomial step.  Call after tlfea_newton_set_interface. */
 int tlfea_newton_set_interface_owners(tlfea_newton_t s, const int *owned);
 
+/* ---- Overlapping partition: owner-computes with ghost layers (the scalable multi-GPU path; the reference has no
+ * counterpart -- it is a single-GPU code; SURVEY.md section 8e / north_star ask for it) ---------------------------------
+ * Every node has ONE owning rank.  A rank's mesh (the data object it was built on) holds its owned nodes, `depth` layers
+ * of ghost nodes (layer k = graph distance k from the owned set, nodes adjacent when they share an element) and every
+ * element touching a node of layer < depth; local numbering: owned nodes first, then ghosts by increasing layer
+ * (`node_layer` must be non-decreasing).  Rows of H, M and grad L of layers < depth are then complete on the rank:
+ * nothing is summed over ranks.  The solver instead REFRESHES ghost values from their owners, neighbour to neighbour
+ * (payload independent of the number of ranks), only where a step needs them: one nodal vector per CG iteration on the
+ * fine level, the coarse polynomial's vectors once per `depth` steps (the overlap is computed redundantly in between),
+ * the Newton update once per iteration, the diagonal blocks once per solve; dot products weigh owned DOFs 1 and ghosts 0
+ * and are summed with `allreduce` (two fixed-size calls per CG iteration).  f_ext, fixed nodes and velocities are given
+ * in full on every node the rank holds (no 1/multiplicity shares).
+ * Lists: for peer k (`peers[k]`), send_nodes[send_off[k] .. send_off[k+1]) = my owned nodes that peer holds as ghosts,
+ * ordered by (layer ON THE PEER = send_layer, global id); recv_nodes[...] = my ghosts owned by that peer ordered by
+ * (own layer, global id) -- the peer's send list in the same order, so 'layers <= D' is a prefix on both sides.
+ * exchange(user, d_send, d_recv, n_peers, peers, send_off, recv_off): for every peer k send bytes
+ * [send_off[k], send_off[k+1]) of d_send to it and receive bytes [recv_off[k], recv_off[k+1]) of d_recv from it (device
+ * buffers; empty ranges are skipped on both sides).  sync_before_callback as in tlfea_newton_set_interface. */
+typedef int (*tlfea_halo_exchange_fn)(void *user, const void *d_send, void *d_recv, int n_peers, const int *peers,
+                                      const long long *send_off, const long long *recv_off);
+typedef struct {
+  int n_peers;
+  const int *peers;
+  const int *send_off, *send_nodes, *send_layer;
+  const int *recv_off, *recv_nodes;
+} tlfea_halo_lists;
+int tlfea_newton_set_halo(tlfea_newton_t s, const int *node_layer /*N*/, int depth, const tlfea_halo_lists *lists,
+                          tlfea_allreduce_fn allreduce, tlfea_halo_exchange_fn exchange, void *user,
+                          int sync_before_callback);
+/* Built-in exchange on a communicator of tlfea_rccl_comm_create: one ncclGroup of ncclSend / ncclRecv pairs per refresh,
+ * ncclAllReduce for the dot-product slots, all enqueued from C++ on the solver's launch stream, so the whole CG
+ * iteration -- collectives included -- is captured in the solver's hipGraphs.  user = the communicator. */
+tlfea_halo_exchange_fn tlfea_rccl_halo_exchange_fn(void);
+/* Known-answer check of a fresh communicator (an all-reduce and a ring send/recv with values a rank can verify) under a
+ * watchdog: returns 0 when every rank saw the right answers; on a wrong answer or when the collectives have not
+ * completed after timeout_s seconds it prints the reason to stderr and terminates the PROCESS with exit code 97 (a
+ * collective that never completes cannot be abandoned safely) -- the launcher sees a failed rank instead of a hang. */
+int tlfea_rccl_self_check(void *comm, int rank, int world, double timeout_s);
+/* tlfea_rccl_comm_create under the same watchdog (ncclCommInitRank blocks until every rank has joined). */
+int tlfea_rccl_comm_create_timeout(const char *id128, int rank, int world, double timeout_s, void **comm_out);
+/* Communication since the solver was built.  out8: [0] ghost refreshes (neighbour exchanges), [1] all-reduces,
+ * [2] bytes sent in refreshes, [3] bytes all-reduced, [4] ms in exchanges + all-reduces measured with hipEvents on the
+ * launch stream (only while tlfea_newton_set_profiling is on), [5] CG iterations, [6] / [7] the refreshes / all-reduces
+ * issued INSIDE CG iterations (the per-iteration budget; the rest is per-solve set-up: diagonal blocks, lambda_max
+ * estimates, the Newton update). */
+int tlfea_newton_get_comm_stats(tlfea_newton_t s, double *out8);
+
 /* ---- SyncedAdamWNocoopSolver (SyncedAdamWNocoop.cuh:22-198, SyncedAdamWNocoop.cu:262-500) ------------------------
  * First-order ALM solver on the same velocity unknowns: per inner iteration one AdamW moment update, x = x_prev + dt v,
  * compute_p + internal force + constraints + grad L (the Newton solver's own residual path).  Single GPU. */

@@ -153,6 +153,14 @@ def main():
                     help="nccl = RCCL on device buffers (the production exchange); one rank per GPU")
     ap.add_argument("--native-rccl", action="store_true",
                     help="the engine's built-in RCCL all-reduce (tlfea_rccl_*) instead of the torch.distributed callback")
+    ap.add_argument("--mode", default="bsum", choices=("bsum", "halo"),
+                    help="bsum: boundary sums over a global interface list (all-reduce); halo: overlapping partition, "
+                         "owner-computes with ghost layers and neighbour exchanges (tlfea_newton_set_halo)")
+    ap.add_argument("--depth", type=int, default=4, help="halo mode: ghost layers")
+    ap.add_argument("--partitioner", default="slab", choices=("slab", "rcb"))
+    ap.add_argument("--loose-counts", action="store_true",
+                    help="do not require the oracle's Newton iteration count (meshes whose ||g|| sits at the round-off floor "
+                         "of the 1e14 penalty terms, where the count is noise: the bunny)")
     ap.add_argument("--fake-iface", action="store_true",
                     help="world_size 1: declare a band of nodes an 'interface' of multiplicity 1, so that every exchange "
                          "of the partitioned path runs (as an identity all-reduce) on the one GPU of the test box")
@@ -165,8 +173,13 @@ def main():
     rank, world = dist.get_rank(), dist.get_world_size()
     X, conn, fixed, f_ext = problem(args.mesh)
     m = helpers.MATERIALS["svk"]
-    owner = par.slab_owner(X, conn, world)
-    part = par.partition_from_global(X, conn, owner, rank, world)
+    owner = par.rcb_owner(X, conn, world) if args.partitioner == "rcb" else par.slab_owner(X, conn, world)
+    if args.mode == "halo":
+        assert args.engine == "hip"
+        node_owner = par.node_owner_from_elements(X.shape[0], conn, owner, world)
+        part = par.halo_partition(X, conn, node_owner, np.arange(X.shape[0]), rank, world, args.depth)
+    else:
+        part = par.partition_from_global(X, conn, owner, rank, world)
     if args.fake_iface:
         assert world == 1
         band = np.argsort(np.abs(X[:, 0] - 0.5 * X[:, 0].max()), kind="stable")[:40].astype(np.int32)
@@ -174,7 +187,7 @@ def main():
         part = par.Partition(0, 1, part.X, part.conn, part.l2g, band, np.arange(len(band)), len(band), part.node_weight,
                              part.elem_ids, part.node_owned)
     fixed_loc = part.localize_nodes(fixed)
-    f_share = part.share_of_nodal_vector(f_ext)
+    f_share = part.local_nodal_vector(f_ext) if args.mode == "halo" else part.share_of_nodal_vector(f_ext)
     prm = orc.NewtonParams(1e-4, 0.0, 1e-6, 1e14, 5, 12, 1e-3)
 
     if args.engine == "oracle":
@@ -190,7 +203,10 @@ def main():
         s.SetParameters(tl.SyncedNewtonParams(1e-4, 0.0, 1e-6, 1e14, 5, 12, 1e-3))
         s.SetLinSolveOpts(tl.LinSolveOpts(1e-13, 20000, 10))
         comm = par.rccl_communicator(dist, rank, world) if args.native_rccl else None
-        par.attach(s, part, torch, dist, local_preconditioner=(args.precond == "local"), native_rccl=comm)
+        if args.mode == "halo":
+            par.attach_halo(s, part, torch, dist, native_rccl=comm)
+        else:
+            par.attach(s, part, torch, dist, local_preconditioner=(args.precond == "local"), native_rccl=comm)
         if os.environ.get("TLFEA_VERBOSE"):
             s.SetVerbose(1)
         counts = []
@@ -201,6 +217,7 @@ def main():
             counts.append((st["outer"], st["newton"]))
             pcg_iters += int(st["pcg_iters"])
         n_collectives = s.Collectives()
+        comm_stats = s.GetCommStats()
         precond = s.GetPreconditioner()
         x_loc = np.stack(d.RetrievePositionToCPU(), axis=1)
         del s
@@ -230,12 +247,12 @@ def main():
         err = float(np.max(np.abs(xg - xo)))
         floor = 8 * np.finfo(np.float64).eps * float(np.max(np.abs(xo)))
         ok = bool(err <= 1e-10 * disp + floor and max_dup <= floor and not np.isnan(xg).any()
-                  and [tuple(c) for c in counts] == ref_counts)
+                  and ([tuple(c) for c in counts] == ref_counts or args.loose_counts))
         report = dict(err=err, disp=disp, max_dup=max_dup, counts=counts, ref_counts=ref_counts, ok=ok,
-                      n_iface=part.n_global_iface)
+                      n_iface=(sum(len(a) for a in part.recv) if args.mode == "halo" else part.n_global_iface))
         if args.engine != "oracle":
             report.update(collectives=n_collectives, pcg_iters=pcg_iters, precond=precond,
-                          newton=int(sum(c[1] for c in counts)))
+                          newton=int(sum(c[1] for c in counts)), comm=comm_stats)
         print(json.dumps(report), flush=True)
         if args.out:
             json.dump(report, open(args.out, "w"))

@@ -13,6 +13,13 @@ _LIB = None
 c_dp = C.POINTER(C.c_double)
 c_ip = C.POINTER(C.c_int)
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int)
+c_llp = C.POINTER(C.c_longlong)
+HALO_EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, c_ip, c_llp, c_llp)
+
+
+class HaloListsC(C.Structure):  # tlfea_halo_lists
+    _fields_ = [("n_peers", C.c_int), ("peers", c_ip), ("send_off", c_ip), ("send_nodes", c_ip), ("send_layer", c_ip),
+                ("recv_off", c_ip), ("recv_nodes", c_ip)]
 
 
 class TlfeaError(RuntimeError):

@@ -169,22 +169,25 @@ void launch_pcg_init(hipStream_t s, int N, const double* b, const double* Dinv, 
 // issued ahead of the dependent cols -> z/p gather chain.  Workgroups of 1024 threads own contiguous row
 // chunks (neighbouring rows share most column nodes -> the gathers hit L1/L2) and the grid never exceeds
 // kNPart workgroups, so the p.q partials fit the common slot array.
-template <bool NT>
-__device__ __forceinline__ double ld_stream(const double* p) {
+template <bool NT, typename HT>
+__device__ __forceinline__ double ld_stream(const HT* p) {
   // H is streamed once per CG iteration: a non-temporal load keeps it from evicting the gathered vectors
-  return NT ? __builtin_nontemporal_load(p) : *p;
+  return (double)(NT ? __builtin_nontemporal_load(p) : *p);
 }
 
 // FUSED: p_new = z + beta p_old is formed on the fly (small meshes: one launch fewer per iteration).
 // !FUSED: p was written by pcg_direction_kernel; only p is gathered (large meshes: half the gather traffic).
-template <bool FUSED, bool NT, int LANES>
-__global__ __launch_bounds__(1024) void spmv_dir_dot_kernel(int N, Incidence inc, const double* __restrict__ Hval,
+// HT: double = H itself; float = its single-precision copy (same layout), the CG's working operator between two
+// fp64 residual replacements (tlfea_api.hip, pcg()): products and sums stay fp64.
+template <typename HT, bool FUSED, bool NT, int LANES>
+__global__ __launch_bounds__(1024) void spmv_dir_dot_kernel(int N, Incidence inc, const HT* __restrict__ Hval,
                                                            const double* __restrict__ z,
                                                            const double* __restrict__ p_old, int first,
                                                            const double* __restrict__ rz_part_old,
                                                            const double* __restrict__ rz_part_new,
                                                            double* __restrict__ p_new, double* __restrict__ q,
-                                                           double* __restrict__ pq_part, int tiled) {
+                                                           double* __restrict__ pq_part, int tiled,
+                                                           const double* __restrict__ wown) {
   __shared__ double sh[32];
   double beta = 0.0;
   if (FUSED && !first) {
@@ -204,7 +207,7 @@ __global__ __launch_bounds__(1024) void spmv_dir_dot_kernel(int N, Incidence inc
   double pq = 0.0;
   for (int i = r0 + hw; i < r1; i += stride) {
     const int off0 = inc.off[i], deg = inc.off[i + 1] - off0, row = 3 * deg;
-    const double* Hi = Hval + (size_t)9 * off0;
+    const HT* Hi = Hval + (size_t)9 * off0;
     double s0 = 0.0, s1 = 0.0, s2 = 0.0;
     // two column rounds in flight per pass (the loads of both rounds are issued before either gather returns)
     for (int t = l32; t < row; t += 2 * LANES) {
@@ -251,7 +254,9 @@ __global__ __launch_bounds__(1024) void spmv_dir_dot_kernel(int N, Incidence inc
       }
       const double sv = (l32 == 0) ? s0 : ((l32 == 1) ? s1 : s2);
       q[c] = sv;
-      pq += pv * sv;  // sv is this rank's partial (H_r p)_c: sum_r p.(H_r p) = p.Hp, so no interface weight here
+      // boundary-sum partition: sv is this rank's partial (H_r p)_c and sum_r p.(H_r p) = p.Hp, so no weight (wown null);
+      // overlapping partition: the row is complete on every rank that holds it, only its owner counts it (wown 1 | 0)
+      pq += (wown ? wown[c] : 1.0) * pv * sv;
     }
   }
   const double r = block_sum(pq, sh);
@@ -266,13 +271,13 @@ int spmv_grid(int N) { return std::max(1, std::min(kNPart, (N + 31) / 32)); }  /
 
 void launch_spmv_dir_dot(hipStream_t s, int N, const Incidence& inc, const double* Hval, const double* z,
                          const double* p_old, int first, const double* rz_part_old, const double* rz_part_new,
-                         double* p_new, double* q, double* pq_part, bool fused, bool nt) {
+                         double* p_new, double* q, double* pq_part, bool fused, bool nt, const double* wown) {
   const dim3 g(spmv_grid(N)), b(1024);
   const int tiled = row_map_tiled() ? 1 : 0;
   static const int lanes = std::getenv("TLFEA_SPMV_LANES") ? std::atoi(std::getenv("TLFEA_SPMV_LANES")) : 32;
 #define TLFEA_SPMV(F, T, L)                                                                                       \
-  hipLaunchKernelGGL((spmv_dir_dot_kernel<F, T, L>), g, b, 0, s, N, inc, Hval, z, p_old, first, rz_part_old,          \
-                     rz_part_new, p_new, q, pq_part, tiled)
+  hipLaunchKernelGGL((spmv_dir_dot_kernel<double, F, T, L>), g, b, 0, s, N, inc, Hval, z, p_old, first, rz_part_old,  \
+                     rz_part_new, p_new, q, pq_part, tiled, wown)
   if (lanes == 16) {
     if (fused) TLFEA_SPMV(true, false, 16);
     else TLFEA_SPMV(false, false, 16);
@@ -281,6 +286,20 @@ void launch_spmv_dir_dot(hipStream_t s, int N, const Incidence& inc, const doubl
   else if (nt) TLFEA_SPMV(false, true, 32);
   else TLFEA_SPMV(false, false, 32);
 #undef TLFEA_SPMV
+}
+
+// the same launch on the single-precision copy of H
+void launch_spmv_dir_dot_f32(hipStream_t s, int N, const Incidence& inc, const float* Hval32, const double* z,
+                             const double* p_old, int first, const double* rz_part_old, const double* rz_part_new,
+                             double* p_new, double* q, double* pq_part, bool fused, const double* wown) {
+  const dim3 g(spmv_grid(N)), b(1024);
+  const int tiled = row_map_tiled() ? 1 : 0;
+  if (fused)
+    hipLaunchKernelGGL((spmv_dir_dot_kernel<float, true, false, 32>), g, b, 0, s, N, inc, Hval32, z, p_old, first,
+                       rz_part_old, rz_part_new, p_new, q, pq_part, tiled, wown);
+  else
+    hipLaunchKernelGGL((spmv_dir_dot_kernel<float, false, false, 32>), g, b, 0, s, N, inc, Hval32, z, p_old, first,
+                       rz_part_old, rz_part_new, p_new, q, pq_part, tiled, wown);
 }
 
 // p = z + beta p (beta from the partial slots; first iteration p = z) -- large meshes only
@@ -1488,7 +1507,8 @@ __global__ __launch_bounds__(256) void pcg_update_init32_kernel(
     int N, const double* __restrict__ p, const double* __restrict__ q, const double* __restrict__ rz_part_old,
     const double* __restrict__ pq_part, double* __restrict__ x, double* __restrict__ r, double* __restrict__ rr_part,
     double* __restrict__ indefinite, const float* __restrict__ Dinv_f, const double* __restrict__ sc,
-    const double* __restrict__ coef, float* __restrict__ d, float* __restrict__ z, float* __restrict__ res) {
+    const double* __restrict__ coef, float* __restrict__ d, float* __restrict__ z, float* __restrict__ res,
+    const double* __restrict__ wown) {
   __shared__ double sh[32];
   double rz_old, pq;
   sum_slots2(rz_part_old, pq_part, rz_old, pq, sh);
@@ -1503,7 +1523,7 @@ __global__ __launch_bounds__(256) void pcg_update_init32_kernel(
       x[3 * i + c] += alpha * p[3 * i + c];
       const double rv = r[3 * i + c] - alpha * q[3 * i + c];
       r[3 * i + c] = rv;
-      rr += rv * rv;
+      rr += (wown ? wown[3 * i + c] : 1.0) * rv * rv;
       rs[c] = (float)(rv * sc[3 * i + c]);
     }
     const float* D = Dinv_f + (size_t)9 * i;
@@ -1524,10 +1544,52 @@ __global__ __launch_bounds__(256) void pcg_update_init32_kernel(
 void launch_pcg_update_init32(hipStream_t s, int N, const double* p, const double* q, const double* rz_part_old,
                               const double* pq_part, double* x, double* r, double* rr_part, double* indefinite,
                               const float* Dinv_f, const double* sc, const double* coef, float* d, float* z,
-                              float* res) {
+                              float* res, const double* wown) {
   const int n_blocks = std::max(1, std::min(kNPart, (N + 255) / 256));
   hipLaunchKernelGGL(pcg_update_init32_kernel, dim3(n_blocks), dim3(256), 0, s, N, p, q, rz_part_old, pq_part, x, r,
-                     rr_part, indefinite, Dinv_f, sc, coef, d, z, res);
+                     rr_part, indefinite, Dinv_f, sc, coef, d, z, res, wown);
+}
+
+// Residual replacement of the mixed-precision CG (q = H x in fp64 on H): r = b - q, its r.r slots, and the fp32 start
+// vectors of the next polynomial -- what pcg_update_init32_kernel leaves, from the TRUE residual.
+__global__ __launch_bounds__(256) void residual_replace_init32_kernel(
+    int N, const double* __restrict__ b, const double* __restrict__ q, double* __restrict__ r,
+    double* __restrict__ rr_part, const float* __restrict__ Dinv_f, const double* __restrict__ sc,
+    const double* __restrict__ coef, float* __restrict__ d, float* __restrict__ z, float* __restrict__ res,
+    const double* __restrict__ wown) {
+  __shared__ double sh[32];
+  const float inv_theta = (float)coef[0];
+  double rr = 0.0;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < N; i += gridDim.x * 256) {
+    float rs[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      const double rv = b[3 * i + c] - q[3 * i + c];
+      r[3 * i + c] = rv;
+      rr += (wown ? wown[3 * i + c] : 1.0) * rv * rv;
+      rs[c] = (float)(rv * sc[3 * i + c]);
+    }
+    const float* D = Dinv_f + (size_t)9 * i;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      const float v = (D[3 * c] * rs[0] + D[3 * c + 1] * rs[1] + D[3 * c + 2] * rs[2]) * inv_theta;
+      d[3 * i + c] = v;
+      z[3 * i + c] = v;
+      res[3 * i + c] = rs[c];
+    }
+  }
+  const double t = block_sum(rr, sh);
+  if (threadIdx.x == 0) rr_part[blockIdx.x] = t;
+  if (blockIdx.x == 0)
+    for (int k = gridDim.x + threadIdx.x; k < kNPart; k += blockDim.x) rr_part[k] = 0.0;
+}
+
+void launch_residual_replace_init32(hipStream_t s, int N, const double* b, const double* q, double* r, double* rr_part,
+                                    const float* Dinv_f, const double* sc, const double* coef, float* d, float* z,
+                                    float* res, const double* wown) {
+  const int n_blocks = std::max(1, std::min(kNPart, (N + 255) / 256));
+  hipLaunchKernelGGL(residual_replace_init32_kernel, dim3(n_blocks), dim3(256), 0, s, N, b, q, r, rr_part, Dinv_f, sc, coef,
+                     d, z, res, wown);
 }
 
 void launch_pcg_update_noz(hipStream_t s, int N, const double* w, const double* p, const double* q,
@@ -1694,6 +1756,48 @@ void launch_pack(hipStream_t s, int n, int dim, const int* node, const int* slot
 void launch_unpack(hipStream_t s, int n, int dim, const int* node, const int* slot, const double* buf, double* dst) {
   if (n <= 0) return;
   hipLaunchKernelGGL(unpack_kernel, dim3((n * dim + 255) / 256), dim3(256), 0, s, n, dim, node, slot, buf, dst);
+}
+
+// ---- overlapping partition: ghost refresh (pack owned values for a peer / scatter a peer's values into my ghosts) -------
+// nvec nodal fields of `dim` values each, interleaved per node in the message: msg[(t * nvec + v) * dim + c]
+template <typename T>
+__global__ __launch_bounds__(256) void halo_pack_kernel(int n, const int* __restrict__ idx, int dim, int nvec,
+                                                       const T* __restrict__ a, const T* __restrict__ b,
+                                                       const T* __restrict__ c, T* __restrict__ msg) {
+  const int per = dim * nvec;
+  for (size_t t = blockIdx.x * (size_t)256 + threadIdx.x; t < (size_t)n * per; t += (size_t)gridDim.x * 256) {
+    const int node = (int)(t / per), r = (int)(t - (size_t)node * per), v = r / dim, cc = r - v * dim;
+    const T* src = v == 0 ? a : (v == 1 ? b : c);
+    msg[t] = src[(size_t)dim * idx[node] + cc];
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void halo_unpack_kernel(int n, const int* __restrict__ idx, int dim, int nvec,
+                                                         const T* __restrict__ msg, T* __restrict__ a,
+                                                         T* __restrict__ b, T* __restrict__ c) {
+  const int per = dim * nvec;
+  for (size_t t = blockIdx.x * (size_t)256 + threadIdx.x; t < (size_t)n * per; t += (size_t)gridDim.x * 256) {
+    const int node = (int)(t / per), r = (int)(t - (size_t)node * per), v = r / dim, cc = r - v * dim;
+    T* dst = v == 0 ? a : (v == 1 ? b : c);
+    dst[(size_t)dim * idx[node] + cc] = msg[t];
+  }
+}
+static int halo_grid(size_t n) { return (int)std::max<size_t>(1, std::min<size_t>(2048, (n + 255) / 256)); }
+void launch_halo_pack_f64(hipStream_t s, int n, const int* idx, int dim, int nvec, const double* a, const double* b,
+                          const double* c, double* msg) {
+  if (n > 0) hipLaunchKernelGGL(halo_pack_kernel<double>, dim3(halo_grid((size_t)n * dim * nvec)), dim3(256), 0, s, n, idx, dim, nvec, a, b, c, msg);
+}
+void launch_halo_unpack_f64(hipStream_t s, int n, const int* idx, int dim, int nvec, const double* msg, double* a, double* b,
+                            double* c) {
+  if (n > 0) hipLaunchKernelGGL(halo_unpack_kernel<double>, dim3(halo_grid((size_t)n * dim * nvec)), dim3(256), 0, s, n, idx, dim, nvec, msg, a, b, c);
+}
+void launch_halo_pack_f32(hipStream_t s, int n, const int* idx, int dim, int nvec, const float* a, const float* b,
+                          const float* c, float* msg) {
+  if (n > 0) hipLaunchKernelGGL(halo_pack_kernel<float>, dim3(halo_grid((size_t)n * dim * nvec)), dim3(256), 0, s, n, idx, dim, nvec, a, b, c, msg);
+}
+void launch_halo_unpack_f32(hipStream_t s, int n, const int* idx, int dim, int nvec, const float* msg, float* a, float* b,
+                            float* c) {
+  if (n > 0) hipLaunchKernelGGL(halo_unpack_kernel<float>, dim3(halo_grid((size_t)n * dim * nvec)), dim3(256), 0, s, n, idx, dim, nvec, msg, a, b, c);
 }
 
 __global__ void extract_diag_kernel(int N, Incidence inc, const double* __restrict__ Hval, double* __restrict__ D) {

@@ -5,13 +5,18 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <map>
 #include <string>
+#include <thread>
 #include <vector>
+#include <unistd.h>
 
 #include "../../include/tlfea_c.h"
 #include "ancf_host.h"
@@ -996,7 +1001,19 @@ struct tlfea_newton_s {
   double* d_scal = nullptr;   // 4 scalars
   double* h_pin = nullptr;    // pinned host words: [0..7] scalars read back, [8..] Chebyshev coefficients to upload
   double* d_coef = nullptr;   // Chebyshev coefficients on the device (2 per step)
-  hipGraphExec_t cg_graph[2] = {nullptr, nullptr};  // CG iteration of even / odd parity
+  hipGraphExec_t cg_graph[3] = {nullptr, nullptr, nullptr};  // CG iteration of even / odd parity / odd + residual replacement
+  // Mixed-precision outer iteration (single GPU, fp32 polynomial path): the CG's SpMV streams a single-precision copy of
+  // H (half the bytes of the iteration's largest launch); every `spmv32_every` iterations -- and before convergence is
+  // declared -- the residual is replaced by b - H x in fp64 on H itself (reliable updates), so the attained residual
+  // and the stopping test are those of the fp64 system.  OPT-IN (TLFEA_SPMV32 = replacement period, even; 0 = off = the
+  // default): measured at config C it saves 2.6 % of a Newton iteration with period 8, stagnates at 5e-11 with period
+  // 16, and on ill-conditioned systems (welded ANCF net, penalty 1e14: cond(H) eps_fp32 > 1) it stagnates at 7e-9 --
+  // each replacement restarts from the error of the fp32 copy.  Kept as an experiment switch, not a default.
+  float* d_H32 = nullptr;
+  int spmv32_every = 0;
+  bool spmv32_now = false;       // this solve runs the mixed-precision iteration
+  const double* cur_b = nullptr; // right-hand side of the running solve (residual replacement)
+  long n_replacements = 0;
   long cg_graph_key[6] = {0, 0, 0, 0, 0, 0};
   bool use_graphs = true;     // TLFEA_GRAPH=0 launches every kernel eagerly
   int last_outer_iters = 0;   // CG iterations of the previous solve: where the next one starts testing convergence
@@ -1023,6 +1040,40 @@ struct tlfea_newton_s {
   bool sync_before_cb = true;
   tlfea_allreduce_fn ar = nullptr;
   void* ar_user = nullptr;
+  // Overlapping partition (tlfea_newton_set_halo): owner-computes with ghost layers.  `ar` stays null -- no boundary
+  // sums exist -- so every launch sequence is the single-GPU one; the hooks are ghost refreshes, owner-weighted dot
+  // products summed with halo.arfn, and row counts that stop at the layers a launch can still compute correctly.
+  struct HaloPlan {   // "refresh ghost layers <= D" of one level: concatenated per-peer prefixes of the send / recv lists
+    int n_send = 0, n_recv = 0;
+    int *d_sidx = nullptr, *d_ridx = nullptr;
+    std::vector<long long> soff, roff;   // [n_peers + 1], in nodes
+  };
+  struct HaloLevel {  // per-peer segments, each ordered by (layer on the receiving side, global id)
+    std::vector<int> send_off, send_nodes, send_layer, recv_off, recv_nodes, recv_layer;
+    std::map<int, HaloPlan> plans;
+  };
+  struct Halo {
+    bool on = false, native = false;
+    int depth = 0;
+    std::vector<int> peers, layer, n_upto;   // n_upto[k] = local nodes of layers <= k (k = 0 .. depth)
+    std::vector<int> n_upto_c;               // the same for the coarse (vertex) level
+    HaloLevel lv[2];                         // 0 fine, 1 coarse
+    void *d_sbuf = nullptr, *d_rbuf = nullptr;
+    size_t cap_s = 0, cap_r = 0;
+    double* d_red = nullptr;                 // staging of the reduction slots
+    tlfea_halo_exchange_fn xfn = nullptr;
+    tlfea_allreduce_fn arfn = nullptr;
+    void* user = nullptr;
+    bool sync_cb = true;
+    long n_exch = 0, n_allred = 0, n_cg_iters = 0, n_exch_cg = 0, n_allred_cg = 0;
+    double bytes_exch = 0.0, bytes_allred = 0.0, comm_ms = 0.0;
+    bool in_cg = false;                       // inside enqueue_cg_iteration: what the per-iteration budget counts
+    double graph_cost[3][5] = {{0}};          // per captured graph: exchanges, all-reduces, bytes, bytes, iterations (added per replay)
+    std::vector<long long> so_b, ro_b;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int rows(int k) const { return n_upto[std::max(0, std::min(k, depth))]; }
+    int rows_c(int k) const { return n_upto_c[std::max(0, std::min(k, depth))]; }
+  } halo;
 };
 
 extern "C" int tlfea_newton_create(tlfea_t10_t data, int n_constraints, tlfea_newton_t* out) {
@@ -1047,7 +1098,7 @@ extern "C" int tlfea_newton_create(tlfea_t10_t data, int n_constraints, tlfea_ne
   TRY(dmalloc(&s->d_xp, (size_t)s->N)); TRY(dmalloc(&s->d_yp, (size_t)s->N)); TRY(dmalloc(&s->d_zp, (size_t)s->N));
   TRY(dmalloc(&s->d_parts, (size_t)6 * kNPart));
   TRY(dmalloc(&s->d_scal, (size_t)4));
-  HIP_TRY(hipHostMalloc((void**)&s->h_pin, (8 + 8 + 2 * 64) * sizeof(double)));
+  HIP_TRY(hipHostMalloc((void**)&s->h_pin, (8 + 32 + 2 * 64) * sizeof(double)));
   TRY(dmalloc(&s->d_coef, (size_t)2 * 64));
   if (const char* e = std::getenv("TLFEA_GRAPH")) s->use_graphs = std::atoi(e) != 0;
   TRY(dmalloc(&s->d_Dinv, (size_t)9 * s->N));
@@ -1059,6 +1110,7 @@ extern "C" int tlfea_newton_create(tlfea_t10_t data, int n_constraints, tlfea_ne
   HIP_TRY(hipStreamCreate(&s->stream_own));
   s->stream = s->stream_own;
   if (const char* e = std::getenv("TLFEA_PCG_FUSED")) s->pcg_fused = std::atoi(e);
+  if (const char* e = std::getenv("TLFEA_SPMV32")) s->spmv32_every = std::max(0, std::atoi(e)) & ~1;  // even: odd parity
   if (const char* e = std::getenv("TLFEA_CHEB_DEG")) s->lin.cheb_degree = std::min(64, std::max(0, std::atoi(e)));
   if (const char* e = std::getenv("TLFEA_SPMV_NT")) s->spmv_nt = std::atoi(e) != 0;
   if (const char* e = std::getenv("TLFEA_CHEB_BITS")) s->lin.cheb_bits = std::atoi(e);
@@ -1072,10 +1124,11 @@ extern "C" int tlfea_newton_create(tlfea_t10_t data, int n_constraints, tlfea_ne
 
 static void cg_graphs_destroy(tlfea_newton_t s);
 static void direct_destroy(tlfea_newton_t s);
+static void halo_free_plans(tlfea_newton_s::HaloLevel& L);
 extern "C" int tlfea_newton_destroy(tlfea_newton_t s) {
   if (!s) return 0;
   void* ptrs[] = {s->d_v, s->d_vprev, s->d_lam, s->d_g, s->d_dv, s->d_r, s->d_b, s->d_eigv, s->d_cd, s->d_cd2, s->d_cres, s->d_xp, s->d_yp, s->d_zp, s->d_H,
-                  s->d_Kbuf, s->d_Dinv, s->d_p, s->d_p2, s->d_q, s->d_zv, s->d_parts, s->d_scal, s->d_if_node, s->d_if_slot, s->d_ibuf, s->d_w, s->d_nw, s->d_wc, s->d_D, s->d_B8, s->d_B1, s->d_sc, s->d_Dinv_s, s->d_cz, s->d_cz2, s->d_cres2, s->d_f32, s->d_own, s->d_sc_mask, s->d_step0, s->d_lam0};
+                  s->d_Kbuf, s->d_Dinv, s->d_p, s->d_p2, s->d_q, s->d_zv, s->d_parts, s->d_scal, s->d_if_node, s->d_if_slot, s->d_ibuf, s->d_w, s->d_nw, s->d_wc, s->d_D, s->d_B8, s->d_B1, s->d_sc, s->d_Dinv_s, s->d_cz, s->d_cz2, s->d_cres2, s->d_f32, s->d_own, s->d_sc_mask, s->d_step0, s->d_lam0, s->d_H32};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   for (int* p : s->d_rg)
@@ -1109,6 +1162,16 @@ extern "C" int tlfea_newton_destroy(tlfea_newton_t s) {
       if (q) (void)hipFree(q);
   }
   if (s->d_coef) (void)hipFree(s->d_coef);
+  {
+    auto& h = s->halo;
+    halo_free_plans(h.lv[0]);
+    halo_free_plans(h.lv[1]);
+    if (h.d_sbuf) (void)hipFree(h.d_sbuf);
+    if (h.d_rbuf) (void)hipFree(h.d_rbuf);
+    if (h.d_red) (void)hipFree(h.d_red);
+    if (h.ev0) (void)hipEventDestroy(h.ev0);
+    if (h.ev1) (void)hipEventDestroy(h.ev1);
+  }
   if (s->stream_own) (void)hipStreamDestroy(s->stream_own);
   delete s;
   return 0;
@@ -1426,6 +1489,10 @@ struct RcclApi {
   int (*all_reduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
   int (*comm_destroy)(void*) = nullptr;
   const char* (*error_string)(int) = nullptr;
+  int (*send)(const void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  int (*recv)(void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  int (*group_start)() = nullptr;
+  int (*group_end)() = nullptr;
 };
 RcclApi& rccl_api() {
   static RcclApi a;
@@ -1445,6 +1512,10 @@ RcclApi& rccl_api() {
   a.all_reduce = (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))dlsym(a.lib, "ncclAllReduce");
   a.comm_destroy = (int (*)(void*))dlsym(a.lib, "ncclCommDestroy");
   a.error_string = (const char* (*)(int))dlsym(a.lib, "ncclGetErrorString");
+  a.send = (int (*)(const void*, size_t, int, int, void*, hipStream_t))dlsym(a.lib, "ncclSend");
+  a.recv = (int (*)(void*, size_t, int, int, void*, hipStream_t))dlsym(a.lib, "ncclRecv");
+  a.group_start = (int (*)())dlsym(a.lib, "ncclGroupStart");
+  a.group_end = (int (*)())dlsym(a.lib, "ncclGroupEnd");
   if (!a.get_unique_id || !a.comm_init_rank || !a.all_reduce || !a.comm_destroy) a.lib = nullptr;
   return a;
 }
@@ -1452,10 +1523,27 @@ int rccl_fail(const char* what, int rc) {
   RcclApi& a = rccl_api();
   return fail(std::string(what) + ": " + (a.error_string ? a.error_string(rc) : "RCCL error " + std::to_string(rc)));
 }
-int rccl_allreduce_cb(void* comm, double* d_buf, int n) {  // sum of n doubles in place, on the null stream (the solver's
-  RcclApi& a = rccl_api();                                  // launch stream once an interface is set)
-  const int rc = a.all_reduce(d_buf, d_buf, (size_t)n, /*ncclDouble*/ 8, /*ncclSum*/ 0, comm, nullptr);
+// stream the built-in callbacks enqueue on: the null stream on the boundary-sum path (its launch stream once an interface
+// is set), the solver's own stream on the overlapping-partition path (set by the engine around every call)
+thread_local hipStream_t g_rccl_stream = nullptr;
+int rccl_allreduce_cb(void* comm, double* d_buf, int n) {  // sum of n doubles in place
+  RcclApi& a = rccl_api();
+  const int rc = a.all_reduce(d_buf, d_buf, (size_t)n, /*ncclDouble*/ 8, /*ncclSum*/ 0, comm, g_rccl_stream);
   return rc == 0 ? 0 : 1;
+}
+// one group of send / recv pairs per ghost refresh (ncclGroup makes the pairs deadlock-free in any order)
+int rccl_halo_exchange_cb(void* comm, const void* d_send, void* d_recv, int n_peers, const int* peers,
+                          const long long* so, const long long* ro) {
+  RcclApi& a = rccl_api();
+  if (!a.send || !a.recv || !a.group_start || !a.group_end) return 1;
+  int rc = a.group_start();
+  for (int k = 0; k < n_peers && rc == 0; k++) {
+    const long long ns = so[k + 1] - so[k], nr = ro[k + 1] - ro[k];
+    if (ns > 0) rc = a.send((const char*)d_send + so[k], (size_t)ns, /*ncclInt8*/ 0, peers[k], comm, g_rccl_stream);
+    if (rc == 0 && nr > 0) rc = a.recv((char*)d_recv + ro[k], (size_t)nr, /*ncclInt8*/ 0, peers[k], comm, g_rccl_stream);
+  }
+  const int rc2 = a.group_end();
+  return (rc == 0 && rc2 == 0) ? 0 : 1;
 }
 }  // namespace
 
@@ -1488,6 +1576,303 @@ extern "C" int tlfea_rccl_comm_destroy(void* comm) {
 }
 extern "C" tlfea_allreduce_fn tlfea_rccl_allreduce_fn(void) { return rccl_allreduce_cb; }
 
+extern "C" tlfea_halo_exchange_fn tlfea_rccl_halo_exchange_fn(void) { return rccl_halo_exchange_cb; }
+
+// A collective that never completes cannot be abandoned: the watchdog reports and ends the process (exit code 97), so the
+// launcher sees a failed rank instead of a hang.
+[[noreturn]] static void rccl_watchdog_abort(const char* what, int rank, double timeout_s) {
+  std::fprintf(stderr, "tlfea: rank %d: %s did not complete within %.0f s -- giving up (exit 97)\n", rank, what, timeout_s);
+  std::fflush(stderr);
+  _exit(97);
+}
+extern "C" int tlfea_rccl_comm_create_timeout(const char* id128, int rank, int world, double timeout_s, void** comm_out) {
+  RcclApi& a = rccl_api();
+  if (!a.lib) return fail("tlfea_rccl: librccl.so could not be resolved");
+  int dev = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  std::atomic<int> done{0};
+  int rc = 0;
+  void* comm = nullptr;
+  RcclUniqueId id;
+  std::memcpy(id.internal, id128, 128);
+  std::thread t([&] {
+    (void)hipSetDevice(dev);
+    rc = a.comm_init_rank(&comm, world, id, rank);
+    done.store(1);
+  });
+  const auto t0 = std::chrono::steady_clock::now();
+  while (!done.load()) {
+    std::this_thread::sleep_for(std::chrono::milliseconds(20));
+    if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s) {
+      t.detach();
+      rccl_watchdog_abort("ncclCommInitRank", rank, timeout_s);
+    }
+  }
+  t.join();
+  if (rc) return rccl_fail("ncclCommInitRank", rc);
+  *comm_out = comm;
+  return 0;
+}
+extern "C" int tlfea_rccl_self_check(void* comm, int rank, int world, double timeout_s) {
+  RcclApi& a = rccl_api();
+  if (!a.lib || !comm) return fail("tlfea_rccl_self_check: no communicator");
+  hipStream_t st = nullptr;
+  HIP_TRY(hipStreamCreate(&st));
+  double* d = nullptr;
+  HIP_TRY(hipMalloc((void**)&d, 8 * sizeof(double)));
+  // all-reduce: sum over ranks of (rank + 1) and of (rank + 1)^2; ring: every rank sends 1000 + rank to rank + 1
+  double h[8] = {rank + 1.0, (rank + 1.0) * (rank + 1.0), 1000.0 + rank, 0, -1.0, 0, 0, 0};
+  HIP_TRY(hipMemcpy(d, h, sizeof(h), hipMemcpyHostToDevice));
+  g_rccl_stream = st;
+  int rc = rccl_allreduce_cb(comm, d, 2);
+  if (rc == 0 && world > 1) {
+    const int next = (rank + 1) % world, prev = (rank + world - 1) % world;
+    rc = a.group_start();
+    if (rc == 0) rc = a.send(d + 2, sizeof(double), 0, next, comm, st);
+    if (rc == 0) rc = a.recv(d + 4, sizeof(double), 0, prev, comm, st);
+    const int rc2 = a.group_end();
+    rc = rc ? rc : rc2;
+  }
+  g_rccl_stream = nullptr;
+  if (rc) {
+    (void)hipFree(d);
+    (void)hipStreamDestroy(st);
+    return fail("tlfea_rccl_self_check: RCCL refused the check collectives");
+  }
+  const auto t0 = std::chrono::steady_clock::now();
+  while (hipStreamQuery(st) == hipErrorNotReady) {
+    std::this_thread::sleep_for(std::chrono::milliseconds(5));
+    if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s)
+      rccl_watchdog_abort("the RCCL self-check (all-reduce + ring send/recv)", rank, timeout_s);
+  }
+  HIP_TRY(hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost));
+  (void)hipFree(d);
+  (void)hipStreamDestroy(st);
+  const double s1 = world * (world + 1.0) / 2.0, s2 = world * (world + 1.0) * (2.0 * world + 1.0) / 6.0;
+  const double ring = world > 1 ? 1000.0 + (rank + world - 1) % world : -1.0;
+  if (h[0] != s1 || h[1] != s2 || h[4] != ring) {
+    std::fprintf(stderr, "tlfea: rank %d: RCCL self-check WRONG ANSWER: all-reduce %.17g %.17g (expected %.17g %.17g), ring %.17g "
+                 "(expected %.17g) -- giving up (exit 97)\n", rank, h[0], h[1], s1, s2, h[4], ring);
+    std::fflush(stderr);
+    _exit(97);
+  }
+  return 0;
+}
+
+// ---- overlapping partition ------------------------------------------------------------------------------------------------
+template <typename T>
+static int upload_vec(T** dst, const std::vector<T>& v);
+static bool dist_on(tlfea_newton_t s) { return s->ar != nullptr || s->halo.on; }
+static int precond_eff(tlfea_newton_t s);
+static int pmg_ks(tlfea_newton_t s);
+// Ghost layers on which the CG residual must be exact when the preconditioner starts: the V-cycle's ks pre-smoothing
+// passes give up one layer each and must leave layer 1 (restriction) and layer ks - 1 (the post-smoother's own-row
+// operands); the polynomial fallback refreshes its direction before every step instead.  The direction z is refreshed
+// one layer deeper (the CG's SpMV gives up one).
+static int halo_dr(tlfea_newton_t s) {
+  if (precond_eff(s) != 2) return 0;
+  const int ks = pmg_ks(s);
+  return std::max(ks + 1, 2 * ks - 1);
+}
+
+static void halo_free_plans(tlfea_newton_s::HaloLevel& L) {
+  for (auto& kv : L.plans) {
+    if (kv.second.d_sidx) (void)hipFree(kv.second.d_sidx);
+    if (kv.second.d_ridx) (void)hipFree(kv.second.d_ridx);
+  }
+  L.plans.clear();
+}
+
+extern "C" int tlfea_newton_set_halo(tlfea_newton_t s, const int* node_layer, int depth, const tlfea_halo_lists* lists,
+                                     tlfea_allreduce_fn allreduce, tlfea_halo_exchange_fn exchange, void* user,
+                                     int sync_before_callback) {
+  if (!s || !node_layer || !lists || !allreduce || !exchange) return fail("tlfea_newton_set_halo: null argument");
+  if (s->pmg.tried || s->ar)
+    return fail("tlfea_newton_set_halo: set the halo on a fresh solver, before the first linear solve and instead of "
+                "tlfea_newton_set_interface");
+  tlfea_t10_t d = s->d;
+  if (d->cons_mode == 2) return fail("tlfea_newton_set_halo: general linear constraints are not supported on the multi-GPU path");
+  if (d->kind != kT10) return fail("tlfea_newton_set_halo: T10 meshes only");
+  if (depth < 3) return fail("tlfea_newton_set_halo: depth must be at least 3");
+  const int N = s->N, P = lists->n_peers;
+  if (P < 0 || (P > 0 && (!lists->peers || !lists->send_off || !lists->recv_off)))
+    return fail("tlfea_newton_set_halo: peer lists missing");
+  for (int i = 0; i < N; i++)
+    if (node_layer[i] < 0 || node_layer[i] > depth || (i > 0 && node_layer[i] < node_layer[i - 1]))
+      return fail("tlfea_newton_set_halo: node_layer must be non-decreasing in 0..depth (owned nodes first, ghosts by layer)");
+  auto& h = s->halo;
+  auto& L = h.lv[0];
+  for (int k = 0; k < P; k++) {
+    const int s0 = lists->send_off[k], s1 = lists->send_off[k + 1], r0 = lists->recv_off[k], r1 = lists->recv_off[k + 1];
+    if (s0 < 0 || s1 < s0 || r0 < 0 || r1 < r0) return fail("tlfea_newton_set_halo: offsets must be non-decreasing");
+    for (int t = s0; t < s1; t++) {
+      const int n = lists->send_nodes[t], l = lists->send_layer[t];
+      if (n < 0 || n >= N || node_layer[n] != 0 || l < 1 || l > depth || (t > s0 && l < lists->send_layer[t - 1]))
+        return fail("tlfea_newton_set_halo: send list must hold owned nodes ordered by their layer on the peer (1..depth)");
+    }
+    for (int t = r0; t < r1; t++) {
+      const int n = lists->recv_nodes[t];
+      if (n < 0 || n >= N || node_layer[n] < 1 || (t > r0 && node_layer[n] < node_layer[lists->recv_nodes[t - 1]]))
+        return fail("tlfea_newton_set_halo: recv list must hold ghost nodes ordered by layer");
+    }
+  }
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  h.on = true;
+  h.native = exchange == rccl_halo_exchange_cb && allreduce == rccl_allreduce_cb;
+  h.depth = depth;
+  h.peers.assign(lists->peers, lists->peers + P);
+  h.layer.assign(node_layer, node_layer + N);
+  h.n_upto.assign(depth + 1, 0);
+  for (int k = 0; k <= depth; k++)
+    h.n_upto[k] = (int)(std::upper_bound(h.layer.begin(), h.layer.end(), k) - h.layer.begin());
+  halo_free_plans(L);
+  L.send_off.assign(lists->send_off, lists->send_off + P + 1);
+  L.recv_off.assign(lists->recv_off, lists->recv_off + P + 1);
+  L.send_nodes.assign(lists->send_nodes, lists->send_nodes + L.send_off[P]);
+  L.send_layer.assign(lists->send_layer, lists->send_layer + L.send_off[P]);
+  L.recv_nodes.assign(lists->recv_nodes, lists->recv_nodes + L.recv_off[P]);
+  L.recv_layer.resize(L.recv_nodes.size());
+  for (size_t t = 0; t < L.recv_nodes.size(); t++) L.recv_layer[t] = node_layer[L.recv_nodes[t]];
+  h.xfn = exchange;
+  h.arfn = allreduce;
+  h.user = user;
+  h.sync_cb = sync_before_callback != 0;
+  if (!h.d_red) TRY(dmalloc(&h.d_red, (size_t)2 * kNPart));
+  if (!h.ev0) {
+    HIP_TRY(hipEventCreate(&h.ev0));
+    HIP_TRY(hipEventCreate(&h.ev1));
+  }
+  // dot products: owned DOFs 1, ghosts 0; the assembly takes no shares (d_nw stays null: every row is complete)
+  if (s->d_w) (void)hipFree(s->d_w);
+  if (s->d_wc) (void)hipFree(s->d_wc);
+  s->d_w = s->d_wc = nullptr;
+  std::vector<double> w3(3 * (size_t)N);
+  for (int i = 0; i < N; i++) w3[3 * (size_t)i] = w3[3 * (size_t)i + 1] = w3[3 * (size_t)i + 2] = node_layer[i] == 0 ? 1.0 : 0.0;
+  TRY(dmalloc(&s->d_w, w3.size()));
+  HIP_TRY(hipMemcpy(s->d_w, w3.data(), w3.size() * sizeof(double), hipMemcpyHostToDevice));
+  s->h_nw.assign((size_t)N, 0.0);
+  for (int i = 0; i < N; i++) s->h_nw[i] = node_layer[i] == 0 ? 1.0 : 0.0;
+  if (d->n_constraint > 0) {
+    std::vector<double> wc((size_t)d->n_constraint);
+    for (int k = 0; k < d->n_constraint; k++) wc[k] = s->h_nw[d->h_fixed[k / 3]];
+    TRY(dmalloc(&s->d_wc, wc.size()));
+    HIP_TRY(hipMemcpy(s->d_wc, wc.data(), wc.size() * sizeof(double), hipMemcpyHostToDevice));
+  }
+  s->pcg_fused = 0;  // the fused direction update would read p of ghost columns nobody wrote
+  // every rank must take the same branches of the ALM loop: agree on whether ANY rank OWNS a constraint
+  double cnt = 0.0;
+  for (int k = 0; k < d->n_constraint; k++) cnt += s->h_nw[d->h_fixed[k / 3]];
+  HIP_TRY(hipMemcpy(h.d_red, &cnt, sizeof(double), hipMemcpyHostToDevice));
+  g_rccl_stream = s->stream;
+  if (h.arfn(h.user, h.d_red, 1)) return fail("tlfea_newton_set_halo: all-reduce callback failed");
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  HIP_TRY(hipMemcpy(&cnt, h.d_red, sizeof(double), hipMemcpyDeviceToHost));
+  s->n_constraints_global = (int)(cnt + 0.5);
+  return 0;
+}
+
+// the plan "ghost layers <= D" of a level (built on first use)
+static int halo_plan(tlfea_newton_t s, int level, int D, tlfea_newton_s::HaloPlan** out) {
+  auto& h = s->halo;
+  auto& L = h.lv[level];
+  D = std::max(0, std::min(D, h.depth));
+  auto it = L.plans.find(D);
+  if (it != L.plans.end()) {
+    *out = &it->second;
+    return 0;
+  }
+  tlfea_newton_s::HaloPlan pl;
+  const int P = (int)h.peers.size();
+  std::vector<int> sidx, ridx;
+  pl.soff.assign(P + 1, 0);
+  pl.roff.assign(P + 1, 0);
+  for (int k = 0; k < P; k++) {
+    for (int t = L.send_off[k]; t < L.send_off[k + 1] && L.send_layer[t] <= D; t++) sidx.push_back(L.send_nodes[t]);
+    for (int t = L.recv_off[k]; t < L.recv_off[k + 1] && L.recv_layer[t] <= D; t++) ridx.push_back(L.recv_nodes[t]);
+    pl.soff[k + 1] = (long long)sidx.size();
+    pl.roff[k + 1] = (long long)ridx.size();
+  }
+  pl.n_send = (int)sidx.size();
+  pl.n_recv = (int)ridx.size();
+  if (sidx.empty()) sidx.push_back(0);
+  if (ridx.empty()) ridx.push_back(0);
+  TRY(upload_vec(&pl.d_sidx, sidx));
+  TRY(upload_vec(&pl.d_ridx, ridx));
+  auto ins = L.plans.emplace(D, std::move(pl));
+  *out = &ins.first->second;
+  return 0;
+}
+
+static int halo_exchange_bytes(tlfea_newton_t s, const tlfea_newton_s::HaloPlan& pl, size_t item) {
+  auto& h = s->halo;
+  const int P = (int)h.peers.size();
+  h.so_b.resize(P + 1);
+  h.ro_b.resize(P + 1);
+  for (int k = 0; k <= P; k++) {
+    h.so_b[k] = pl.soff[k] * (long long)item;
+    h.ro_b[k] = pl.roff[k] * (long long)item;
+  }
+  if (h.sync_cb) HIP_TRY(hipStreamSynchronize(s->stream));
+  if (s->profiling) (void)hipEventRecord(h.ev0, s->stream);
+  g_rccl_stream = s->stream;
+  if (h.xfn(h.user, h.d_sbuf, h.d_rbuf, P, h.peers.data(), h.so_b.data(), h.ro_b.data()))
+    return fail("halo exchange callback failed");
+  if (s->profiling) {
+    (void)hipEventRecord(h.ev1, s->stream);
+    (void)hipEventSynchronize(h.ev1);
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, h.ev0, h.ev1);
+    h.comm_ms += ms;
+  }
+  h.n_exch++;
+  h.n_exch_cg += h.in_cg ? 1 : 0;
+  h.bytes_exch += (double)pl.n_send * item;
+  return 0;
+}
+static int halo_reserve(tlfea_newton_t s, size_t bs, size_t br) {
+  auto& h = s->halo;
+  if (bs > h.cap_s) {
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    if (h.d_sbuf) (void)hipFree(h.d_sbuf);
+    h.cap_s = bs + bs / 4 + 256;
+    HIP_TRY(hipMalloc(&h.d_sbuf, h.cap_s));
+  }
+  if (br > h.cap_r) {
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    if (h.d_rbuf) (void)hipFree(h.d_rbuf);
+    h.cap_r = br + br / 4 + 256;
+    HIP_TRY(hipMalloc(&h.d_rbuf, h.cap_r));
+  }
+  return 0;
+}
+// ghost layers <= D of up to three fp64 / fp32 nodal fields (dim values per node) take their owners' values
+static int halo_refresh_f64(tlfea_newton_t s, int level, int D, int dim, double* a, double* b = nullptr, double* c = nullptr) {
+  if (!s->halo.on || s->halo.peers.empty()) return 0;
+  tlfea_newton_s::HaloPlan* pl = nullptr;
+  TRY(halo_plan(s, level, D, &pl));
+  if (pl->n_send == 0 && pl->n_recv == 0) return 0;
+  const int nvec = c ? 3 : (b ? 2 : 1);
+  const size_t item = (size_t)dim * nvec * sizeof(double);
+  TRY(halo_reserve(s, pl->n_send * item, pl->n_recv * item));
+  launch_halo_pack_f64(s->stream, pl->n_send, pl->d_sidx, dim, nvec, a, b, c, (double*)s->halo.d_sbuf);
+  TRY(halo_exchange_bytes(s, *pl, item));
+  launch_halo_unpack_f64(s->stream, pl->n_recv, pl->d_ridx, dim, nvec, (const double*)s->halo.d_rbuf, a, b, c);
+  return 0;
+}
+static int halo_refresh_f32(tlfea_newton_t s, int level, int D, int dim, float* a, float* b = nullptr, float* c = nullptr) {
+  if (!s->halo.on || s->halo.peers.empty()) return 0;
+  tlfea_newton_s::HaloPlan* pl = nullptr;
+  TRY(halo_plan(s, level, D, &pl));
+  if (pl->n_send == 0 && pl->n_recv == 0) return 0;
+  const int nvec = c ? 3 : (b ? 2 : 1);
+  const size_t item = (size_t)dim * nvec * sizeof(float);
+  TRY(halo_reserve(s, pl->n_send * item, pl->n_recv * item));
+  launch_halo_pack_f32(s->stream, pl->n_send, pl->d_sidx, dim, nvec, a, b, c, (float*)s->halo.d_sbuf);
+  TRY(halo_exchange_bytes(s, *pl, item));
+  launch_halo_unpack_f32(s->stream, pl->n_recv, pl->d_ridx, dim, nvec, (const float*)s->halo.d_rbuf, a, b, c);
+  return 0;
+}
+
 // Which of the replicated partition-boundary nodes this rank OWNS (exactly one owner per node over all ranks; interior
 // nodes are owned by definition).  With owners set, the polynomial preconditioner becomes rank-local: each rank
 // applies it to the block of the matrix on its own nodes with no exchange inside, and ONE packed all-reduce per CG
@@ -1505,7 +1890,26 @@ extern "C" int tlfea_newton_set_interface_owners(tlfea_newton_t s, const int* ow
 
 static int call_allreduce(tlfea_newton_t s, double* d_buf, int n) {
   s->n_collectives++;
+  if (s->halo.on) {
+    auto& h = s->halo;
+    if (h.sync_cb) HIP_TRY(hipStreamSynchronize(s->stream));
+    if (s->profiling) (void)hipEventRecord(h.ev0, s->stream);
+    g_rccl_stream = s->stream;
+    if (h.arfn(h.user, d_buf, n)) return fail("all-reduce callback failed");
+    if (s->profiling) {
+      (void)hipEventRecord(h.ev1, s->stream);
+      (void)hipEventSynchronize(h.ev1);
+      float ms = 0.f;
+      (void)hipEventElapsedTime(&ms, h.ev0, h.ev1);
+      h.comm_ms += ms;
+    }
+    h.n_allred++;
+    h.n_allred_cg += h.in_cg ? 1 : 0;
+    h.bytes_allred += 8.0 * n;
+    return 0;
+  }
   if (s->sync_before_cb) HIP_TRY(hipStreamSynchronize(s->stream));
+  g_rccl_stream = nullptr;
   if (s->ar(s->ar_user, d_buf, n)) return fail("interface all-reduce callback failed");
   return 0;
 }
@@ -1548,12 +1952,13 @@ static int iface_sum_lvl(tlfea_newton_t s, int n_if_loc, int n_if_glob, const in
 }
 // sum over ranks of reduction slots only (element-wise), so every rank re-adds identical partials
 static int parts_sum(tlfea_newton_t s, double* d_a, double* d_b = nullptr) {
-  if (!s->ar) return 0;
-  HIP_TRY(hipMemcpyAsync(s->d_ibuf, d_a, (size_t)kNPart * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
-  if (d_b) HIP_TRY(hipMemcpyAsync(s->d_ibuf + kNPart, d_b, (size_t)kNPart * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
-  TRY(call_allreduce(s, s->d_ibuf, d_b ? 2 * kNPart : kNPart));
-  HIP_TRY(hipMemcpyAsync(d_a, s->d_ibuf, (size_t)kNPart * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
-  if (d_b) HIP_TRY(hipMemcpyAsync(d_b, s->d_ibuf + kNPart, (size_t)kNPart * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
+  if (!dist_on(s)) return 0;
+  double* buf = s->halo.on ? s->halo.d_red : s->d_ibuf;
+  HIP_TRY(hipMemcpyAsync(buf, d_a, (size_t)kNPart * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
+  if (d_b) HIP_TRY(hipMemcpyAsync(buf + kNPart, d_b, (size_t)kNPart * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
+  TRY(call_allreduce(s, buf, d_b ? 2 * kNPart : kNPart));
+  HIP_TRY(hipMemcpyAsync(d_a, buf, (size_t)kNPart * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
+  if (d_b) HIP_TRY(hipMemcpyAsync(d_b, buf + kNPart, (size_t)kNPart * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
   return 0;
 }
 
@@ -1562,7 +1967,7 @@ static double* part(tlfea_newton_t s, int k) { return s->d_parts + (size_t)k * k
 // sum of squares (over ranks) left in s->d_scal[0]; no host synchronisation on the single-GPU path
 static int device_sumsq_async(tlfea_newton_t s, const double* d_vec, const double* w, int n) {
   launch_norm2(s->stream, d_vec, w, n, part(s, 5), s->d_scal);
-  if (s->ar) {
+  if (dist_on(s)) {
     TRY(parts_sum(s, part(s, 5)));
     launch_sum_parts(s->stream, part(s, 5), s->d_scal);
   }
@@ -1621,7 +2026,7 @@ static int sync_constraints(tlfea_newton_t s) {
   s->n_constraints = d->n_constraint;
   TRY(dmalloc(&s->d_lam, (size_t)std::max(1, s->n_constraints)));
   HIP_TRY(hipMemset(s->d_lam, 0, (size_t)std::max(1, s->n_constraints) * sizeof(double)));
-  if (!s->ar) {
+  if (!dist_on(s)) {
     s->n_constraints_global = s->n_constraints;
     return 0;
   }
@@ -1635,11 +2040,13 @@ static int sync_constraints(tlfea_newton_t s) {
     TRY(dmalloc(&s->d_wc, wc.size()));
     HIP_TRY(hipMemcpy(s->d_wc, wc.data(), wc.size() * sizeof(double), hipMemcpyHostToDevice));
   }
-  double cnt = d->n_constraint;
-  HIP_TRY(hipMemcpy(s->d_ibuf, &cnt, sizeof(double), hipMemcpyHostToDevice));
-  TRY(call_allreduce(s, s->d_ibuf, 1));
+  double cnt = 0.0;   // boundary sums: every holder counts its rows; overlapping partition: owners only
+  for (int k = 0; k < d->n_constraint; k++) cnt += s->halo.on ? s->h_nw[d->h_fixed[k / 3]] : 1.0;
+  double* buf = s->halo.on ? s->halo.d_red : s->d_ibuf;
+  HIP_TRY(hipMemcpy(buf, &cnt, sizeof(double), hipMemcpyHostToDevice));
+  TRY(call_allreduce(s, buf, 1));
   HIP_TRY(hipStreamSynchronize(s->stream));
-  HIP_TRY(hipMemcpy(&cnt, s->d_ibuf, sizeof(double), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(&cnt, buf, sizeof(double), hipMemcpyDeviceToHost));
   s->n_constraints_global = (int)(cnt + 0.5);
   return 0;
 }
@@ -1869,20 +2276,24 @@ static int estimate_lam_max_local(tlfea_newton_t s) {
 static int estimate_lam_max(tlfea_newton_t s, const double* d_b) {
   if (s->ar && s->d_own && cheb_bits_eff(s) != 64) return estimate_lam_max_local(s);
   tlfea_t10_t d = s->d;
-  const int N = s->N, n = 3 * N;
+  const int N = s->N;
   const bool cold = !(s->lam_max > 0.0);
   const int iters = cold ? 16 : 2;  // warm: H moves little between Newton iterations, the vector is kept
   // v <- D^-1 H v / ||D^-1 H v||, the norm stays on the device between iterations: one host read at the end
-  if (cold) launch_apply_dinv(s->stream, N, s->d_Dinv, d_b, s->d_eigv);
-  TRY(device_sumsq_async(s, s->d_eigv, s->d_w, n));
-  launch_scale_inv_sqrt(s->stream, n, s->d_scal, s->d_eigv);
+  // overlapping partition: the iteration lives on the owned rows; ghost layer 1 of the vector is refreshed before every
+  // product, deeper ghosts are never touched
+  const int Nr = s->halo.on ? s->halo.rows(0) : N, nr = 3 * Nr;
+  if (cold) launch_apply_dinv(s->stream, Nr, s->d_Dinv, d_b, s->d_eigv);
+  TRY(device_sumsq_async(s, s->d_eigv, s->d_w, nr));
+  launch_scale_inv_sqrt(s->stream, nr, s->d_scal, s->d_eigv);
   for (int k = 0; k < iters; k++) {
-    launch_spmv_dir_dot(s->stream, N, d->inc(), s->d_H, s->d_eigv, s->d_eigv, 1, part(s, 1), part(s, 0), s->d_p2, s->d_q,
+    TRY(halo_refresh_f64(s, 0, 1, 3, s->d_eigv));
+    launch_spmv_dir_dot(s->stream, Nr, d->inc(), s->d_H, s->d_eigv, s->d_eigv, 1, part(s, 1), part(s, 0), s->d_p2, s->d_q,
                         part(s, 2), false, s->spmv_nt);
     if (s->ar) TRY(iface_sum(s, s->d_q, 3));
-    launch_apply_dinv(s->stream, N, s->d_Dinv, s->d_q, s->d_eigv);
-    TRY(device_sumsq_async(s, s->d_eigv, s->d_w, n));
-    launch_scale_inv_sqrt(s->stream, n, s->d_scal, s->d_eigv);
+    launch_apply_dinv(s->stream, Nr, s->d_Dinv, s->d_q, s->d_eigv);
+    TRY(device_sumsq_async(s, s->d_eigv, s->d_w, nr));
+    launch_scale_inv_sqrt(s->stream, nr, s->d_scal, s->d_eigv);
   }
   double ss = 0.0;
   TRY(fetch_scalar(s, s->d_scal, &ss));
@@ -1937,11 +2348,17 @@ static int cheb_apply(tlfea_newton_t s, const double* d_r, double* d_z, double* 
     float *f_d = s->d_f32, *f_d2 = f_d + n, *f_z = f_d2 + n, *f_z2 = f_z + n, *f_r = f_z2 + n, *f_r2 = f_r + n;
     const float* Dinv_f = f_r2 + n;
     // init_done: the previous iteration's update kernel already wrote the start vectors (pcg_update_init32_kernel)
-    if (!init_done) launch_cheb32_init(s->stream, N, Dinv_f, d_r, sc, s->d_coef, f_d, f_z, f_r);
+    // overlapping partition (meshes without a p-multigrid hierarchy): owned rows only, the direction's first ghost layer
+    // is refreshed before every step
+    const bool hal = s->halo.on;
+    const int Nr = hal ? s->halo.rows(0) : N;
+    const C32Bnd bnd = hal ? C32Bnd{nullptr, nullptr, s->d_w} : C32Bnd();
+    if (!init_done) launch_cheb32_init(s->stream, Nr, Dinv_f, d_r, sc, s->d_coef, f_d, f_z, f_r);
     for (int k = 1; k < deg; k++) {
       const bool last = (k == deg - 1);
-      launch_cheb32(s->stream, N, d->nnz_coef, d->inc(), s->d_B8, s->d_B1, bits, Dinv_f, sc, f_d, s->d_coef + 2 * k, f_d2,
-                    f_z, f_z2, f_r, f_r2, d_r, d_z, rz_part, last);
+      if (hal) TRY(halo_refresh_f32(s, 0, 1, 3, f_d));
+      launch_cheb32(s->stream, Nr, d->nnz_coef, d->inc(), s->d_B8, s->d_B1, bits, Dinv_f, sc, f_d, s->d_coef + 2 * k, f_d2,
+                    f_z, f_z2, f_r, f_r2, d_r, d_z, rz_part, last, bnd);
       std::swap(f_d, f_d2);
       std::swap(f_z, f_z2);
       std::swap(f_r, f_r2);
@@ -2011,10 +2428,23 @@ static double pmg_kappa_coarse(int kc) {
   return forced > 1.0 ? forced : 1.5 * kc * kc;
 }
 static int pmg_coarse_degree_eff(tlfea_newton_t s) {
-  const int base = pmg_coarse_degree((s->ar && s->pmg.Nc_glob > 0) ? s->pmg.Nc_glob : s->pmg.Nc);
+  const int base = pmg_coarse_degree((dist_on(s) && s->pmg.Nc_glob > 0) ? s->pmg.Nc_glob : s->pmg.Nc);
   return std::min(kPmgMaxCoarseDeg, (int)std::lround(base * s->pmg.kc_boost));
 }
 static const double kPmgKappaS = std::getenv("TLFEA_PMG_KAPPA_S") ? std::atof(std::getenv("TLFEA_PMG_KAPPA_S")) : 8.0;
+// terms of the fine smoother's Chebyshev polynomial (TLFEA_PMG_KS; 2 = the measured optimum): pre- and post-smoothing
+// cost ks fine passes each (ks - 1 steps + the residual / restart pass)
+static const int kPmgMaxKs = 6;
+static int pmg_ks(tlfea_newton_t s) {
+  static const int forced = std::getenv("TLFEA_PMG_KS") ? std::atoi(std::getenv("TLFEA_PMG_KS")) : 0;
+  if (s->pmg.agg.ok) return 2;  // the three-level tables keep the fixed two-term layout
+  return forced >= 1 ? std::min(forced, kPmgMaxKs) : 2;
+}
+// coefficient table of the cycle (device doubles): [0 .. 2 ks) init + steps of the fine smoother, then the residual pass
+// (0, 0), the post-smoothing restart (0, 1/theta), then the coarse polynomial
+static int pmg_cf_resid(tlfea_newton_t s) { return 2 * pmg_ks(s); }
+static int pmg_cf_restart(tlfea_newton_t s) { return 2 * pmg_ks(s) + 2; }
+static int pmg_cf_coarse(tlfea_newton_t s) { return 2 * pmg_ks(s) + 4; }
 // Third level (rigid-body-mode aggregates below the vertex level): opt-in with TLFEA_PMG_LEVELS=3.  Measured at config C
 // it makes a CG iteration 10-12 % cheaper (4 vertex-level steps + a degree-20..32 polynomial on ~20 000 level-3 nodes
 // instead of 31 vertex-level steps) and costs 10-17 % more iterations (33-35 instead of 30, whatever the accuracy of
@@ -2079,7 +2509,7 @@ static int pmg_prepare(tlfea_newton_t s) {
   TRY(dmalloc(&m.d_sc_c, nc)); TRY(dmalloc(&m.d_Dinv_s_c, (size_t)9 * m.Nc));
   TRY(dmalloc(&m.d_eigv_c, nc)); TRY(dmalloc(&m.d_q_c, nc)); TRY(dmalloc(&m.d_p_c, nc));
   TRY(dmalloc(&m.d_f32c, 6 * nc + (size_t)9 * m.Nc));
-  TRY(dmalloc(&m.d_coef, (size_t)8 + 2 * kPmgMaxCoarseDeg));
+  TRY(dmalloc(&m.d_coef, (size_t)2 * kPmgMaxKs + 4 + 2 * kPmgMaxCoarseDeg));
   m.ok = true;
   if (s->verbose) std::printf("p-multigrid: %d fine nodes -> %d vertex nodes, %d coarse blocks\n", d->N, m.Nc, m.nnz_c);
   if (s->ar) {
@@ -2135,6 +2565,56 @@ static int pmg_prepare(tlfea_newton_t s) {
     TRY(upload_vec(&m.d_child_w_dist, cw));
     if (s->verbose) std::printf("p-multigrid: partitioned coarse level, %d of %d boundary vertices on this rank\n", m.n_ifc_loc, nc_glob);
   }
+  if (s->halo.on) {
+    // Overlapping partition: the coarse level inherits owners and layers (a vertex is adjacent to the vertices of its
+    // elements: the same graph distance).  Coarse exchange lists = the fine lists restricted to vertex nodes.
+    if (pmg_levels_wanted(m.Nc) == 3) return fail("p-multigrid: the third level is single-GPU only");
+    auto& hl = s->halo;
+    const auto& Lf = hl.lv[0];
+    auto& Lc = hl.lv[1];
+    halo_free_plans(Lc);
+    const int P = (int)hl.peers.size();
+    auto is_vertex = [&](int n) { return h.par0[n] == h.par1[n]; };
+    Lc.send_off.assign(P + 1, 0);
+    Lc.recv_off.assign(P + 1, 0);
+    Lc.send_nodes.clear(); Lc.send_layer.clear(); Lc.recv_nodes.clear(); Lc.recv_layer.clear();
+    for (int k = 0; k < P; k++) {
+      for (int t = Lf.send_off[k]; t < Lf.send_off[k + 1]; t++)
+        if (is_vertex(Lf.send_nodes[t])) {
+          Lc.send_nodes.push_back(h.par0[Lf.send_nodes[t]]);
+          Lc.send_layer.push_back(Lf.send_layer[t]);
+        }
+      for (int t = Lf.recv_off[k]; t < Lf.recv_off[k + 1]; t++)
+        if (is_vertex(Lf.recv_nodes[t])) {
+          Lc.recv_nodes.push_back(h.par0[Lf.recv_nodes[t]]);
+          Lc.recv_layer.push_back(Lf.recv_layer[t]);
+        }
+      Lc.send_off[k + 1] = (int)Lc.send_nodes.size();
+      Lc.recv_off[k + 1] = (int)Lc.recv_nodes.size();
+    }
+    // owner weights and layer counts of the coarse nodes (coarse ids ascend with the fine ids of their vertices, so the
+    // coarse numbering is ordered by layer as well -- checked)
+    std::vector<double> wc3(nc);
+    std::vector<int> lay_c((size_t)m.Nc);
+    for (int I = 0; I < m.Nc; I++) {
+      const int nf = h.child[h.child_off[I]];  // the vertex itself is its first child
+      lay_c[I] = hl.layer[nf];
+      wc3[3 * (size_t)I] = wc3[3 * (size_t)I + 1] = wc3[3 * (size_t)I + 2] = lay_c[I] == 0 ? 1.0 : 0.0;
+      if (I > 0 && lay_c[I] < lay_c[I - 1]) return fail("p-multigrid: coarse numbering is not ordered by ghost layer");
+    }
+    hl.n_upto_c.assign(hl.depth + 1, 0);
+    for (int k = 0; k <= hl.depth; k++) hl.n_upto_c[k] = (int)(std::upper_bound(lay_c.begin(), lay_c.end(), k) - lay_c.begin());
+    TRY(upload_vec(&m.d_wc3, wc3));
+    double cnt = hl.n_upto_c[0];
+    HIP_TRY(hipMemcpy(hl.d_red, &cnt, sizeof(double), hipMemcpyHostToDevice));
+    TRY(call_allreduce(s, hl.d_red, 1));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    HIP_TRY(hipMemcpy(&cnt, hl.d_red, sizeof(double), hipMemcpyDeviceToHost));
+    m.Nc_glob = (int)std::lround(cnt);
+    if (s->verbose)
+      std::printf("p-multigrid: overlapped coarse level, %d owned of %d local vertices (%d over all ranks)\n", hl.n_upto_c[0],
+                  m.Nc, m.Nc_glob);
+  }
   if (pmg_levels_wanted(m.Nc) == 3) {
     // reference coordinates of the vertex nodes (slot 0 of a coarse node's children is the vertex itself)
     std::vector<double> xf((size_t)3 * d->N), Xv((size_t)3 * m.Nc);
@@ -2187,6 +2667,9 @@ static int pmg_build_level(tlfea_newton_t s) {
   launch_extract_diag(s->stream, m.Nc, ic, m.d_Hc, m.d_Dc);
   // multi-GPU: Hc = sum over ranks of P^T H_r P -- the diagonal blocks of boundary vertices are partial per rank
   if (s->ar) TRY(iface_sum_lvl(s, m.n_ifc_loc, m.n_ifc_glob, m.d_ifc_node, m.d_ifc_slot, m.d_Dc, 9));
+  // overlapping partition: rows of the outermost ghost layer are incomplete -- their diagonal blocks (hence the scaling of
+  // their COLUMNS in every complete row) come from their owners
+  TRY(halo_refresh_f64(s, 1, s->halo.depth, 9, m.d_Dc));
   launch_invert_diag(s->stream, m.Nc, m.d_Dc, m.d_Dinv_c);
   launch_lp_scale(s->stream, m.Nc, m.d_Dc, m.d_Dinv_c, m.d_sc_c, m.d_Dinv_s_c);
   launch_lp_convert(s->stream, m.Nc, ic, m.d_Hc, m.d_sc_c, nullptr, m.d_Dc, m.d_B8c, m.d_B1c, bits);
@@ -2228,29 +2711,37 @@ static int pmg_coefficients(tlfea_newton_t s) {
   }
   // multi-GPU: norms weigh replicated DOFs by 1/multiplicity and are summed over ranks, boundary rows of Hc v are
   // summed like the fine level's -- every rank ends with the same estimate, hence the same polynomial
-  TRY(device_sumsq_async(s, m.d_eigv_c, s->ar ? m.d_wc3 : nullptr, nc));
-  launch_scale_inv_sqrt(s->stream, nc, s->d_scal, m.d_eigv_c);
+  const int Ncr = s->halo.on ? s->halo.rows_c(0) : Nc, ncr = 3 * Ncr;  // overlapping partition: owned rows, layer-1 refresh
+  TRY(device_sumsq_async(s, m.d_eigv_c, dist_on(s) ? m.d_wc3 : nullptr, ncr));
+  launch_scale_inv_sqrt(s->stream, ncr, s->d_scal, m.d_eigv_c);
   for (int k = 0; k < (cold ? 16 : 2); k++) {
-    launch_spmv_dir_dot(s->stream, Nc, ic, m.d_Hc, m.d_eigv_c, m.d_eigv_c, 1, part(s, 1), part(s, 0), m.d_p_c, m.d_q_c,
+    TRY(halo_refresh_f64(s, 1, 1, 3, m.d_eigv_c));
+    launch_spmv_dir_dot(s->stream, Ncr, ic, m.d_Hc, m.d_eigv_c, m.d_eigv_c, 1, part(s, 1), part(s, 0), m.d_p_c, m.d_q_c,
                         part(s, 2), false, false);
     if (s->ar) TRY(iface_sum_lvl(s, m.n_ifc_loc, m.n_ifc_glob, m.d_ifc_node, m.d_ifc_slot, m.d_q_c, 3));
-    launch_apply_dinv(s->stream, Nc, m.d_Dinv_c, m.d_q_c, m.d_eigv_c);
-    TRY(device_sumsq_async(s, m.d_eigv_c, s->ar ? m.d_wc3 : nullptr, nc));
-    launch_scale_inv_sqrt(s->stream, nc, s->d_scal, m.d_eigv_c);
+    launch_apply_dinv(s->stream, Ncr, m.d_Dinv_c, m.d_q_c, m.d_eigv_c);
+    TRY(device_sumsq_async(s, m.d_eigv_c, dist_on(s) ? m.d_wc3 : nullptr, ncr));
+    launch_scale_inv_sqrt(s->stream, ncr, s->d_scal, m.d_eigv_c);
   }
   double ss = 0.0;
   TRY(fetch_scalar(s, s->d_scal, &ss));
   if (!(ss > 0.0)) return fail("p-multigrid: coarse lambda_max estimate failed");
   m.lam_c = std::sqrt(ss);
   double* h = s->h_pin + 8;
+  const int ks = pmg_ks(s);
   {
     const double b = s->lam_safety * s->lam_max, a = b / kPmgKappaS;
     const double theta = 0.5 * (b + a), delta = 0.5 * (b - a), sigma = theta / delta;
-    const double rho0 = 1.0 / sigma, rho1 = 1.0 / (2.0 * sigma - rho0);
+    double rho = 1.0 / sigma;
     h[0] = 1.0 / theta; h[1] = 0.0;
-    h[2] = rho1 * rho0; h[3] = 2.0 * rho1 / delta;
-    h[4] = 0.0; h[5] = 0.0;
-    h[6] = 0.0; h[7] = 1.0 / theta;
+    for (int k = 1; k < ks; k++) {
+      const double rho_new = 1.0 / (2.0 * sigma - rho);
+      h[2 * k] = rho_new * rho;
+      h[2 * k + 1] = 2.0 * rho_new / delta;
+      rho = rho_new;
+    }
+    h[2 * ks] = 0.0; h[2 * ks + 1] = 0.0;
+    h[2 * ks + 2] = 0.0; h[2 * ks + 3] = 1.0 / theta;
   }
   if (m.agg.ok) {
     // three levels: the vertex level smooths like the fine one (d_coef[8..15], same four pairs), the polynomial
@@ -2296,20 +2787,20 @@ static int pmg_coefficients(tlfea_newton_t s) {
     HIP_TRY(hipMemcpyAsync(m.d_coef, h, (size_t)(16 + 2 * k3) * sizeof(double), hipMemcpyHostToDevice, s->stream));
     return 0;
   }
-  const int kc = pmg_coarse_degree_eff(s);
+  const int kc = pmg_coarse_degree_eff(s), oc = pmg_cf_coarse(s);
   {
     const double b = s->lam_safety * m.lam_c, a = b / pmg_kappa_coarse(kc);
     const double theta = 0.5 * (b + a), delta = 0.5 * (b - a), sigma = theta / delta;
     double rho = 1.0 / sigma;
-    h[8] = 1.0 / theta; h[9] = 0.0;
+    h[oc] = 1.0 / theta; h[oc + 1] = 0.0;
     for (int k = 1; k < kc; k++) {
       const double rho_new = 1.0 / (2.0 * sigma - rho);
-      h[8 + 2 * k] = rho_new * rho;
-      h[8 + 2 * k + 1] = 2.0 * rho_new / delta;
+      h[oc + 2 * k] = rho_new * rho;
+      h[oc + 2 * k + 1] = 2.0 * rho_new / delta;
       rho = rho_new;
     }
   }
-  HIP_TRY(hipMemcpyAsync(m.d_coef, h, (size_t)(8 + 2 * kc) * sizeof(double), hipMemcpyHostToDevice, s->stream));
+  HIP_TRY(hipMemcpyAsync(m.d_coef, h, (size_t)(oc + 2 * kc) * sizeof(double), hipMemcpyHostToDevice, s->stream));
   return 0;
 }
 
@@ -2352,38 +2843,59 @@ static int pmg_apply(tlfea_newton_t s, const double* d_r, double* d_z, double* r
                     rout, d_r, d_z, rz_part, false, C32Bnd{m.d_bslot_c, s->d_ibuf, nullptr});
       return 0;
     };
+    const int ks = pmg_ks(s), o_res = pmg_cf_resid(s), o_rst = pmg_cf_restart(s), o_c = pmg_cf_coarse(s);
+    auto fine = [&](const double* co, bool last) -> int {  // one fine pass; the ping-pong partners swap roles
+      TRY(fine_step(f_d, co, f_d2, f_z, f_z2, f_r, f_r2, last));
+      std::swap(f_d, f_d2);
+      std::swap(f_z, f_z2);
+      std::swap(f_r, f_r2);
+      return 0;
+    };
     launch_cheb32_init(s->stream, N, Dinv_f, d_r, s->d_sc, cf, f_d, f_z, f_r);
-    TRY(fine_step(f_d, cf + 2, f_d2, f_z, f_z2, f_r, f_r2, false));
-    TRY(fine_step(f_d2, cf + 4, f_d, f_z2, f_z, f_r2, f_r, false));
+    for (int k = 1; k < ks; k++) TRY(fine(cf + 2 * k, false));
+    TRY(fine(cf + o_res, false));
     {
       const int nb = 3 * m.n_ifc_glob;
       if (nb) HIP_TRY(hipMemsetAsync(s->d_ibuf, 0, (size_t)nb * sizeof(double), s->stream));
       launch_pmg_restrict_rows(s->stream, m.n_ifc_loc, m.d_ifc_node, m.d_ifc_slot, m.d_child_off, m.d_child,
                                m.d_child_w_dist, f_r, s->d_sc, s->d_ibuf);
       if (nb) TRY(call_allreduce(s, s->d_ibuf, nb));
-      launch_pmg_restrict_init(s->stream, Nc, m.d_child_off, m.d_child, m.d_child_w, f_r, s->d_sc, m.d_sc_c, Dinv_fc, cf + 8,
+      launch_pmg_restrict_init(s->stream, Nc, m.d_child_off, m.d_child, m.d_child_w, f_r, s->d_sc, m.d_sc_c, Dinv_fc, cf + o_c,
                                c_d, c_z, c_r, m.d_bslot_c, s->d_ibuf);
     }
     const int kc = pmg_coarse_degree_eff(s);
     for (int k = 1; k < kc; k++) {
-      TRY(coarse_step(c_d, cf + 8 + 2 * k, c_d2, c_z, c_z2, c_r, c_r2));
+      TRY(coarse_step(c_d, cf + o_c + 2 * k, c_d2, c_z, c_z2, c_r, c_r2));
       std::swap(c_d, c_d2);
       std::swap(c_z, c_z2);
       std::swap(c_r, c_r2);
     }
     launch_pmg_prolong(s->stream, N, m.d_par0, m.d_par1, c_z, m.d_sc_c, s->d_sc, f_z, f_d);
-    TRY(fine_step(f_d, cf + 6, f_d2, f_z, f_z2, f_r, f_r2, false));
-    TRY(fine_step(f_d2, cf + 2, f_d, f_z2, f_z, f_r2, f_r, true));
+    TRY(fine(cf + o_rst, ks == 1));
+    for (int k = 1; k < ks; k++) TRY(fine(cf + 2 * k, k == ks - 1));
     return 0;
   }
-  // pre-smooth: d0 = (SDS)^-1 r^/theta ; one Chebyshev step ; residual of the result
-  if (!init_done) launch_cheb32_init(s->stream, N, Dinv_f, d_r, s->d_sc, cf, f_d, f_z, f_r);
-  launch_cheb32(s->stream, N, d->nnz_coef, inc_f, s->d_B8, s->d_B1, bits, Dinv_f, s->d_sc, f_d, cf + 2, f_d2, f_z, f_z2, f_r,
-                f_r2, d_r, d_z, rz_part, false);
-  launch_cheb32(s->stream, N, d->nnz_coef, inc_f, s->d_B8, s->d_B1, bits, Dinv_f, s->d_sc, f_d2, cf + 4, f_d, f_z2, f_z, f_r2,
-                f_r, d_r, d_z, rz_part, false);  // coefficients (0,0): res -= Hs d only; z^, res^ are back in f_z, f_r
+  // pre-smooth: d0 = (SDS)^-1 r^/theta ; ks - 1 Chebyshev steps ; residual of the result (coefficients (0,0): res -= Hs d)
+  const int ks = pmg_ks(s), o_res = pmg_cf_resid(s), o_rst = pmg_cf_restart(s), o_c = pmg_cf_coarse(s);
+  // Overlapping partition: r comes in exact on layers <= halo_dr(); every fine pass gives up one layer (the restriction
+  // needs layer 1 after the ks pre-smoothing passes, the post-smoother's pointwise operands layer ks - 1), so the fine
+  // launches stop at that row count -- deeper ghosts are never computed, they would only accumulate garbage -- and the
+  // r.z slots weigh owned DOFs only.
+  const bool hal = s->halo.on;
+  const int Nf = hal ? s->halo.rows(halo_dr(s)) : N;
+  const C32Bnd bnd = hal ? C32Bnd{nullptr, nullptr, s->d_w} : C32Bnd();
+  auto fine = [&](const double* co, bool last) {  // one fine pass; the ping-pong partners swap roles
+    launch_cheb32(s->stream, Nf, d->nnz_coef, inc_f, s->d_B8, s->d_B1, bits, Dinv_f, s->d_sc, f_d, co, f_d2, f_z, f_z2, f_r, f_r2,
+                  d_r, d_z, rz_part, last, bnd);
+    std::swap(f_d, f_d2);
+    std::swap(f_z, f_z2);
+    std::swap(f_r, f_r2);
+  };
+  if (!init_done) launch_cheb32_init(s->stream, Nf, Dinv_f, d_r, s->d_sc, cf, f_d, f_z, f_r);
+  for (int k = 1; k < ks; k++) fine(cf + 2 * k, false);
+  fine(cf + o_res, false);
   // coarse correction
-  launch_pmg_restrict_init(s->stream, Nc, m.d_child_off, m.d_child, m.d_child_w, f_r, s->d_sc, m.d_sc_c, Dinv_fc, cf + 8,
+  launch_pmg_restrict_init(s->stream, Nc, m.d_child_off, m.d_child, m.d_child_w, f_r, s->d_sc, m.d_sc_c, Dinv_fc, cf + o_c,
                            c_d, c_z, c_r);
   if (m.agg.ok) {
     // vertex level as a smoothing level: the fine level's sequence once more, with the level-3 polynomial inside
@@ -2413,28 +2925,46 @@ static int pmg_apply(tlfea_newton_t s, const double* d_r, double* d_z, double* r
 #undef TLFEA_L2
   } else {
     const int kc = pmg_coarse_degree_eff(s);
+    // Overlapping partition: the restricted residual is exact on the owned vertices only.  A refresh makes the three
+    // vectors exact on every ghost layer (G of them); a step gives up one layer, and the prolongation needs ks + 1 layers
+    // at the end (ks fine passes follow) -- so one exchange buys up to G steps, computed redundantly on the overlap.
+    const int G = s->halo.depth, need_end = ks + 1;
+    int valid = 0;
     for (int k = 1; k < kc; k++) {
-      launch_cheb32(s->stream, Nc, m.nnz_c, inc_c, m.d_B8c, m.d_B1c, bits, Dinv_fc, m.d_sc_c, c_d, cf + 8 + 2 * k, c_d2, c_z,
+      if (hal && valid < 1) {
+        TRY(halo_refresh_f32(s, 1, G, 3, c_d, c_z, c_r));
+        valid = G;
+      }
+      launch_cheb32(s->stream, Nc, m.nnz_c, inc_c, m.d_B8c, m.d_B1c, bits, Dinv_fc, m.d_sc_c, c_d, cf + o_c + 2 * k, c_d2, c_z,
                     c_z2, c_r, c_r2, d_r, d_z, rz_part, false);
+      valid--;
       std::swap(c_d, c_d2);
       std::swap(c_z, c_z2);
       std::swap(c_r, c_r2);
     }
+    if (hal && valid < need_end) TRY(halo_refresh_f32(s, 1, need_end, 3, c_z));  // the last chunk ended too shallow
   }
-  launch_pmg_prolong(s->stream, N, m.d_par0, m.d_par1, c_z, m.d_sc_c, s->d_sc, f_z, f_d);  // z^ += corr ; d := corr
-  // post-smooth: res^ -= Hs corr ; d0' = (SDS)^-1 res^/theta ; z^ += d0'   == one step with coefficients (0, 1/theta)
-  launch_cheb32(s->stream, N, d->nnz_coef, inc_f, s->d_B8, s->d_B1, bits, Dinv_f, s->d_sc, f_d, cf + 6, f_d2, f_z, f_z2, f_r,
-                f_r2, d_r, d_z, rz_part, false);
-  // ... and the Chebyshev step that completes the 2-term polynomial; returns z = S z^ (fp64) and the r.z slots
-  launch_cheb32(s->stream, N, d->nnz_coef, inc_f, s->d_B8, s->d_B1, bits, Dinv_f, s->d_sc, f_d2, cf + 2, f_d, f_z2, f_z, f_r2,
-                f_r, d_r, d_z, rz_part, true);
+  launch_pmg_prolong(s->stream, Nf, m.d_par0, m.d_par1, c_z, m.d_sc_c, s->d_sc, f_z, f_d);  // z^ += corr ; d := corr
+  // post-smooth: res^ -= Hs corr ; d0' = (SDS)^-1 res^/theta ; z^ += d0'   == one step with coefficients (0, 1/theta),
+  // then the ks - 1 Chebyshev steps that complete the polynomial; the last pass returns z = S z^ (fp64) and the r.z slots
+  fine(cf + o_rst, ks == 1);
+  for (int k = 1; k < ks; k++) fine(cf + 2 * k, k == ks - 1);
   return 0;
 }
 
 // Enqueue CG iteration `it` (parity cur = it & 1 selects the r.z slot pair and, in the fused variant, which of the
 // two direction buffers is read).  Everything an iteration needs from the previous one (alpha, beta, Chebyshev
 // coefficients) is read from device memory, so iterations >= 1 of either parity are the SAME launch sequence.
-static int enqueue_cg_iteration(tlfea_newton_t s, double* d_x, bool first, int cur, bool fused, int deg) {
+static int enqueue_residual_replacement(tlfea_newton_t s, double* d_x);
+static int enqueue_cg_iteration_impl(tlfea_newton_t s, double* d_x, bool first, int cur, bool fused, int deg, bool replace);
+static int enqueue_cg_iteration(tlfea_newton_t s, double* d_x, bool first, int cur, bool fused, int deg,
+                                bool replace = false) {
+  s->halo.in_cg = true;
+  const int rc = enqueue_cg_iteration_impl(s, d_x, first, cur, fused, deg, replace);
+  s->halo.in_cg = false;
+  return rc;
+}
+static int enqueue_cg_iteration_impl(tlfea_newton_t s, double* d_x, bool first, int cur, bool fused, int deg, bool replace) {
   tlfea_t10_t d = s->d;
   const int N = s->N;
   const double* w = s->d_w;
@@ -2443,23 +2973,40 @@ static int enqueue_cg_iteration(tlfea_newton_t s, double* d_x, bool first, int c
   if (fused && cur) std::swap(p_old, p_new);
   // single-GPU fp32 polynomial: its start vectors come out of the previous iteration's update kernel
   const bool fuse_init = deg > 1 && cheb_bits_eff(s) != 64 && !s->ar;
+  // Overlapping partition: the residual is kept exact on ghost layers <= Dr, the direction is refreshed on layers <= Dr + 1
+  // (one neighbour exchange per iteration on this level), launches stop at the rows they can still compute exactly,
+  // dot products weigh owned DOFs (wown) and are summed over ranks: r.z after the preconditioner, p.q after the SpMV; the
+  // r.r slots are summed only when the host tests convergence (pcg()).
+  const bool hal = s->halo.on;
+  const int Dr = hal ? halo_dr(s) : 0;
+  const int Nr = hal ? s->halo.rows(Dr) : N, Np = hal ? s->halo.rows(Dr + 1) : N;
+  const double* wown = hal ? s->d_w : nullptr;
   if (deg > 1) {
     // polynomial preconditioner: z = Cheb(r), r.z slots -> part(cur)   (deg-1 SpMV launches, no reductions)
     if (precond_eff(s) == 2)
       TRY(pmg_apply(s, s->d_r, s->d_zv, part(s, cur), fuse_init && !first));
     else
       TRY(cheb_apply(s, s->d_r, s->d_zv, part(s, cur), fuse_init && !first));
-    if (s->ar && !(s->d_own && cheb_bits_eff(s) != 64)) TRY(parts_sum(s, part(s, cur)));
+    if ((s->ar && !(s->d_own && cheb_bits_eff(s) != 64)) || hal) TRY(parts_sum(s, part(s, cur)));
+    if (hal) TRY(halo_refresh_f64(s, 0, Dr + 1, 3, s->d_zv));
   }
   if (s->profiling) (void)hipEventRecord(s->ev[4], s->stream);
   // beta = rz(cur)/rz(1-cur); p = z + beta p; q = H p; partials of p.q
   if (fused) {
-    launch_spmv_dir_dot(s->stream, N, d->inc(), s->d_H, s->d_zv, p_old, first, part(s, 1 - cur), part(s, cur), p_new,
-                        s->d_q, pq_part, true, s->spmv_nt);
+    if (s->spmv32_now)
+      launch_spmv_dir_dot_f32(s->stream, N, d->inc(), s->d_H32, s->d_zv, p_old, first, part(s, 1 - cur), part(s, cur), p_new,
+                              s->d_q, pq_part, true);
+    else
+      launch_spmv_dir_dot(s->stream, N, d->inc(), s->d_H, s->d_zv, p_old, first, part(s, 1 - cur), part(s, cur), p_new,
+                          s->d_q, pq_part, true, s->spmv_nt);
   } else {
-    launch_pcg_direction(s->stream, 3 * N, s->d_zv, first, part(s, 1 - cur), part(s, cur), p_old);
-    launch_spmv_dir_dot(s->stream, N, d->inc(), s->d_H, s->d_zv, p_old, first, part(s, 1 - cur), part(s, cur), p_old,
-                        s->d_q, pq_part, false, s->spmv_nt);
+    launch_pcg_direction(s->stream, 3 * Np, s->d_zv, first, part(s, 1 - cur), part(s, cur), p_old);
+    if (s->spmv32_now)
+      launch_spmv_dir_dot_f32(s->stream, Nr, d->inc(), s->d_H32, s->d_zv, p_old, first, part(s, 1 - cur), part(s, cur), p_old,
+                              s->d_q, pq_part, false, wown);
+    else
+      launch_spmv_dir_dot(s->stream, Nr, d->inc(), s->d_H, s->d_zv, p_old, first, part(s, 1 - cur), part(s, cur), p_old,
+                          s->d_q, pq_part, false, s->spmv_nt, wown);
   }
   if (s->profiling) {
     (void)hipEventRecord(s->ev[5], s->stream);
@@ -2470,25 +3017,48 @@ static int enqueue_cg_iteration(tlfea_newton_t s, double* d_x, bool first, int c
     s->stage_n[6] += deg;  // SpMV launches of this iteration (Chebyshev steps included)
   }
   if (s->ar) TRY(iface_sum(s, s->d_q, 3, pq_part, kNPart));  // boundary rows of q + p.q slots, one collective
+  if (hal) TRY(parts_sum(s, pq_part));
   if (deg > 1) {
     // alpha = rz(cur)/pq; x += alpha p; r -= alpha q; r.r slots
     if (fuse_init) {
       const size_t n = 3 * (size_t)N;
       float* f = s->d_f32;  // d, z^, res^ start buffers of cheb_apply and (SDS)^-1
-      launch_pcg_update_init32(s->stream, N, fused ? p_new : p_old, s->d_q, part(s, cur), pq_part, d_x, s->d_r,
+      launch_pcg_update_init32(s->stream, Nr, fused ? p_new : p_old, s->d_q, part(s, cur), pq_part, d_x, s->d_r,
                                part(s, 3), s->d_scal + 3, f + 6 * n, s->d_sc,
-                               precond_eff(s) == 2 ? s->pmg.d_coef : s->d_coef, f, f + 2 * n, f + 4 * n);
+                               precond_eff(s) == 2 ? s->pmg.d_coef : s->d_coef, f, f + 2 * n, f + 4 * n, wown);
     } else {
       launch_pcg_update_noz(s->stream, N, w, fused ? p_new : p_old, s->d_q, part(s, cur), pq_part, d_x, s->d_r,
                             part(s, 3), s->d_scal + 3);
     }
     if (s->ar) TRY(parts_sum(s, part(s, 3)));
+    if (replace) TRY(enqueue_residual_replacement(s, d_x));
   } else {
     // ... and z = Dinv r with the new r.z slots into part(1-cur)
     launch_pcg_update(s->stream, N, s->d_Dinv, w, fused ? p_new : p_old, s->d_q, part(s, cur), pq_part, d_x, s->d_r,
                       s->d_zv, part(s, 1 - cur), part(s, 3));
     if (s->ar) TRY(parts_sum(s, part(s, 1 - cur), part(s, 3)));  // r.z and r.r slots, one collective
   }
+  if (hal) s->halo.n_cg_iters++;
+  return 0;
+}
+
+// r = b - H x in fp64 on H itself, the r.r slots of the TRUE residual and the next polynomial's start vectors (mixed-
+// precision iteration only: s->spmv32_now).  q is free between the update and the next iteration's SpMV.
+static int enqueue_residual_replacement(tlfea_newton_t s, double* d_x) {
+  tlfea_t10_t d = s->d;
+  const int N = s->N;
+  const size_t n = 3 * (size_t)N;
+  // un-fused form: reads x only; its p.q slots go to the scratch slot array of the norms
+  // overlapping partition: x is updated on layers <= Dr like r; one more layer comes from its owners, so H x is exact on
+  // layers <= Dr again
+  const int Nr = s->halo.on ? s->halo.rows(halo_dr(s)) : N;
+  if (s->halo.on) TRY(halo_refresh_f64(s, 0, halo_dr(s) + 1, 3, d_x));
+  launch_spmv_dir_dot(s->stream, Nr, d->inc(), s->d_H, d_x, d_x, 1, part(s, 0), part(s, 1), s->d_cd, s->d_q, part(s, 5), false,
+                      s->spmv_nt);
+  float* f = s->d_f32;
+  launch_residual_replace_init32(s->stream, Nr, s->cur_b, s->d_q, s->d_r, part(s, 3), f + 6 * n, s->d_sc,
+                                 precond_eff(s) == 2 ? s->pmg.d_coef : s->d_coef, f, f + 2 * n, f + 4 * n,
+                                 s->halo.on ? s->d_w : nullptr);
   return 0;
 }
 
@@ -2500,23 +3070,34 @@ static void cg_graphs_destroy(tlfea_newton_t s) {
     }
 }
 
-// The two launch sequences (even / odd iteration) captured once as hipGraphs and replayed: one host call per CG
-// iteration instead of deg+2 launches.  On small meshes the kernels last 5-10 us and the launch rate of the host
-// is what an iteration costs otherwise.  Single-GPU path only (the multi-GPU path calls back into the host
-// between kernels).
+// The launch sequences (even / odd iteration, odd iteration followed by a residual replacement) captured once as
+// hipGraphs and replayed: one host call per CG iteration instead of deg+2 launches.  On small meshes the kernels last
+// 5-10 us and the launch rate of the host is what an iteration costs otherwise.  Single-GPU path only (the multi-GPU
+// path calls back into the host between kernels).
 static int cg_graphs_prepare(tlfea_newton_t s, double* d_x, bool fused, int deg, int bits) {
-  const long key[6] = {deg + 1000 * precond_eff(s) + 100000L * (s->pmg.ok ? pmg_coarse_degree_eff(s) : 0), bits, fused ? 1 : 0, (long)(size_t)d_x, (long)(size_t)s->d_B8,
-                       (long)(size_t)s->pmg.d_B8c};
+  const long key[6] = {deg + 1000 * precond_eff(s) + 100000L * (s->pmg.ok ? pmg_coarse_degree_eff(s) : 0),
+                       bits + (s->spmv32_now ? 100000L : 0), (fused ? 1 : 0) + 2 * (long)(size_t)s->cur_b, (long)(size_t)d_x,
+                       (long)(size_t)s->d_B8, (long)(size_t)s->pmg.d_B8c};
   if (s->cg_graph[0] && std::equal(key, key + 6, s->cg_graph_key)) return 0;
   cg_graphs_destroy(s);
-  for (int cur = 0; cur < 2; cur++) {
+  for (int k = 0; k < (s->spmv32_now ? 3 : 2); k++) {
     hipGraph_t g = nullptr;
+    auto& hh = s->halo;
+    const double c0[5] = {(double)hh.n_exch, (double)hh.n_allred, hh.bytes_exch, hh.bytes_allred, (double)hh.n_cg_iters};
     HIP_TRY(hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
-    const int rc = enqueue_cg_iteration(s, d_x, false, cur, fused, deg);
+    const int rc = enqueue_cg_iteration(s, d_x, false, k & 1 ? 1 : (k == 2 ? 1 : 0), fused, deg, k == 2);
     const hipError_t e = hipStreamEndCapture(s->stream, &g);
+    {  // nothing ran: the counters go back, the cost of one replay is kept
+      const double c1[5] = {(double)hh.n_exch, (double)hh.n_allred, hh.bytes_exch, hh.bytes_allred, (double)hh.n_cg_iters};
+      for (int t = 0; t < 5; t++) hh.graph_cost[k][t] = c1[t] - c0[t];
+      hh.n_exch_cg -= (long)(c1[0] - c0[0]);
+      hh.n_allred_cg -= (long)(c1[1] - c0[1]);
+      hh.n_exch = (long)c0[0]; hh.n_allred = (long)c0[1]; hh.bytes_exch = c0[2]; hh.bytes_allred = c0[3]; hh.n_cg_iters = (long)c0[4];
+      s->n_collectives -= (long)(c1[1] - c0[1]);
+    }
     if (rc) return rc;
     HIP_TRY(e);
-    HIP_TRY(hipGraphInstantiate(&s->cg_graph[cur], g, nullptr, nullptr, 0));
+    HIP_TRY(hipGraphInstantiate(&s->cg_graph[k], g, nullptr, nullptr, 0));
     (void)hipGraphDestroy(g);
   }
   std::copy(key, key + 6, s->cg_graph_key);
@@ -2593,7 +3174,7 @@ static int direct_prepare(tlfea_newton_t s) {
   if (m.tried) return m.ok ? 0 : fail("sparse direct solve is not available (see the earlier message)");
   m.tried = true;
   tlfea_t10_t d = s->d;
-  if (s->ar) return fail("sparse direct solve: single-GPU path only");
+  if (dist_on(s)) return fail("sparse direct solve: single-GPU path only");
   DTRACE("resolving rocsolver");
   RocsolverApi& a = rocsolver_api();
   DTRACE("resolved");
@@ -2702,10 +3283,21 @@ static int pcg(tlfea_newton_t s, const double* d_b, double* d_x, int* iters_out,
   StageTimer t(s, 4);
   const double* w = s->d_w;
   const bool lp = cheb_bits_eff(s) != 64;
+  if (s->halo.on) {
+    if (!lp || cheb_degree_eff(s) <= 1)
+      return fail("overlapping partition: needs the polynomial / p-multigrid preconditioner on the scaled low-precision copy "
+                  "(cheb_degree > 1, cheb_bits 16 or 32)");
+    if (halo_dr(s) + 1 > s->halo.depth)
+      return fail("overlapping partition: halo depth " + std::to_string(s->halo.depth) + " is below the " +
+                  std::to_string(halo_dr(s) + 1) + " layers the fine level needs");
+  }
   if (s->ar || lp) {
     // diagonal blocks of partition-boundary nodes are partial per rank: sum them before inverting
     launch_extract_diag(s->stream, N, d->inc(), s->d_H, s->d_D);
     TRY(iface_sum(s, s->d_D, 9));
+    // overlapping partition: the outermost ghost layer's rows are incomplete -- its diagonal blocks (the scaling of its
+    // columns in every complete row) come from their owners
+    TRY(halo_refresh_f64(s, 0, s->halo.depth, 9, s->d_D));
     launch_invert_diag(s->stream, N, s->d_D, s->d_Dinv);
     if (lp) TRY(lp_build(s));
   } else {
@@ -2747,7 +3339,19 @@ static int pcg(tlfea_newton_t s, const double* d_b, double* d_x, int* iters_out,
         }
       }
     }
-    const bool graphs = s->use_graphs && !s->ar && !s->profiling;
+    // hipGraph replay: single GPU, and the overlapping partition when its exchange is the built-in RCCL one (enqueued
+    // from C++ on this stream, so the neighbour exchanges and all-reduces are captured with the kernels)
+    const bool graphs = s->use_graphs && !s->ar && !s->profiling && (!s->halo.on || s->halo.native);
+    // mixed-precision iteration: where the fp32 polynomial path runs (its update kernel writes the start vectors the
+    // replacement rewrites), on one GPU
+    s->cur_b = d_b;
+    s->spmv32_now = s->spmv32_every >= 2 && deg > 1 && lp && !s->ar;
+    if (s->spmv32_now) {
+      if (!s->d_H32) HIP_TRY(hipMalloc((void**)&s->d_H32, (size_t)9 * d->nnz_coef * sizeof(float)));
+      launch_to_float(s->stream, (size_t)9 * d->nnz_coef, s->d_H, s->d_H32);
+    }
+    const int R = s->spmv32_every;
+    bool r_is_true = !s->spmv32_now;  // the residual vector is b - H x of the fp64 system (not the recurrence's)
     if (graphs) TRY(cg_graphs_prepare(s, d_x, fused, deg, bits));
     double indefinite = 0.0;
     HIP_TRY(hipMemsetAsync(s->d_scal + 3, 0, sizeof(double), s->stream));
@@ -2759,14 +3363,38 @@ static int pcg(tlfea_newton_t s, const double* d_b, double* d_x, int* iters_out,
     for (int attempt = 0;; attempt++) {
       while (it < s->lin.max_iter) {
         // r.z slots of iteration `it` live in part(it & 1), the previous ones in the other pair
-        if (graphs && it > 0)
-          HIP_TRY(hipGraphLaunch(s->cg_graph[it & 1], s->stream));
-        else
-          TRY(enqueue_cg_iteration(s, d_x, it == 0, it & 1, fused, deg));
+        const bool replace = s->spmv32_now && it > 0 && (it + 1) % R == 0;  // R is even: always an odd iteration
+        if (graphs && it > 0) {
+          const int gk = replace ? 2 : (it & 1);
+          HIP_TRY(hipGraphLaunch(s->cg_graph[gk], s->stream));
+          if (s->halo.on) {
+            auto& hh = s->halo;
+            const double* c = hh.graph_cost[gk];
+            hh.n_exch += (long)c[0]; hh.n_exch_cg += (long)c[0];
+            hh.n_allred += (long)c[1]; hh.n_allred_cg += (long)c[1];
+            hh.bytes_exch += c[2]; hh.bytes_allred += c[3]; hh.n_cg_iters += (long)c[4];
+            s->n_collectives += (long)c[1];
+          }
+        } else
+          TRY(enqueue_cg_iteration(s, d_x, it == 0, it & 1, fused, deg, replace));
+        if (s->spmv32_now) {
+          r_is_true = replace;
+          s->n_replacements += replace ? 1 : 0;
+        }
         it++;
         if ((it >= first_check && (it - first_check) % check_every == 0) || it == s->lin.max_iter || it == stall_check) {
+          if (s->halo.on) TRY(parts_sum(s, part(s, 3)));  // the r.r slots are summed over ranks only when tested
           launch_sum_parts(s->stream, part(s, 3), s->d_scal + 2);
           TRY(fetch_scalar2(s, s->d_scal + 2, &rr, &indefinite));  // ||r||^2 and the r.z < 0 flag
+          if (!(rr > target) && rr == rr && !r_is_true) {
+            // the recurrence says converged: the verdict is the fp64 system's -- replace the residual and test that
+            TRY(enqueue_residual_replacement(s, d_x));
+            s->n_replacements++;
+            r_is_true = true;
+            if (s->halo.on) TRY(parts_sum(s, part(s, 3)));
+            launch_sum_parts(s->stream, part(s, 3), s->d_scal + 2);
+            TRY(fetch_scalar2(s, s->d_scal + 2, &rr, &indefinite));
+          }
           if (!(rr > target)) break;                       // also leaves on NaN
           if (rr > 1e8 * bb || indefinite != 0.0) break;   // the preconditioner is not positive definite
           if (it >= stall_check && stall_check > 0) {      // p-multigrid far beyond its usual 30-45 iterations
@@ -2805,6 +3433,7 @@ static int pcg(tlfea_newton_t s, const double* d_b, double* d_x, int* iters_out,
       indefinite = 0.0;
       it = 0;
       rr = bb;
+      r_is_true = !s->spmv32_now;
       first_check = std::max(1, s->lin.check_every / deg);
       check_every = first_check;
     }
@@ -2985,7 +3614,7 @@ extern "C" int tlfea_newton_time_kernels(tlfea_newton_t s, int reps, double* out
         for (int c = 1; c < kc; c++) {
           const int a = c & 1, b = 1 - a;
           launch_cheb32(s->stream, m.Nc, m.nnz_c, m.inc(), m.d_B8c, m.d_B1c, bits, g + 6 * nc, m.d_sc_c, g + a * nc,
-                        m.d_coef + 10, g + b * nc, g + (2 + a) * nc, g + (2 + b) * nc, g + (4 + a) * nc, g + (4 + b) * nc,
+                        m.d_coef + pmg_cf_coarse(s) + 2, g + b * nc, g + (2 + a) * nc, g + (2 + b) * nc, g + (4 + a) * nc, g + (4 + b) * nc,
                         s->d_r, s->d_zv, part(s, 0), false);
         }
         fine(0);
@@ -2995,7 +3624,7 @@ extern "C" int tlfea_newton_time_kernels(tlfea_newton_t s, int reps, double* out
         float* f = m.d_f32c;
         const int a = r & 1, b = 1 - a;
         launch_cheb32(s->stream, m.Nc, m.nnz_c, m.inc(), m.d_B8c, m.d_B1c, cheb_bits_eff(s), f + 6 * nc, m.d_sc_c,
-                      f + a * nc, m.d_coef + 10, f + b * nc, f + (2 + a) * nc, f + (2 + b) * nc, f + (4 + a) * nc,
+                      f + a * nc, m.d_coef + pmg_cf_coarse(s) + 2, f + b * nc, f + (2 + a) * nc, f + (2 + b) * nc, f + (4 + a) * nc,
                       f + (4 + b) * nc, s->d_r, s->d_zv, part(s, 0), false);
       } else if (cheb_bits_eff(s) != 64 && s->d_B8 && !s->ar) {  // one step of the polynomial, buffers ping-pong as in
         const size_t n = 3 * (size_t)N;                          // cheb_apply (each step reads what the last one wrote)
@@ -3038,6 +3667,9 @@ extern "C" int tlfea_newton_apply_hessian(tlfea_newton_t s, const double* x, dou
 static int newton_update(tlfea_newton_t s) {
   tlfea_t10_t d = s->d;
   StageTimer t(s, 5);
+  // overlapping partition: the solve leaves dv exact on the owned nodes (and a few ghost layers); every ghost a rank
+  // holds moves with its owner's value
+  TRY(halo_refresh_f64(s, 0, s->halo.depth, 3, s->d_dv));
   launch_newton_update(s->stream, s->N, s->d_dv, s->d_v, s->d_xp, s->d_yp, s->d_zp, s->prm.time_step, d->d_x, d->d_y,
                        d->d_z);
   t.stop();
@@ -3184,6 +3816,19 @@ extern "C" int tlfea_newton_get_stats(tlfea_newton_t s, double* st) {
   return 0;
 }
 extern "C" long tlfea_newton_collectives(tlfea_newton_t s) { return s ? s->n_collectives : -1; }
+extern "C" int tlfea_newton_get_comm_stats(tlfea_newton_t s, double* out8) {
+  if (!s || !out8) return fail("null argument");
+  const auto& h = s->halo;
+  out8[0] = (double)h.n_exch;
+  out8[1] = h.on ? (double)h.n_allred : (double)s->n_collectives;
+  out8[2] = h.bytes_exch;
+  out8[3] = h.bytes_allred;
+  out8[4] = h.comm_ms;
+  out8[5] = (double)h.n_cg_iters;
+  out8[6] = (double)h.n_exch_cg;
+  out8[7] = (double)h.n_allred_cg;
+  return 0;
+}
 extern "C" int tlfea_newton_n_constraints(tlfea_newton_t s) { return s ? s->n_constraints : -1; }
 extern "C" int tlfea_newton_get_linsolve_status(tlfea_newton_t s, double* out4) {
   if (!s || !out4) return fail("null argument");
@@ -3288,7 +3933,7 @@ extern "C" int tlfea_adamw_solve(tlfea_adamw_t a) {
   tlfea_t10_t d = s->d;
   const tlfea_adamw_params& p = a->prm;
   if (!d->is_csr_setup) return fail("SyncedAdamWNocoop: CalcMassMatrix() must precede Solve() (the gradient uses the mass CSR)");
-  if (s->ar) return fail("SyncedAdamWNocoop: single-GPU path only");
+  if (dist_on(s)) return fail("SyncedAdamWNocoop: single-GPU path only");
   TRY(sync_constraints(s));
   const int N = s->N, n = 3 * N;
   const double dt = p.time_step;
@@ -3421,7 +4066,7 @@ extern "C" int tlfea_nesterov_solve(tlfea_nesterov_t a) {
   tlfea_t10_t d = s->d;
   const tlfea_nesterov_params& p = a->prm;
   if (!d->is_csr_setup) return fail("SyncedNesterov: CalcMassMatrix() must precede Solve() (the gradient uses the mass CSR)");
-  if (s->ar) return fail("SyncedNesterov: single-GPU path only");
+  if (dist_on(s)) return fail("SyncedNesterov: single-GPU path only");
   TRY(sync_constraints(s));
   if (d->cons_mode == 2) return fail("SyncedNesterov: fixed-coefficient constraints only (as the reference, :197-200)");
   const int N = s->N, n = 3 * N;
@@ -3672,7 +4317,7 @@ extern "C" int tlfea_vbd_solve(tlfea_vbd_t a) {
   tlfea_newton_t s = a->core;
   tlfea_t10_t d = s->d;
   const tlfea_vbd_params& p = a->prm;
-  if (s->ar) return fail("SyncedVBDSolver: single-GPU path only");
+  if (dist_on(s)) return fail("SyncedVBDSolver: single-GPU path only");
   TRY(sync_constraints(s));
   if (!a->mass_ready && !d->is_csr_setup) TRY(tlfea_vbd_initialize_mass_diag_blocks(a));
   TRY(tlfea_vbd_initialize_coloring(a));

@@ -166,7 +166,7 @@ void launch_pcg_init(hipStream_t s, int N, const double* b, const double* Dinv, 
                      double* r, double* z, double* rz_part, double* bb_part);
 void launch_spmv_dir_dot(hipStream_t s, int N, const Incidence& inc, const double* Hval, const double* z,
                          const double* p_old, int first, const double* rz_part_old, const double* rz_part_new,
-                         double* p_new, double* q, double* pq_part, bool fused, bool nt);
+                         double* p_new, double* q, double* pq_part, bool fused, bool nt, const double* wown = nullptr);
 void launch_pcg_direction(hipStream_t s, int n, const double* z, int first, const double* rz_part_old,
                           const double* rz_part_new, double* p);
 void launch_pcg_update(hipStream_t s, int N, const double* Dinv, const double* w, const double* p, const double* q,
@@ -187,6 +187,21 @@ void launch_lp_convert(hipStream_t s, int N, const Incidence& inc, const double*
                        const double* Dglob, void* B8, void* B1, int bits);
 void launch_mask_scale(hipStream_t s, int N, const double* sc, const int* own, double* out);
 // the polynomial in single precision (single-GPU path): fp32 vectors, fp16/fp32 matrix, fp32 accumulation
+void launch_spmv_dir_dot_f32(hipStream_t s, int N, const Incidence& inc, const float* Hval32, const double* z,
+                             const double* p_old, int first, const double* rz_part_old, const double* rz_part_new,
+                             double* p_new, double* q, double* pq_part, bool fused, const double* wown = nullptr);
+void launch_residual_replace_init32(hipStream_t s, int N, const double* b, const double* q, double* r, double* rr_part,
+                                    const float* Dinv_f, const double* sc, const double* coef, float* d, float* z,
+                                    float* res, const double* wown = nullptr);
+// overlapping partition: ghost refresh messages (nvec fields of dim values per node, interleaved per node)
+void launch_halo_pack_f64(hipStream_t s, int n, const int* idx, int dim, int nvec, const double* a, const double* b,
+                          const double* c, double* msg);
+void launch_halo_unpack_f64(hipStream_t s, int n, const int* idx, int dim, int nvec, const double* msg, double* a, double* b,
+                            double* c);
+void launch_halo_pack_f32(hipStream_t s, int n, const int* idx, int dim, int nvec, const float* a, const float* b,
+                          const float* c, float* msg);
+void launch_halo_unpack_f32(hipStream_t s, int n, const int* idx, int dim, int nvec, const float* msg, float* a, float* b,
+                            float* c);
 void launch_to_float(hipStream_t s, size_t n, const double* a, float* b);
 void launch_cheb32_init(hipStream_t s, int N, const float* Dinv_f, const double* r, const double* sc,
                         const double* coef, float* d, float* z, float* res);
@@ -235,7 +250,7 @@ void launch_cheb_lp(hipStream_t s, int N, int nnz_coef, const Incidence& inc, co
 void launch_pcg_update_init32(hipStream_t s, int N, const double* p, const double* q, const double* rz_part_old,
                               const double* pq_part, double* x, double* r, double* rr_part, double* indefinite,
                               const float* Dinv_f, const double* sc, const double* coef, float* d, float* z,
-                              float* res);
+                              float* res, const double* wown = nullptr);
 void launch_pcg_update_noz(hipStream_t s, int N, const double* w, const double* p, const double* q,
                            const double* rz_part_old, const double* pq_part, double* x, double* r, double* rr_part,
                            double* indefinite);

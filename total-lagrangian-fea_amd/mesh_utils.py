@@ -62,7 +62,13 @@ def structured_t10_box(nx, ny, nz, lx=1.0, ly=1.0, lz=1.0):
     Returns (nodes[N,3] float64, elements[E,10] int32); unused lattice points are dropped and nodes are
     numbered in lattice (z-major) order, so neighbouring nodes stay close in memory."""
     gx, gy, gz = 2 * nx + 1, 2 * ny + 1, 2 * nz + 1
-    ii, jj, kk = np.meshgrid(np.arange(nx), np.arange(ny), np.arange(nz), indexing="ij")
+    # cells in the same (z-major, x fastest) order as the nodes: consecutive elements then gather neighbouring nodes
+    # (measured at config C: the thread-per-element residual launch 557 -> 460 us against cells in x-major order)
+    import os
+    if os.environ.get("TLFEA_BOX_ELEMS") == "xmajor":   # the round-1/2 order, kept for A/B runs
+        ii, jj, kk = np.meshgrid(np.arange(nx), np.arange(ny), np.arange(nz), indexing="ij")
+    else:
+        kk, jj, ii = np.meshgrid(np.arange(nz), np.arange(ny), np.arange(nx), indexing="ij")
     base = np.stack([ii.ravel(), jj.ravel(), kk.ravel()], axis=1) * 2  # lattice coords of cell corner 0
     corners = np.asarray(_HEX_CORNERS) * 2
     tets = np.asarray(_HEX_TETS)
@@ -76,6 +82,15 @@ def structured_t10_box(nx, ny, nz, lx=1.0, ly=1.0, lz=1.0):
     v[flip, 1], v[flip, 2] = v[flip, 2].copy(), v[flip, 1].copy()
     mids = np.stack([(v[:, a] + v[:, b]) // 2 for a, b in EDGES], axis=1)
     lat = np.concatenate([v, mids], axis=1)  # [E,10,3]
+    if os.environ.get("TLFEA_BOX_ORDER") == "x":   # experiment: x slowest (planes of (2ny+1)(2nz+1) nodes)
+        gz = 2 * nz + 1
+        lin = (lat[..., 0] * gy + lat[..., 1]) * gz + lat[..., 2]
+        used, inv = np.unique(lin.ravel(), return_inverse=True)
+        elements = inv.reshape(-1, 10).astype(np.int32)
+        zs = (used % gz) * (lz / (2 * nz))
+        ys = ((used // gz) % gy) * (ly / (2 * ny))
+        xs = (used // (gz * gy)) * (lx / (2 * nx))
+        return np.stack([xs, ys, zs], axis=1).astype(np.float64), elements
     lin = (lat[..., 2] * gy + lat[..., 1]) * gx + lat[..., 0]
     used, inv = np.unique(lin.ravel(), return_inverse=True)
     elements = inv.reshape(-1, 10).astype(np.int32)

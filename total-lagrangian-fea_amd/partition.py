@@ -51,6 +51,29 @@ def slab_owner(X, conn, world, axis=0):
     return owner
 
 
+def rcb_owner(X, conn, world):
+    """Element owner by recursive coordinate bisection of the element centroids (unstructured meshes): the
+    set is split at the weighted median along its longest extent, `world` = any count (parts get sizes in proportion to
+    the ranks they will hold); deterministic (stable sorts), balanced to one element."""
+    c = X[conn[:, :4]].mean(axis=1)
+    owner = np.zeros(conn.shape[0], dtype=np.int32)
+
+    def split(ids, r0, nr):
+        if nr == 1:
+            owner[ids] = r0
+            return
+        ext = c[ids].max(axis=0) - c[ids].min(axis=0)
+        ax = int(np.argmax(ext))
+        order = ids[np.argsort(c[ids, ax], kind="stable")]
+        nl = nr // 2
+        cut = (len(ids) * nl) // nr
+        split(order[:cut], r0, nl)
+        split(order[cut:], r0 + nl, nr - nl)
+
+    split(np.arange(conn.shape[0]), 0, world)
+    return owner
+
+
 def partition_from_global(X, conn, owner, rank, world):
     """General partition of a global T10 mesh by an element->rank map (bit-exact integer bookkeeping)."""
     N = X.shape[0]
@@ -127,9 +150,12 @@ def make_allreduce(torch, dist, backend):
     return ar_host, 1
 
 
-def rccl_communicator(dist, rank, world):
+def rccl_communicator(dist, rank, world, timeout_s=120.0, self_check=True):
     """A RCCL communicator owned by the engine (tlfea_rccl_*): rank 0 creates the unique id, torch.distributed ships its
-    128 bytes once, every rank joins.  -> opaque handle for SyncedNewtonSolver.SetInterfaceRccl / rccl_destroy."""
+    128 bytes once, every rank joins -- under a watchdog: a rank whose ncclCommInitRank or whose known-answer check
+    (all-reduce + ring send/recv, tlfea_rccl_self_check) does not finish within timeout_s, or sees a wrong answer, prints
+    why and exits with code 97 (a stuck collective cannot be abandoned), so a broken fabric shows as a failed launch, not
+    a hang.  -> opaque handle for SyncedNewtonSolver.SetHalo / SetInterfaceRccl / rccl_destroy."""
     import ctypes as C
 
     from . import binding
@@ -141,7 +167,9 @@ def rccl_communicator(dist, rank, world):
     if world > 1:
         dist.broadcast_object_list(box, src=0)
     comm = C.c_void_p()
-    binding.check(lib.tlfea_rccl_comm_create(box[0], int(rank), int(world), C.byref(comm)))
+    binding.check(lib.tlfea_rccl_comm_create_timeout(box[0], int(rank), int(world), C.c_double(timeout_s), C.byref(comm)))
+    if self_check:
+        binding.check(lib.tlfea_rccl_self_check(comm, int(rank), int(world), C.c_double(timeout_s)))
     return comm
 
 
@@ -179,3 +207,205 @@ def restrict_bcs_to_global_ends(w, rank, world, cfg):
             face = np.where(np.abs(X[:, 0] - lx * world) < 1e-9)[0]
             w["f_ext"][3 * face] = 5000.0 / max(1, len(face))
     return w
+
+
+# ---- overlapping partition (round 3): owner-computes with ghost layers -------------------------------------------------
+# Every node has exactly ONE owner.  A rank holds its owned nodes plus `depth` layers of ghost nodes (layer k = nodes at
+# graph distance k from the owned set, two nodes being adjacent when they share an element) and every element that
+# touches a node of layer < depth, so the rows of H, M and grad L of all nodes of layers < depth are COMPLETE on the rank:
+# nothing is summed over ranks.  What the path exchanges instead is a refresh of ghost VALUES from their owners
+# (neighbour to neighbour, payload independent of the number of ranks), and only every few steps: after a refresh the
+# ghost layers are exact, each SpMV-like step invalidates the outermost valid layer, so a halo of depth G buys G - 1
+# steps of the coarse polynomial per exchange (computed redundantly on the overlap).  Dot products weigh owned nodes 1,
+# ghosts 0, and are summed with one small world all-reduce.
+class HaloPartition:
+    """One rank's overlapped sub-mesh.  Local numbering: owned nodes first (original relative order), then ghosts by
+    increasing layer.  For peer p: `send[p]` = my owned nodes that p holds as ghosts, `recv[p]` = my ghosts owned by p;
+    both sorted by (layer on the receiving side, global id), so 'refresh up to layer D' is a PREFIX of either list
+    (`send_upto[p][D]`, `recv_upto[p][D]`) and both sides agree on the order without communicating."""
+
+    def __init__(self, rank, world, depth, X, conn, l2g, layer, peers, send, send_layer, recv, elem_gids, src=None):
+        self.rank, self.world, self.depth = rank, world, int(depth)
+        self.X, self.conn = X, conn
+        self.l2g = l2g
+        self.src = l2g if src is None else src      # index of each local node in the mesh halo_partition was given
+        self.layer = np.ascontiguousarray(layer, dtype=np.int32)
+        self.n_owned = int(np.sum(self.layer == 0))
+        self.peers = [int(p) for p in peers]
+        self.send = [np.ascontiguousarray(a, dtype=np.int32) for a in send]
+        self.send_layer = [np.ascontiguousarray(a, dtype=np.int32) for a in send_layer]
+        self.recv = [np.ascontiguousarray(a, dtype=np.int32) for a in recv]
+        self.elem_gids = elem_gids
+        self.node_owned = (self.layer == 0).astype(np.int32)
+
+    def n_upto(self, k):
+        """number of local nodes of layers <= k (a prefix of the local numbering)"""
+        return int(np.searchsorted(self.layer, k, side="right"))
+
+    def localize_nodes(self, global_nodes):
+        """Global node ids -> local ids (dropping nodes this rank does not hold)."""
+        g = np.asarray(global_nodes, dtype=np.int64)
+        order = np.argsort(self.l2g, kind="stable")
+        sl = self.l2g[order]
+        pos = np.searchsorted(sl, g)
+        pos[pos >= len(sl)] = 0
+        ok = sl[pos] == g
+        return np.sort(order[pos[ok]]).astype(np.int32)
+
+    def local_nodal_vector(self, f_global_3n):
+        """A global nodal vector on this rank's nodes, UNSHARED: every rank evaluates complete rows."""
+        return np.ascontiguousarray(np.asarray(f_global_3n).reshape(-1, 3)[self.l2g]).reshape(-1)
+
+
+def _node_layers(n_nodes, conn, seed_mask, max_layer):
+    """BFS over 'shares an element': layer[n] = graph distance from the seed set (max_layer + 1 = farther)."""
+    layer = np.full(n_nodes, max_layer + 1, dtype=np.int32)
+    layer[seed_mask] = 0
+    reached = seed_mask.copy()
+    for k in range(1, max_layer + 1):
+        touch = reached[conn].any(axis=1)              # elements with a node of layer < k
+        nodes = np.unique(conn[touch])
+        new = nodes[~reached[nodes]]
+        if len(new) == 0:
+            break
+        layer[new] = k
+        reached[new] = True
+    return layer
+
+
+def halo_partition(X, conn, node_owner, gid, rank, world, depth):
+    """Overlapped sub-mesh of `rank` out of a mesh that contains at least everything within `depth` + 1 layers of the
+    rank's owned nodes (the whole global mesh in the tests; a generously extended slab in bench.py).
+    node_owner[n] = owning rank of node n, gid[n] = a global id all ranks agree on (ordering of the exchange lists)."""
+    conn = np.asarray(conn)
+    node_owner = np.asarray(node_owner)
+    gid = np.asarray(gid, dtype=np.int64)
+    N = X.shape[0]
+    G = int(depth)
+    owned = node_owner == rank
+    layer = _node_layers(N, conn, owned, G)
+    # elements that touch a node of layer < G: rows of layers < G are complete
+    keep_e = (layer[conn] < G).any(axis=1)
+    elem_ids = np.where(keep_e)[0]
+    keep_n = np.zeros(N, dtype=bool)
+    keep_n[conn[elem_ids]] = True
+    assert np.all(layer[keep_n] <= G)
+    old = np.where(keep_n)[0]
+    order = np.lexsort((old, layer[old]))              # by layer, original order inside a layer
+    old = old[order]
+    new_of = np.full(N, -1, dtype=np.int64)
+    new_of[old] = np.arange(len(old))
+    conn_loc = new_of[conn[elem_ids]].astype(np.int32)
+    lay_loc = layer[old]
+    own_loc = node_owner[old]
+    gid_loc = gid[old]
+    peers = sorted(int(p) for p in np.unique(own_loc) if p != rank)
+    send, send_layer, recv = [], [], []
+    for p in peers:
+        # my ghosts owned by p, by (my layer, gid)
+        r = np.where(own_loc == p)[0]
+        r = r[np.lexsort((gid_loc[r], lay_loc[r]))]
+        recv.append(r)
+        # my owned nodes p holds: layer ON p = distance from p's owned set, measured on the mesh I was given (exact up to
+        # G: every shortest path of length <= G from p's owned set to one of my owned nodes runs inside my overlap)
+        lay_on_p = _node_layers(N, conn, node_owner == p, G)[old]
+        s = np.where((own_loc == rank) & (lay_on_p <= G))[0]
+        s = s[np.lexsort((gid_loc[s], lay_on_p[s]))]
+        send.append(s)
+        send_layer.append(lay_on_p[s])
+    return HaloPartition(rank, world, G, X[old].copy(), conn_loc, gid_loc.copy(), lay_loc, peers, send, send_layer, recv,
+                         elem_ids, src=old)
+
+
+def node_owner_from_elements(n_nodes, conn, elem_owner, world):
+    """Lowest rank among the owners of a node's elements (the rule of partition_from_global)."""
+    first = np.full(n_nodes, world, dtype=np.int32)
+    for r in range(world - 1, -1, -1):
+        first[np.unique(conn[elem_owner == r])] = r
+    return first
+
+
+def halo_slab_structured(wl, config, rank, world, depth):
+    """bench.py weak scaling: rank-local construction of one config-sized x-slab of a bar `world` times as long, extended
+    by `depth` + 1 cell layers into each neighbour.  Owner of a node = the slab whose half-open x-range (lo, hi] holds it
+    (rank 0 also owns x = 0); global ids = lattice index in the long bar, so neighbours agree on every list order.
+    -> (workload dict of the extended slab, HaloPartition)"""
+    cfg = wl.CONFIGS[config]
+    nx, ny, nz = cfg["cells"]
+    ext = depth + 1
+    c_lo = max(0, rank * nx - ext)
+    c_hi = min(world * nx, (rank + 1) * nx + ext)
+    w = wl.build(config, cells=(c_hi - c_lo, ny, nz), x_offset_cells=c_lo)
+    X = w["X"]
+    lx = cfg["size"][0]
+    hx = lx / nx / 2.0                                             # lattice spacing (corner + mid-edge nodes)
+    ix = np.rint(X[:, 0] / hx).astype(np.int64)
+    iy = np.rint(X[:, 1] / (cfg["size"][1] / ny / 2.0)).astype(np.int64)
+    iz = np.rint(X[:, 2] / (cfg["size"][2] / nz / 2.0)).astype(np.int64)
+    gx, gy = 2 * nx * world + 1, 2 * ny + 1
+    gid = (iz * gy + iy) * gx + ix
+    owner = np.clip((ix - 1) // (2 * nx), 0, world - 1).astype(np.int32)   # (lo, hi]: the plane x = hi belongs to the slab
+    hp = halo_partition(X, w["conn"], owner, gid, rank, world, depth)
+    src = hp.src
+    Xl = hp.X
+    # boundary conditions of the LONG bar (test_feat10_resolution.cc:283-312): clamp at x = 0, 5000 N over x = L; every
+    # rank that holds such a node carries its full value (rows are complete on every rank, nothing is shared out)
+    fixed = np.where(np.abs(Xl[:, 0]) < 1e-12)[0].astype(np.int32)
+    f_ext = np.zeros(3 * Xl.shape[0])
+    n_face = (2 * ny + 1) * (2 * nz + 1)
+    face = np.where(np.abs(Xl[:, 0] - lx * world) < 1e-9)[0]
+    f_ext[3 * face] = 5000.0 / n_face
+    x0 = w["x0"][src].copy()
+    x0[fixed] = Xl[fixed]
+    wl_loc = dict(X=Xl, conn=hp.conn, fixed=fixed, f_ext=f_ext, x0=x0, material=w["material"], params=w["params"],
+                  desc=w["desc"])
+    return wl_loc, hp
+
+
+class _DeviceBytes:
+    """Zero-copy uint8 view of a raw device buffer (CUDA array interface v2)."""
+
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
+
+
+def make_halo_exchange(torch, dist, backend):
+    """-> callable(send_ptr, recv_ptr, peers, send_off, recv_off) moving byte ranges of two device buffers between
+    neighbours.  'nccl': batched isend / irecv on device views (RCCL); anything else: host staging (gloo)."""
+    dev = backend == "nccl"
+
+    def ex(sp, rp, peers, so, ro):
+        ns, nr = so[-1], ro[-1]
+        st = torch.as_tensor(_DeviceBytes(sp, ns), device="cuda") if ns else None
+        rt = torch.as_tensor(_DeviceBytes(rp, nr), device="cuda") if nr else None
+        if not dev:
+            st = st.cpu() if st is not None else None
+            rh = torch.empty(nr, dtype=torch.uint8) if nr else None
+        else:
+            rh = rt
+        ops = []
+        for k, p in enumerate(peers):
+            if so[k + 1] > so[k]:
+                ops.append(dist.P2POp(dist.isend, st[so[k]:so[k + 1]], p))
+            if ro[k + 1] > ro[k]:
+                ops.append(dist.P2POp(dist.irecv, rh[ro[k]:ro[k + 1]], p))
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        if not dev and nr:
+            rt.copy_(rh)
+            torch.cuda.synchronize()
+    return ex, (0 if dev else 1)
+
+
+def attach_halo(solver, hp, torch, dist, native_rccl=None):
+    """Wire a SyncedNewtonSolver to its overlapping partition: the library's own RCCL exchange when a communicator is
+    given (collectives enqueued from C++ on the solver's stream and captured in its hipGraphs), else torch.distributed
+    callbacks (RCCL on device views with the nccl backend, gloo through host staging in the CPU / one-GPU rehearsals)."""
+    if native_rccl is not None:
+        solver.SetHalo(hp, rccl_comm=native_rccl)
+        return
+    backend = dist.get_backend()
+    ar, sync = make_allreduce(torch, dist, backend)
+    ex, _ = make_halo_exchange(torch, dist, backend)
+    solver.SetHalo(hp, allreduce=ar, exchange=ex, sync_before_callback=1)

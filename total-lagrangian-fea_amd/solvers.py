@@ -275,6 +275,58 @@ class SyncedNewtonSolver:
         check(self._lib.tlfea_newton_set_interface(self._h, ip(nodes), ip(slots), int(nodes.size),
                                                    int(n_global_iface), dp(w), fn, comm, 0))
 
+    def SetHalo(self, part, allreduce=None, exchange=None, sync_before_callback=1, rccl_comm=None):
+        """Overlapping partition (tlfea_newton_set_halo): `part` is a partition.HaloPartition built on the mesh this
+        solver's data object holds.  Either Python callbacks -- allreduce(ptr, n) sums n device doubles over ranks in
+        place, exchange(send_ptr, recv_ptr, peers, send_off, recv_off) moves byte ranges neighbour to neighbour -- or
+        rccl_comm: the library's built-in RCCL exchange on a communicator of partition.rccl_communicator()."""
+        from .binding import HALO_EXCHANGE_FN, HaloListsC
+        assert len(part.layer) == self.n_coef
+        P = len(part.peers)
+        peers = np.ascontiguousarray(part.peers, dtype=np.int32)
+        cat = lambda arrs: (np.ascontiguousarray(np.concatenate(arrs), dtype=np.int32) if arrs else np.zeros(0, np.int32))  # noqa: E731
+        off = lambda arrs: np.ascontiguousarray(np.concatenate([[0], np.cumsum([len(a) for a in arrs])]), dtype=np.int32)  # noqa: E731
+        so, ro = off(part.send), off(part.recv)
+        sn, sl, rn = cat(part.send), cat(part.send_layer), cat(part.recv)
+        layer = np.ascontiguousarray(part.layer, dtype=np.int32)
+        lists = HaloListsC(P, ip(peers), ip(so), ip(sn), ip(sl), ip(ro), ip(rn))
+        self._halo_keep = (peers, so, ro, sn, sl, rn, layer, lists)
+        if rccl_comm is not None:
+            self._lib.tlfea_rccl_allreduce_fn.restype = C.c_void_p
+            self._lib.tlfea_rccl_halo_exchange_fn.restype = C.c_void_p
+            ar = C.cast(self._lib.tlfea_rccl_allreduce_fn(), ALLREDUCE_FN)
+            ex = C.cast(self._lib.tlfea_rccl_halo_exchange_fn(), HALO_EXCHANGE_FN)
+            self._cb = (ar, ex)
+            check(self._lib.tlfea_newton_set_halo(self._h, ip(layer), int(part.depth), C.byref(lists), ar, ex, rccl_comm, 0))
+            return
+
+        def _ar(_user, ptr, n):
+            try:
+                allreduce(ptr, n)
+                return 0
+            except Exception as exc:  # pragma: no cover
+                print("allreduce callback failed:", repr(exc), flush=True)
+                return 1
+
+        def _ex(_user, sp, rp, n_peers, peers_p, so_p, ro_p):
+            try:
+                exchange(sp, rp, [peers_p[k] for k in range(n_peers)], [so_p[k] for k in range(n_peers + 1)],
+                         [ro_p[k] for k in range(n_peers + 1)])
+                return 0
+            except Exception as exc:  # pragma: no cover
+                print("halo exchange callback failed:", repr(exc), flush=True)
+                return 1
+
+        self._cb = (ALLREDUCE_FN(_ar), HALO_EXCHANGE_FN(_ex))
+        check(self._lib.tlfea_newton_set_halo(self._h, ip(layer), int(part.depth), C.byref(lists), self._cb[0], self._cb[1],
+                                              None, int(sync_before_callback)))
+
+    def GetCommStats(self):
+        out = np.zeros(8)
+        check(self._lib.tlfea_newton_get_comm_stats(self._h, dp(out)))
+        return dict(exchanges=int(out[0]), allreduces=int(out[1]), bytes_exchanged=float(out[2]), bytes_allreduced=float(out[3]),
+                    comm_ms=float(out[4]), cg_iterations=int(out[5]), exchanges_in_cg=int(out[6]), allreduces_in_cg=int(out[7]))
+
     def SetInterfaceOwners(self, node_owned):
         """node_owned[n_coef] = 1 where this rank owns the node (one owner per replicated node over all ranks):
         switches the polynomial preconditioner to its rank-local form (see tlfea_c.h)."""
