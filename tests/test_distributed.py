@@ -235,6 +235,7 @@ def test_halo_structured_slabs_agree():
     built = [par.halo_slab_structured(wl, "S", r, world, depth) for r in range(world)]
     cfg = wl.CONFIGS["S"]
     n_plane = (2 * cfg["cells"][1] + 1) * (2 * cfg["cells"][2] + 1)
+    assert all(w["grid"] == (world, 1, 1) for w, _ in built)
     for r, (w, hp) in enumerate(built):
         assert hp.peers == [p for p in (r - 1, r + 1) if 0 <= p < world]
         assert w["X"].shape[0] == len(hp.layer) and w["conn"].max() < len(hp.layer)
@@ -246,6 +247,8 @@ def test_halo_structured_slabs_agree():
             assert np.array_equal(hp.l2g[hp.send[k]], q.l2g[q.recv[kq]])
             assert np.array_equal(hp.send_layer[k], q.layer[q.recv[kq]])
             assert np.allclose(w["X"][hp.send[k]], built[p][0]["X"][q.recv[kq]])
+            # a ghost copy starts where its owner starts (the timing state's noise is keyed by the node, not by a local index)
+            assert np.array_equal(w["x0"][hp.send[k]], built[p][0]["x0"][q.recv[kq]])
     total_owned = sum(hp.n_owned for _, hp in built)
     assert total_owned == (2 * cfg["cells"][0] * world + 1) * n_plane
 
@@ -271,3 +274,40 @@ def test_halo_hip_engine_matches_unpartitioned_oracle(tmp_path, world, mesh, par
     c = rep["comm"]
     per_it = (c["exchanges_in_cg"] + c["allreduces_in_cg"]) / max(1, c["cg_iterations"])
     assert c["cg_iterations"] >= rep["pcg_iters"] and per_it <= 12.0, rep
+
+
+@pytest.mark.gpu
+def test_halo_builtin_rccl_single_rank(tmp_path):
+    """The production exchange of the overlapping partition (tlfea_rccl_*: communicator from a shipped unique id under the
+    init watchdog, known-answer self-check, ncclAllReduce / ncclSend / ncclRecv enqueued from C++ on the solver's stream)
+    with the one rank the test box allows: no neighbour exists, but every all-reduce of the path runs -- CAPTURED in the
+    CG iteration's hipGraphs -- and the step must reproduce the un-partitioned oracle."""
+    rep = launch(1, ["--engine", "hip", "--mesh", "res2", "--steps", "2", "--backend", "nccl", "--mode", "halo",
+                     "--native-rccl"], tmp_path)
+    assert rep["ok"] and rep["precond"] == 2, rep
+    c = rep["comm"]
+    assert c["exchanges"] == 0 and c["allreduces_in_cg"] >= 2 * c["cg_iterations"] > 0, rep
+
+
+@pytest.mark.parametrize("world", [4, 8])
+def test_halo_structured_blocks_agree(world):
+    """The block series of bench.py (2x2x1, 2x2x2 blocks of the config; 8 blocks of config C = BASELINE's config E): every
+    rank builds its block alone, every pair of neighbours (faces, edges, corners: up to 7 peers) agrees on the exchange
+    lists and on the start positions of shared nodes, and the owned sets tile the body's lattice exactly once."""
+    wl = __import__("importlib").import_module("total-lagrangian-fea_amd.workloads")
+    built = [par.halo_block_structured(wl, "S", r, world, 2) for r in range(world)]
+    cfg = wl.CONFIGS["S"]
+    pg = par.process_grid(world)
+    assert sum(hp.n_owned for _, hp in built) == int(np.prod([2 * c * g + 1 for c, g in zip(cfg["cells"], pg)]))
+    gids = np.concatenate([hp.l2g[:hp.n_owned] for _, hp in built])
+    assert len(np.unique(gids)) == len(gids)
+    for r, (w, hp) in enumerate(built):
+        assert len(hp.peers) == world - 1 and w["grid"] == pg            # 2 blocks per axis: every block touches every other
+        for k, p in enumerate(hp.peers):
+            q = built[p][1]
+            kq = q.peers.index(r)
+            assert np.array_equal(hp.l2g[hp.send[k]], q.l2g[q.recv[kq]])
+            assert np.array_equal(hp.send_layer[k], q.layer[q.recv[kq]])
+            assert np.array_equal(w["x0"][hp.send[k]], built[p][0]["x0"][q.recv[kq]])
+    n_fixed = sum(len(w["fixed"][hp.layer[w["fixed"]] == 0]) for w, hp in built)
+    assert n_fixed == (2 * cfg["cells"][1] * pg[1] + 1) * (2 * cfg["cells"][2] * pg[2] + 1)   # the x = 0 face, owned once

@@ -414,3 +414,27 @@ def test_strip_constructor_and_print_dsdu_pre(capsys):
     first = [float(v) for v in out.split("Shape 0: ")[1].splitlines()[0].split()]
     assert np.allclose(first, g[0, 0, 0], atol=5e-7)
     d.Destroy()
+
+
+def test_position_coefficient_two_level_cycle_is_a_valid_preconditioner(monkeypatch):
+    """TLFEA_PMG_ANCF=1 (experiment switch): the two-level cycle whose coarse space is the position coefficient of every
+    ANCF node (pmg_build_ancf: injection, Galerkin operator = H restricted to those coefficients).  Not a default -- at
+    config D it needs more CG iterations than the polynomial saves per iteration -- but it must be a correct SPD
+    preconditioner: same Newton steps as the oracle's direct solve on a plate."""
+    monkeypatch.setenv("TLFEA_PMG_ANCF", "1")
+    o, d = make_pair(PROBLEMS["plate3443"](), SVK_D)
+    s = tl.SyncedNewtonSolver(d, d.get_n_constraint())
+    s.Setup()
+    s.SetParameters(tl.SyncedNewtonParams(1e-4, 0.0, 1e-6, 1e14, 5, 10, 1e-3))
+    s.SetLinSolveOpts(tl.LinSolveOpts(1e-13, 50000, 10, 0, 0.0, 0, 2))
+    assert s.GetPreconditioner() == 2
+    s.Solve()
+    info = s.GetPmgInfo()
+    assert info is not None and info[0] == d.get_n_coef() // 4
+    st = o.newton_step(orc.NewtonParams(1e-4, 0.0, 1e-6, 1e14, 5, 10, 1e-3))
+    assert s.GetStats()["newton"] == st[1]
+    X0 = np.stack([o.xt, o.yt, o.zt], axis=1)
+    assert disp_err_ok(np.stack(d.RetrievePositionToCPU(), axis=1), np.stack([o.x, o.y, o.z], axis=1), X0)
+    assert s.GetLinSolveStatus()["all_converged"]
+    del s
+    d.Destroy()

@@ -171,6 +171,63 @@ inline bool pmg_build(int N, int E, const int* conn, const int* off, const int* 
   return true;
 }
 
+// ---- the same two-level set-up for the ANCF kinds (3243 beams, 3443 shells) ---------------------------------------------
+// An ANCF node carries four coefficient vectors (position r and the gradients r_u, r_v, r_w: coefficient 4 node + slot,
+// ANCF3243DataFunc.cuh:212-215).  Coarse space = the POSITION coefficient of every node: P injects coarse node I into
+// coefficient 4 I and leaves the gradient coefficients to the smoother, Hc = P^T H P is the sub-matrix of H on the
+// position coefficients (pattern = nodes sharing an element, 1/16 of H's blocks).  The bookkeeping arrays are those of
+// pmg_build with one child and one contributing fine block per coarse entity; par = -1 marks a coefficient without a
+// coarse parent (the prolongation leaves it untouched).
+inline bool pmg_build_ancf(int N, const int* off, const int* cols, PmgHost& o) {
+  o = PmgHost();
+  if (N <= 0 || N % 4 != 0) return false;
+  o.N = N;
+  const int Nc = N / 4;
+  o.Nc = Nc;
+  o.par0.assign(N, -1);
+  o.par1.assign(N, -1);
+  for (int I = 0; I < Nc; I++) o.par0[4 * I] = o.par1[4 * I] = I;
+  o.c_off.assign((size_t)Nc + 1, 0);
+  for (int I = 0; I < Nc; I++) {
+    int cnt = 0;
+    for (int g = off[4 * I]; g < off[4 * I + 1]; g++) cnt += cols[g] % 4 == 0;
+    o.c_off[I + 1] = o.c_off[I] + cnt;
+  }
+  o.nnz_c = o.c_off[Nc];
+  o.c_cols.resize((size_t)o.nnz_c);
+  o.c_diagpos.assign((size_t)Nc, -1);
+  o.cblk_row.resize((size_t)o.nnz_c);
+  o.con_off.resize((size_t)o.nnz_c + 1);
+  o.con_blk.resize((size_t)o.nnz_c);
+  o.con_base.resize((size_t)o.nnz_c);
+  o.con_deg.resize((size_t)o.nnz_c);
+  o.con_w.assign((size_t)o.nnz_c, 1.f);
+  for (int I = 0; I < Nc; I++) {
+    int k = o.c_off[I];
+    const int i = 4 * I, deg = off[i + 1] - off[i];
+    for (int g = off[i]; g < off[i + 1]; g++) {
+      if (cols[g] % 4) continue;
+      const int J = cols[g] / 4;
+      if (J == I) o.c_diagpos[I] = k - o.c_off[I];
+      o.c_cols[k] = J;           // fine columns ascend, so do these
+      o.cblk_row[k] = I;
+      o.con_off[k] = k;
+      o.con_blk[k] = g;
+      o.con_base[k] = 9 * off[i] + 3 * (g - off[i]);
+      o.con_deg[k] = deg;
+      k++;
+    }
+    if (o.c_diagpos[I] < 0) return false;
+  }
+  o.con_off[o.nnz_c] = o.nnz_c;
+  o.child_off.resize((size_t)Nc + 1);
+  o.child.resize((size_t)Nc);
+  o.child_w.assign((size_t)Nc, 1.f);
+  for (int I = 0; I <= Nc; I++) o.child_off[I] = I;
+  for (int I = 0; I < Nc; I++) o.child[I] = 4 * I;
+  return true;
+}
+
 // ---- third level: aggregation of the vertex mesh with rigid-body modes ---------------------------------------------
 // The vertex (P1) problem is still elasticity on the full mesh; a polynomial on it needs a degree that grows with the
 // mesh (31 at config C).  Below it sits one more Galerkin level: greedy aggregates of a vertex and its neighbours

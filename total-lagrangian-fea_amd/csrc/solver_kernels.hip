@@ -802,10 +802,11 @@ void launch_cheb_lp(hipStream_t s, int N, int nnz_coef, const Incidence& inc, co
 __global__ __launch_bounds__(256) void cheb32_init_kernel(int N, const float* __restrict__ Dinv_f,
                                                          const double* __restrict__ r, const double* __restrict__ sc,
                                                          const double* __restrict__ coef, float* __restrict__ d,
-                                                         float* __restrict__ z, float* __restrict__ res) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
+                                                         float* __restrict__ z, float* __restrict__ res, int row0) {
+  const int i = row0 + blockIdx.x * 256 + threadIdx.x;
   if (i >= N) return;
   const float inv_theta = (float)coef[0];
+  const float zw0 = coef[1] != 0.0 ? (float)coef[1] : 1.f;  // fourth-kind smoothers: z^0 = beta_1 d0
   const float r0 = (float)(r[3 * i] * sc[3 * i]), r1 = (float)(r[3 * i + 1] * sc[3 * i + 1]),
               r2 = (float)(r[3 * i + 2] * sc[3 * i + 2]);
   const float* D = Dinv_f + (size_t)9 * i;
@@ -813,7 +814,7 @@ __global__ __launch_bounds__(256) void cheb32_init_kernel(int N, const float* __
   for (int c = 0; c < 3; c++) {
     const float v = (D[3 * c] * r0 + D[3 * c + 1] * r1 + D[3 * c + 2] * r2) * inv_theta;
     d[3 * i + c] = v;
-    z[3 * i + c] = v;
+    z[3 * i + c] = zw0 * v;
   }
   res[3 * i] = r0;
   res[3 * i + 1] = r1;
@@ -821,8 +822,10 @@ __global__ __launch_bounds__(256) void cheb32_init_kernel(int N, const float* __
 }
 
 void launch_cheb32_init(hipStream_t s, int N, const float* Dinv_f, const double* r, const double* sc,
-                        const double* coef, float* d, float* z, float* res) {
-  hipLaunchKernelGGL(cheb32_init_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, Dinv_f, r, sc, coef, d, z, res);
+                        const double* coef, float* d, float* z, float* res, int row0) {  // rows row0 .. N - 1
+  if (N <= row0) return;
+  hipLaunchKernelGGL(cheb32_init_kernel, dim3((N - row0 + 255) / 256), dim3(256), 0, s, N, Dinv_f, r, sc, coef, d, z, res,
+                     row0);
 }
 
 // Dinv_f = float((S D S)^-1)
@@ -889,6 +892,7 @@ __global__ __launch_bounds__(TPB) void cheb32_kernel(int N, Incidence inc, const
                                                      double* __restrict__ rz_part, C32Bnd bnd) {
   __shared__ double sh[32];
   const float c1 = (float)coef[0], c2 = (float)coef[1];
+  const float zwf = bnd.zw ? (float)bnd.zw[0] : 1.f;
   constexpr int G = TPB / L;
   const int lane = threadIdx.x & (L - 1), grp = threadIdx.x / L;
   const int c = lane < 3 ? lane : 0;
@@ -993,7 +997,7 @@ __global__ __launch_bounds__(TPB) void cheb32_kernel(int N, Incidence inc, const
         const float e0 = (w ? eB0 : eA0) - t0, e1 = (w ? eB1 : eA1) - t1, e2 = (w ? eB2 : eA2) - t2;
         const float dn = c1 * (w ? dcB : dcA) +
                          c2 * ((w ? DB0 : DA0) * e0 + (w ? DB1 : DA1) * e1 + (w ? DB2 : DA2) * e2);
-        const float zn = (w ? zcB : zcA) + dn;
+        const float zn = (w ? zcB : zcA) + zwf * dn;
         d_new[3 * iw + c] = dn;
         if (LAST) {
           const double zt = sc[3 * iw + c] * (double)zn;
@@ -1253,6 +1257,10 @@ __global__ __launch_bounds__(256) void pmg_prolong_kernel(int N, const int* __re
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
   const int a = par0[i], b = par1[i];
+  if (a < 0) {  // no coarse parent (ANCF gradient coefficients): the correction is zero here
+    d_f[3 * i] = d_f[3 * i + 1] = d_f[3 * i + 2] = 0.f;
+    return;
+  }
 #pragma unroll
   for (int c = 0; c < 3; c++) {
     const double ea = sc_c[3 * a + c] * (double)z_c[3 * a + c];
@@ -1515,6 +1523,7 @@ __global__ __launch_bounds__(256) void pcg_update_init32_kernel(
   const double alpha = pq != 0.0 ? rz_old / pq : 0.0;
   if (blockIdx.x == 0 && threadIdx.x == 0 && rz_old < 0.0) indefinite[0] = 1.0;
   const float inv_theta = (float)coef[0];
+  const float zw0 = coef[1] != 0.0 ? (float)coef[1] : 1.f;  // fourth-kind smoothers: z^0 = beta_1 d0
   double rr = 0.0;
   for (int i = blockIdx.x * 256 + threadIdx.x; i < N; i += gridDim.x * 256) {
     float rs[3];
@@ -1531,7 +1540,7 @@ __global__ __launch_bounds__(256) void pcg_update_init32_kernel(
     for (int c = 0; c < 3; c++) {
       const float v = (D[3 * c] * rs[0] + D[3 * c + 1] * rs[1] + D[3 * c + 2] * rs[2]) * inv_theta;
       d[3 * i + c] = v;
-      z[3 * i + c] = v;
+      z[3 * i + c] = zw0 * v;
       res[3 * i + c] = rs[c];
     }
   }
@@ -1559,6 +1568,7 @@ __global__ __launch_bounds__(256) void residual_replace_init32_kernel(
     const double* __restrict__ wown) {
   __shared__ double sh[32];
   const float inv_theta = (float)coef[0];
+  const float zw0 = coef[1] != 0.0 ? (float)coef[1] : 1.f;  // fourth-kind smoothers: z^0 = beta_1 d0
   double rr = 0.0;
   for (int i = blockIdx.x * 256 + threadIdx.x; i < N; i += gridDim.x * 256) {
     float rs[3];
@@ -1574,7 +1584,7 @@ __global__ __launch_bounds__(256) void residual_replace_init32_kernel(
     for (int c = 0; c < 3; c++) {
       const float v = (D[3 * c] * rs[0] + D[3 * c + 1] * rs[1] + D[3 * c + 2] * rs[2]) * inv_theta;
       d[3 * i + c] = v;
-      z[3 * i + c] = v;
+      z[3 * i + c] = zw0 * v;
       res[3 * i + c] = rs[c];
     }
   }

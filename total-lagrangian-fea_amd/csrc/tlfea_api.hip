@@ -1098,7 +1098,7 @@ extern "C" int tlfea_newton_create(tlfea_t10_t data, int n_constraints, tlfea_ne
   TRY(dmalloc(&s->d_xp, (size_t)s->N)); TRY(dmalloc(&s->d_yp, (size_t)s->N)); TRY(dmalloc(&s->d_zp, (size_t)s->N));
   TRY(dmalloc(&s->d_parts, (size_t)6 * kNPart));
   TRY(dmalloc(&s->d_scal, (size_t)4));
-  HIP_TRY(hipHostMalloc((void**)&s->h_pin, (8 + 32 + 2 * 64) * sizeof(double)));
+  HIP_TRY(hipHostMalloc((void**)&s->h_pin, (8 + 48 + 2 * 64) * sizeof(double)));
   TRY(dmalloc(&s->d_coef, (size_t)2 * 64));
   if (const char* e = std::getenv("TLFEA_GRAPH")) s->use_graphs = std::atoi(e) != 0;
   TRY(dmalloc(&s->d_Dinv, (size_t)9 * s->N));
@@ -2444,7 +2444,15 @@ static int pmg_ks(tlfea_newton_t s) {
 // (0, 0), the post-smoothing restart (0, 1/theta), then the coarse polynomial
 static int pmg_cf_resid(tlfea_newton_t s) { return 2 * pmg_ks(s); }
 static int pmg_cf_restart(tlfea_newton_t s) { return 2 * pmg_ks(s) + 2; }
-static int pmg_cf_coarse(tlfea_newton_t s) { return 2 * pmg_ks(s) + 4; }
+static int pmg_cf_beta(tlfea_newton_t s) { return 2 * pmg_ks(s) + 4; }                 // ks weights of z^ += beta_k d
+static int pmg_cf_coarse(tlfea_newton_t s) { return 2 * pmg_ks(s) + 4 + kPmgMaxKs; }
+// Smoother polynomial (TLFEA_PMG_SMOOTHER): 1 = first-kind Chebyshev on [lmax / kappa_s, lmax] (the default),
+// 3 = fourth-kind Chebyshev (needs lmax only), 4 = fourth kind with the optimised weights of Lottes (2022),
+// "Optimal polynomial smoothers for multigrid V-cycles": the z^ update is weighted, z^_k = z^_{k-1} + beta_k d_{k-1}.
+static int pmg_smoother_kind() {
+  static const int k = std::getenv("TLFEA_PMG_SMOOTHER") ? std::atoi(std::getenv("TLFEA_PMG_SMOOTHER")) : 1;
+  return (k == 3 || k == 4) ? k : 1;
+}
 // Third level (rigid-body-mode aggregates below the vertex level): opt-in with TLFEA_PMG_LEVELS=3.  Measured at config C
 // it makes a CG iteration 10-12 % cheaper (4 vertex-level steps + a degree-20..32 polynomial on ~20 000 level-3 nodes
 // instead of 31 vertex-level steps) and costs 10-17 % more iterations (33-35 instead of 30, whatever the accuracy of
@@ -2480,7 +2488,12 @@ static int upload_vec(T** dst, const std::vector<T>& v) {
 static int precond_eff(tlfea_newton_t s) {
   if (s->lin.precond == 1) return 1;
   tlfea_t10_t d = s->d;
-  const bool possible = d->kind == kT10 && !(s->ar && s->d_own) && d->cons_mode != 2 && cheb_degree_eff(s) > 1 &&
+  // T10: quadratic tets -> vertex mesh.  ANCF kinds: all coefficients -> position coefficients (pmg_build_ancf), an
+  // experiment switch only (TLFEA_PMG_ANCF=1): measured at config D it needs 44-90 CG iterations against the polynomial's
+  // 24 and is no faster, so a precond = 2 request on an ANCF mesh keeps the polynomial
+  const char* ancf_env = std::getenv("TLFEA_PMG_ANCF");
+  const bool kind_ok = d->kind == kT10 || (ancf_env && std::atoi(ancf_env) == 1 && !dist_on(s));
+  const bool possible = kind_ok && !(s->ar && s->d_own) && d->cons_mode != 2 && cheb_degree_eff(s) > 1 &&
                         cheb_bits_eff(s) != 64 && !(s->pmg.tried && !s->pmg.ok);
   return possible ? 2 : 1;
 }
@@ -2491,7 +2504,9 @@ static int pmg_prepare(tlfea_newton_t s) {
   m.tried = true;
   tlfea_t10_t d = s->d;
   PmgHost h;
-  if (!pmg_build(d->N, d->E, d->h_conn.data(), d->h_off.data(), d->h_cols.data(), h)) {
+  const bool built = d->kind == kT10 ? pmg_build(d->N, d->E, d->h_conn.data(), d->h_off.data(), d->h_cols.data(), h)
+                                     : pmg_build_ancf(d->N, d->h_off.data(), d->h_cols.data(), h);
+  if (!built) {
     if (s->verbose) std::printf("p-multigrid: the mesh is not a conforming T10 mesh, using the polynomial preconditioner\n");
     return 0;
   }
@@ -2509,7 +2524,7 @@ static int pmg_prepare(tlfea_newton_t s) {
   TRY(dmalloc(&m.d_sc_c, nc)); TRY(dmalloc(&m.d_Dinv_s_c, (size_t)9 * m.Nc));
   TRY(dmalloc(&m.d_eigv_c, nc)); TRY(dmalloc(&m.d_q_c, nc)); TRY(dmalloc(&m.d_p_c, nc));
   TRY(dmalloc(&m.d_f32c, 6 * nc + (size_t)9 * m.Nc));
-  TRY(dmalloc(&m.d_coef, (size_t)2 * kPmgMaxKs + 4 + 2 * kPmgMaxCoarseDeg));
+  TRY(dmalloc(&m.d_coef, (size_t)3 * kPmgMaxKs + 4 + 2 * kPmgMaxCoarseDeg));
   m.ok = true;
   if (s->verbose) std::printf("p-multigrid: %d fine nodes -> %d vertex nodes, %d coarse blocks\n", d->N, m.Nc, m.nnz_c);
   if (s->ar) {
@@ -2742,6 +2757,23 @@ static int pmg_coefficients(tlfea_newton_t s) {
     }
     h[2 * ks] = 0.0; h[2 * ks + 1] = 0.0;
     h[2 * ks + 2] = 0.0; h[2 * ks + 3] = 1.0 / theta;
+    for (int k = 0; k < kPmgMaxKs; k++) h[2 * ks + 4 + k] = 1.0;
+    if (pmg_smoother_kind() != 1 && !m.agg.ok) {
+      // fourth kind: d0 = 4/(3 rho) D^-1 r ; d_k = (2k-1)/(2k+3) d_{k-1} + (8k+4)/((2k+3) rho) D^-1 r_k ; z_k = z_{k-1} + beta_k d_{k-1}
+      static const double kOpt[4][4] = {{1.12500000000000, 0, 0, 0},
+                                        {1.02387287570313, 1.26408905371085, 0, 0},
+                                        {1.00842544782028, 1.08867839208730, 1.33753125909618, 0},
+                                        {1.00391310427285, 1.04035811188593, 1.14863498546254, 1.38268869241000}};
+      const double rho_s = b;
+      for (int k = 0; k < ks; k++) h[2 * ks + 4 + k] = (pmg_smoother_kind() == 4 && ks <= 4) ? kOpt[ks - 1][k] : 1.0;
+      h[0] = 4.0 / (3.0 * rho_s);
+      h[1] = h[2 * ks + 4];                       // z^0 = beta_1 d0 (the init kernels read it: 0 would mean 1)
+      for (int k = 1; k < ks; k++) {
+        h[2 * k] = (2.0 * k - 1.0) / (2.0 * k + 3.0);
+        h[2 * k + 1] = (8.0 * k + 4.0) / ((2.0 * k + 3.0) * rho_s);
+      }
+      h[2 * ks + 3] = 4.0 / (3.0 * rho_s);        // post-smoothing restart: d0' = 4/(3 rho) D^-1 res
+    }
   }
   if (m.agg.ok) {
     // three levels: the vertex level smooths like the fine one (d_coef[8..15], same four pairs), the polynomial
@@ -2883,8 +2915,11 @@ static int pmg_apply(tlfea_newton_t s, const double* d_r, double* d_z, double* r
   // r.z slots weigh owned DOFs only.
   const bool hal = s->halo.on;
   const int Nf = hal ? s->halo.rows(halo_dr(s)) : N;
-  const C32Bnd bnd = hal ? C32Bnd{nullptr, nullptr, s->d_w} : C32Bnd();
-  auto fine = [&](const double* co, bool last) {  // one fine pass; the ping-pong partners swap roles
+  const bool weighted = pmg_smoother_kind() != 1 && !m.agg.ok;  // fourth-kind smoother: z^ += beta_k d
+  const double* betas = cf + pmg_cf_beta(s);
+  auto fine = [&](const double* co, bool last, const double* zw) {  // one fine pass; the ping-pong partners swap roles
+    C32Bnd bnd = hal ? C32Bnd{nullptr, nullptr, s->d_w} : C32Bnd();
+    bnd.zw = weighted ? zw : nullptr;
     launch_cheb32(s->stream, Nf, d->nnz_coef, inc_f, s->d_B8, s->d_B1, bits, Dinv_f, s->d_sc, f_d, co, f_d2, f_z, f_z2, f_r, f_r2,
                   d_r, d_z, rz_part, last, bnd);
     std::swap(f_d, f_d2);
@@ -2892,8 +2927,8 @@ static int pmg_apply(tlfea_newton_t s, const double* d_r, double* d_z, double* r
     std::swap(f_r, f_r2);
   };
   if (!init_done) launch_cheb32_init(s->stream, Nf, Dinv_f, d_r, s->d_sc, cf, f_d, f_z, f_r);
-  for (int k = 1; k < ks; k++) fine(cf + 2 * k, false);
-  fine(cf + o_res, false);
+  for (int k = 1; k < ks; k++) fine(cf + 2 * k, false, betas + k);
+  fine(cf + o_res, false, nullptr);
   // coarse correction
   launch_pmg_restrict_init(s->stream, Nc, m.d_child_off, m.d_child, m.d_child_w, f_r, s->d_sc, m.d_sc_c, Dinv_fc, cf + o_c,
                            c_d, c_z, c_r);
@@ -2926,14 +2961,16 @@ static int pmg_apply(tlfea_newton_t s, const double* d_r, double* d_z, double* r
   } else {
     const int kc = pmg_coarse_degree_eff(s);
     // Overlapping partition: the restricted residual is exact on the owned vertices only.  A refresh makes the three
-    // vectors exact on every ghost layer (G of them); a step gives up one layer, and the prolongation needs ks + 1 layers
-    // at the end (ks fine passes follow) -- so one exchange buys up to G steps, computed redundantly on the overlap.
+    // vectors exact on every ghost layer (G of them).  Rows of Hc are exact up to layer G - 2 (a vertex of layer G - 1 has
+    // mid-edge children in the outermost fine layer, whose rows of H are incomplete), so the first step after a refresh
+    // leaves layers <= G - 2 exact and every further step gives up one more; the prolongation needs ks + 1 layers at the
+    // end (ks fine passes follow).  One exchange buys up to G - 1 steps, computed redundantly on the overlap.
     const int G = s->halo.depth, need_end = ks + 1;
     int valid = 0;
     for (int k = 1; k < kc; k++) {
       if (hal && valid < 1) {
         TRY(halo_refresh_f32(s, 1, G, 3, c_d, c_z, c_r));
-        valid = G;
+        valid = G - 1;
       }
       launch_cheb32(s->stream, Nc, m.nnz_c, inc_c, m.d_B8c, m.d_B1c, bits, Dinv_fc, m.d_sc_c, c_d, cf + o_c + 2 * k, c_d2, c_z,
                     c_z2, c_r, c_r2, d_r, d_z, rz_part, false);
@@ -2947,14 +2984,26 @@ static int pmg_apply(tlfea_newton_t s, const double* d_r, double* d_z, double* r
   launch_pmg_prolong(s->stream, Nf, m.d_par0, m.d_par1, c_z, m.d_sc_c, s->d_sc, f_z, f_d);  // z^ += corr ; d := corr
   // post-smooth: res^ -= Hs corr ; d0' = (SDS)^-1 res^/theta ; z^ += d0'   == one step with coefficients (0, 1/theta),
   // then the ks - 1 Chebyshev steps that complete the polynomial; the last pass returns z = S z^ (fp64) and the r.z slots
-  fine(cf + o_rst, ks == 1);
-  for (int k = 1; k < ks; k++) fine(cf + 2 * k, k == ks - 1);
+  fine(cf + o_rst, ks == 1, betas);
+  for (int k = 1; k < ks; k++) fine(cf + 2 * k, k == ks - 1, betas + k);
   return 0;
 }
 
 // Enqueue CG iteration `it` (parity cur = it & 1 selects the r.z slot pair and, in the fused variant, which of the
 // two direction buffers is read).  Everything an iteration needs from the previous one (alpha, beta, Chebyshev
 // coefficients) is read from device memory, so iterations >= 1 of either parity are the SAME launch sequence.
+// Overlapping partition: ghost layers <= Dr of the CG residual take their owners' values, and the next polynomial's fp32
+// start vectors of those rows are formed from them (the owned rows' came out of the update kernel).
+static int halo_residual_to_ghosts(tlfea_newton_t s) {
+  const int N = s->N, Dr = halo_dr(s);
+  const size_t n = 3 * (size_t)N;
+  if (Dr < 1) return 0;
+  TRY(halo_refresh_f64(s, 0, Dr, 3, s->d_r));
+  float* f = s->d_f32;
+  launch_cheb32_init(s->stream, s->halo.rows(Dr), f + 6 * n, s->d_r, s->d_sc, precond_eff(s) == 2 ? s->pmg.d_coef : s->d_coef,
+                     f, f + 2 * n, f + 4 * n, s->halo.rows(0));
+  return 0;
+}
 static int enqueue_residual_replacement(tlfea_newton_t s, double* d_x);
 static int enqueue_cg_iteration_impl(tlfea_newton_t s, double* d_x, bool first, int cur, bool fused, int deg, bool replace);
 static int enqueue_cg_iteration(tlfea_newton_t s, double* d_x, bool first, int cur, bool fused, int deg,
@@ -2973,13 +3022,16 @@ static int enqueue_cg_iteration_impl(tlfea_newton_t s, double* d_x, bool first, 
   if (fused && cur) std::swap(p_old, p_new);
   // single-GPU fp32 polynomial: its start vectors come out of the previous iteration's update kernel
   const bool fuse_init = deg > 1 && cheb_bits_eff(s) != 64 && !s->ar;
-  // Overlapping partition: the residual is kept exact on ghost layers <= Dr, the direction is refreshed on layers <= Dr + 1
-  // (one neighbour exchange per iteration on this level), launches stop at the rows they can still compute exactly,
-  // dot products weigh owned DOFs (wown) and are summed over ranks: r.z after the preconditioner, p.q after the SpMV; the
-  // r.r slots are summed only when the host tests convergence (pcg()).
+  // Overlapping partition: the CG recurrences (x, r, p, q) live on the OWNED rows.  Two neighbour exchanges per iteration on
+  // this level: layer 1 of the direction z (the SpMV's ghost columns) and layers <= Dr of the updated residual (what the
+  // next V-cycle starts from).  The residual of a ghost is its OWNER's, bit for bit: recomputing it redundantly (q = H p on
+  // ghost rows) differs by round-off, each rank would precondition its own version of r, and at ||r|| ~ 1e-12 ||b|| that
+  // inconsistency stalled the iteration (two config-C slabs: floor 1.6e-12).  Dot products weigh owned DOFs (wown) and
+  // are summed over ranks: r.z after the preconditioner, p.q after the SpMV; the r.r slots only when the host tests
+  // convergence (pcg()).
   const bool hal = s->halo.on;
   const int Dr = hal ? halo_dr(s) : 0;
-  const int Nr = hal ? s->halo.rows(Dr) : N, Np = hal ? s->halo.rows(Dr + 1) : N;
+  const int Nr = hal ? s->halo.rows(0) : N, Np = hal ? s->halo.rows(1) : N;
   const double* wown = hal ? s->d_w : nullptr;
   if (deg > 1) {
     // polynomial preconditioner: z = Cheb(r), r.z slots -> part(cur)   (deg-1 SpMV launches, no reductions)
@@ -2988,7 +3040,7 @@ static int enqueue_cg_iteration_impl(tlfea_newton_t s, double* d_x, bool first, 
     else
       TRY(cheb_apply(s, s->d_r, s->d_zv, part(s, cur), fuse_init && !first));
     if ((s->ar && !(s->d_own && cheb_bits_eff(s) != 64)) || hal) TRY(parts_sum(s, part(s, cur)));
-    if (hal) TRY(halo_refresh_f64(s, 0, Dr + 1, 3, s->d_zv));
+    if (hal) TRY(halo_refresh_f64(s, 0, 1, 3, s->d_zv));
   }
   if (s->profiling) (void)hipEventRecord(s->ev[4], s->stream);
   // beta = rz(cur)/rz(1-cur); p = z + beta p; q = H p; partials of p.q
@@ -3026,6 +3078,7 @@ static int enqueue_cg_iteration_impl(tlfea_newton_t s, double* d_x, bool first, 
       launch_pcg_update_init32(s->stream, Nr, fused ? p_new : p_old, s->d_q, part(s, cur), pq_part, d_x, s->d_r,
                                part(s, 3), s->d_scal + 3, f + 6 * n, s->d_sc,
                                precond_eff(s) == 2 ? s->pmg.d_coef : s->d_coef, f, f + 2 * n, f + 4 * n, wown);
+      if (hal && !replace) TRY(halo_residual_to_ghosts(s));
     } else {
       launch_pcg_update_noz(s->stream, N, w, fused ? p_new : p_old, s->d_q, part(s, cur), pq_part, d_x, s->d_r,
                             part(s, 3), s->d_scal + 3);
@@ -3049,16 +3102,16 @@ static int enqueue_residual_replacement(tlfea_newton_t s, double* d_x) {
   const int N = s->N;
   const size_t n = 3 * (size_t)N;
   // un-fused form: reads x only; its p.q slots go to the scratch slot array of the norms
-  // overlapping partition: x is updated on layers <= Dr like r; one more layer comes from its owners, so H x is exact on
-  // layers <= Dr again
-  const int Nr = s->halo.on ? s->halo.rows(halo_dr(s)) : N;
-  if (s->halo.on) TRY(halo_refresh_f64(s, 0, halo_dr(s) + 1, 3, d_x));
+  // overlapping partition: x lives on the owned rows; layer 1 comes from its owners for the product
+  const int Nr = s->halo.on ? s->halo.rows(0) : N;
+  if (s->halo.on) TRY(halo_refresh_f64(s, 0, 1, 3, d_x));
   launch_spmv_dir_dot(s->stream, Nr, d->inc(), s->d_H, d_x, d_x, 1, part(s, 0), part(s, 1), s->d_cd, s->d_q, part(s, 5), false,
                       s->spmv_nt);
   float* f = s->d_f32;
   launch_residual_replace_init32(s->stream, Nr, s->cur_b, s->d_q, s->d_r, part(s, 3), f + 6 * n, s->d_sc,
                                  precond_eff(s) == 2 ? s->pmg.d_coef : s->d_coef, f, f + 2 * n, f + 4 * n,
                                  s->halo.on ? s->d_w : nullptr);
+  if (s->halo.on) TRY(halo_residual_to_ghosts(s));
   return 0;
 }
 
@@ -3351,7 +3404,15 @@ static int pcg(tlfea_newton_t s, const double* d_b, double* d_x, int* iters_out,
       launch_to_float(s->stream, (size_t)9 * d->nnz_coef, s->d_H, s->d_H32);
     }
     const int R = s->spmv32_every;
+    static const bool pcg_trace = std::getenv("TLFEA_PCG_TRACE") != nullptr;  // tools: test every iteration, print r.z, p.q
+    if (pcg_trace) {
+      first_check = 1;
+      check_every = 1;
+    }
     bool r_is_true = !s->spmv32_now;  // the residual vector is b - H x of the fp64 system (not the recurrence's)
+    // overlapping partition: the start residual r = b of a ghost is its owner's (grad L is evaluated redundantly on the
+    // overlap and differs by round-off)
+    if (s->halo.on) TRY(halo_refresh_f64(s, 0, halo_dr(s), 3, s->d_r));
     if (graphs) TRY(cg_graphs_prepare(s, d_x, fused, deg, bits));
     double indefinite = 0.0;
     HIP_TRY(hipMemsetAsync(s->d_scal + 3, 0, sizeof(double), s->stream));
@@ -3386,6 +3447,15 @@ static int pcg(tlfea_newton_t s, const double* d_b, double* d_x, int* iters_out,
           if (s->halo.on) TRY(parts_sum(s, part(s, 3)));  // the r.r slots are summed over ranks only when tested
           launch_sum_parts(s->stream, part(s, 3), s->d_scal + 2);
           TRY(fetch_scalar2(s, s->d_scal + 2, &rr, &indefinite));  // ||r||^2 and the r.z < 0 flag
+          if (pcg_trace) {
+            double rz = 0.0, pq = 0.0;
+            launch_sum_parts(s->stream, part(s, (it - 1) & 1), s->d_scal);
+            TRY(fetch_scalar(s, s->d_scal, &rz));
+            launch_sum_parts(s->stream, part(s, 2), s->d_scal);
+            TRY(fetch_scalar(s, s->d_scal, &pq));
+            std::fprintf(stderr, "pcg trace: attempt %d it %d rel %.3e rz %.6e pq %.6e indefinite %g\n", attempt, it,
+                         std::sqrt(rr / bb), rz, pq, indefinite);
+          }
           if (!(rr > target) && rr == rr && !r_is_true) {
             // the recurrence says converged: the verdict is the fp64 system's -- replace the residual and test that
             TRY(enqueue_residual_replacement(s, d_x));
@@ -3429,6 +3499,7 @@ static int pcg(tlfea_newton_t s, const double* d_b, double* d_x, int* iters_out,
       }
       launch_pcg_init(s->stream, N, d_b, s->d_Dinv, w, d_x, s->d_r, s->d_zv, part(s, 0), part(s, 4));
       TRY(parts_sum(s, part(s, 0), part(s, 4)));
+      if (s->halo.on) TRY(halo_refresh_f64(s, 0, halo_dr(s), 3, s->d_r));
       HIP_TRY(hipMemsetAsync(s->d_scal + 3, 0, sizeof(double), s->stream));
       indefinite = 0.0;
       it = 0;

@@ -204,7 +204,7 @@ void launch_halo_unpack_f32(hipStream_t s, int n, const int* idx, int dim, int n
                             float* c);
 void launch_to_float(hipStream_t s, size_t n, const double* a, float* b);
 void launch_cheb32_init(hipStream_t s, int N, const float* Dinv_f, const double* r, const double* sc,
-                        const double* coef, float* d, float* z, float* res);
+                        const double* coef, float* d, float* z, float* res, int row0 = 0);
 // Partition-boundary rows of the single-precision polynomial on the multi-GPU path: their Hs d is the SUM over ranks of
 // the ranks' partial rows (launch_spmv32_rows -> all-reduce), handed to the fused step through bsum; w = 1/multiplicity
 // of a DOF in the r.z partials of the last step.
@@ -212,6 +212,7 @@ struct C32Bnd {
   const int* bslot = nullptr;    // [N] slot of a boundary node in the exchange buffer, -1 for interior nodes
   const double* bsum = nullptr;  // [3 slots] summed Hs d of the boundary rows
   const double* w = nullptr;     // [3N] weights of the r.z partials (last step), null = 1
+  const double* zw = nullptr;    // device scalar: z^ += zw d' instead of z^ += d' (fourth-kind Chebyshev smoothers), null = 1
 };
 void launch_cheb32(hipStream_t s, int N, int nnz_coef, const Incidence& inc, const void* B8, const void* B1, int bits,
                    const float* Dinv_f, const double* sc, const float* d_old, const double* coef, float* d_new,

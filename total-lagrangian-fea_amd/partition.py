@@ -325,41 +325,76 @@ def node_owner_from_elements(n_nodes, conn, elem_owner, world):
     return first
 
 
-def halo_slab_structured(wl, config, rank, world, depth):
-    """bench.py weak scaling: rank-local construction of one config-sized x-slab of a bar `world` times as long, extended
-    by `depth` + 1 cell layers into each neighbour.  Owner of a node = the slab whose half-open x-range (lo, hi] holds it
-    (rank 0 also owns x = 0); global ids = lattice index in the long bar, so neighbours agree on every list order.
-    -> (workload dict of the extended slab, HaloPartition)"""
+def _node_noise(gid, seed):
+    """Standard-normal triples that depend on (global node id, seed) only: splitmix64 hashes -> Box-Muller."""
+    def mix(z):
+        z = (z + np.uint64(0x9E3779B97F4A7C15))
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return z ^ (z >> np.uint64(31))
+    with np.errstate(over="ignore"):
+        base = mix(np.asarray(gid, dtype=np.uint64) * np.uint64(6) + np.uint64(seed) * np.uint64(0x2545F4914F6CDD1D))
+        out = np.empty((len(gid), 3))
+        for c in range(3):
+            a = mix(base + np.uint64(2 * c + 1))
+            b = mix(base + np.uint64(2 * c + 2))
+            u1 = ((a >> np.uint64(11)).astype(np.float64) + 0.5) / 9007199254740992.0
+            u2 = ((b >> np.uint64(11)).astype(np.float64) + 0.5) / 9007199254740992.0
+            out[:, c] = np.sqrt(-2.0 * np.log(u1)) * np.cos(2.0 * np.pi * u2)
+    return out
+
+
+def process_grid(world):
+    """Blocks per axis of the weak-scaling series: every rank owns one config-sized block; 8 ranks = BASELINE config E
+    (2 x 2 x 2 blocks of config C: 180 x 120 x 60 cells, 7.8 M elements); other counts: x-slabs."""
+    return {1: (1, 1, 1), 2: (2, 1, 1), 4: (2, 2, 1), 8: (2, 2, 2)}.get(world, (world, 1, 1))
+
+
+def halo_block_structured(wl, config, rank, world, depth, grid=None):
+    """bench.py weak scaling: rank-local construction of one config-sized block of a body of process_grid(world) blocks,
+    extended by `depth` + 1 cell layers into each neighbour.  Owner of a node = the block whose half-open lattice range
+    (lo, hi] holds it along every axis (the first block of an axis also owns its 0 plane); global ids = lattice index in
+    the whole body, so neighbours agree on every list order without communicating.
+    -> (workload dict of the extended block in the partition's local numbering, HaloPartition)"""
     cfg = wl.CONFIGS[config]
-    nx, ny, nz = cfg["cells"]
+    n = np.array(cfg["cells"])
+    pg = np.array(grid if grid is not None else process_grid(world))
+    assert int(np.prod(pg)) == world
+    b = np.array([rank % pg[0], (rank // pg[0]) % pg[1], rank // (pg[0] * pg[1])])
     ext = depth + 1
-    c_lo = max(0, rank * nx - ext)
-    c_hi = min(world * nx, (rank + 1) * nx + ext)
-    w = wl.build(config, cells=(c_hi - c_lo, ny, nz), x_offset_cells=c_lo)
+    c_lo = np.maximum(0, b * n - ext)
+    c_hi = np.minimum(pg * n, (b + 1) * n + ext)
+    w = wl.build(config, cells=tuple(int(v) for v in (c_hi - c_lo)), offset_cells=tuple(int(v) for v in c_lo))
     X = w["X"]
-    lx = cfg["size"][0]
-    hx = lx / nx / 2.0                                             # lattice spacing (corner + mid-edge nodes)
-    ix = np.rint(X[:, 0] / hx).astype(np.int64)
-    iy = np.rint(X[:, 1] / (cfg["size"][1] / ny / 2.0)).astype(np.int64)
-    iz = np.rint(X[:, 2] / (cfg["size"][2] / nz / 2.0)).astype(np.int64)
-    gx, gy = 2 * nx * world + 1, 2 * ny + 1
-    gid = (iz * gy + iy) * gx + ix
-    owner = np.clip((ix - 1) // (2 * nx), 0, world - 1).astype(np.int32)   # (lo, hi]: the plane x = hi belongs to the slab
+    size = np.array(cfg["size"], dtype=np.float64)
+    hx = size / n / 2.0                                            # lattice spacing per axis (corner + mid-edge nodes)
+    idx = np.rint(X / hx).astype(np.int64)                         # global lattice coordinates
+    g = 2 * n * pg + 1
+    gid = (idx[:, 2] * g[1] + idx[:, 1]) * g[0] + idx[:, 0]
+    ob = np.clip((idx - 1) // (2 * n), 0, pg - 1)                  # (lo, hi] per axis
+    owner = ((ob[:, 2] * pg[1] + ob[:, 1]) * pg[0] + ob[:, 0]).astype(np.int32)
     hp = halo_partition(X, w["conn"], owner, gid, rank, world, depth)
-    src = hp.src
     Xl = hp.X
-    # boundary conditions of the LONG bar (test_feat10_resolution.cc:283-312): clamp at x = 0, 5000 N over x = L; every
+    # boundary conditions of the WHOLE body (test_feat10_resolution.cc:283-312): clamp at x = 0, 5000 N over x = L; every
     # rank that holds such a node carries its full value (rows are complete on every rank, nothing is shared out)
     fixed = np.where(np.abs(Xl[:, 0]) < 1e-12)[0].astype(np.int32)
     f_ext = np.zeros(3 * Xl.shape[0])
-    n_face = (2 * ny + 1) * (2 * nz + 1)
-    face = np.where(np.abs(Xl[:, 0] - lx * world) < 1e-9)[0]
+    n_face = int(g[1] * g[2])
+    face = np.where(np.abs(Xl[:, 0] - size[0] * pg[0]) < 1e-9)[0]
     f_ext[3 * face] = 5000.0 / n_face
-    x0 = w["x0"][src].copy()
+    # kernel-timing state (workloads.build): smooth field + seeded noise.  The noise must be a function of the NODE, not of
+    # a rank-local index: a ghost copy whose position differs from its owner's makes the replicated rows differ
+    u = 1e-2 * np.sin(np.pi * Xl / size)
+    x0 = Xl + u + 1e-4 * float(hx.min()) * _node_noise(hp.l2g, 12345)
     x0[fixed] = Xl[fixed]
     wl_loc = dict(X=Xl, conn=hp.conn, fixed=fixed, f_ext=f_ext, x0=x0, material=w["material"], params=w["params"],
-                  desc=w["desc"])
+                  desc=w["desc"], grid=tuple(int(v) for v in pg), block=tuple(int(v) for v in b))
     return wl_loc, hp
+
+
+def halo_slab_structured(wl, config, rank, world, depth):
+    """x-slabs of a bar `world` times as long (the round-2 series; two ranks: identical to the block series)."""
+    return halo_block_structured(wl, config, rank, world, depth, grid=(world, 1, 1))
 
 
 class _DeviceBytes:

@@ -9,6 +9,10 @@ CONFIGS = {
     "B": dict(cells=(12, 12, 12), size=(1.0, 1.0, 1.0), material="neo", desc="T10 cube 12^3x6, neo-Hookean"),
     "C": dict(cells=(90, 60, 30), size=(3.0, 2.0, 1.0), material="svk", desc="T10 bar 90x60x30x6, SVK"),
     "S": dict(cells=(4, 3, 2), size=(3.0, 2.0, 1.0), material="svk", desc="small bar (tests)"),
+    # two config-C slabs end to end on ONE GPU: the single-GPU reference of the 2-rank rehearsal
+    "C2": dict(cells=(180, 60, 30), size=(6.0, 2.0, 1.0), material="svk", desc="T10 bar 180x60x30x6, SVK"),
+    "M": dict(cells=(24, 16, 8), size=(3.0, 2.0, 1.0), material="svk", desc="medium bar (rehearsals)"),
+    "C4": dict(cells=(360, 60, 30), size=(12.0, 2.0, 1.0), material="svk", desc="T10 bar 360x60x30x6, SVK"),
     # ANCF configs (element counts instead of cells)
     "A": dict(kind=3243, n=(30,), dims=(0.5, 0.1, 0.1), material="svk_damped", desc="ANCF-3243 cantilever, 30 beams"),
     "D": dict(kind=3443, n=(512, 500), dims=(0.1, 0.1, 0.01), material="svk", desc="ANCF-3443 plate 512x500"),
@@ -28,17 +32,21 @@ def material(name):
     raise KeyError(name)
 
 
-def build(config, cells=None, x_offset_cells=0):
-    """-> dict(X, conn, fixed, f_ext, x0, material, params).  `cells`/`x_offset_cells` let a rank build its own
-    x-slab of a longer bar (weak scaling): the slab is shifted so that slabs share their interface plane."""
+def build(config, cells=None, x_offset_cells=0, offset_cells=None):
+    """-> dict(X, conn, fixed, f_ext, x0, material, params).  `cells` / `offset_cells` (or `x_offset_cells`) let a rank
+    build its own block of a larger body with the config's cell size (weak scaling): the block is shifted so that blocks
+    share their interface planes."""
     cfg = CONFIGS[config]
     if "kind" in cfg:
         return build_ancf(config)
     nx, ny, nz = cells or cfg["cells"]
     lx, ly, lz = cfg["size"]
-    full_nx = cfg["cells"][0]
-    X, conn = mesh_utils.structured_t10_box(nx, ny, nz, lx * nx / full_nx, ly, lz)
-    X[:, 0] += lx * x_offset_cells / full_nx
+    full_nx, full_ny, full_nz = cfg["cells"]
+    ox, oy, oz = offset_cells if offset_cells is not None else (x_offset_cells, 0, 0)
+    X, conn = mesh_utils.structured_t10_box(nx, ny, nz, lx * nx / full_nx, ly * ny / full_ny, lz * nz / full_nz)
+    X[:, 0] += lx * ox / full_nx
+    X[:, 1] += ly * oy / full_ny
+    X[:, 2] += lz * oz / full_nz
     mat = material(cfg["material"])
     n = X.shape[0]
     f_ext = np.zeros(3 * n)
