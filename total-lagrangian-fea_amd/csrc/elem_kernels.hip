@@ -1234,8 +1234,9 @@ void launch_assemble_rows(hipStream_t s, int N, int S, int maxdeg, const Inciden
 // ------------------------------------------------------------------------------------------------
 namespace {
 constexpr int kAdInst = 6;                            // instances per pass
-constexpr int kAdRec = 26;                            // doubles per staged record
+constexpr int kAdRec = 26;                            // doubles per staged record (St.Venant-Kirchhoff)
 constexpr int kAdRecTotal = kAdInst * kNQ * kAdRec;   // 780 doubles = 6.1 KiB
+constexpr int kAdRecMR = 60;                          // ... Mooney-Rivlin: seven 3-vectors, 2 scalars, c FF^T, F^-T, F, F C
 constexpr int kAdHraw = kAdInst * kNQ * 4;            // 120 doubles
 }  // namespace
 
@@ -1252,8 +1253,14 @@ __device__ __forceinline__ void store_through(double* p, double v, int mode) {
 
 // EXP (tools/tune_assemble.py only): honours the work-skipping experiment bits of store_mode; the shipping instantiation
 // (EXP = 0) keeps the store flavour (bits 0-1) and nothing else, so no environment variable can change what H holds
-template <int ROLLED, int EXP>  // ROLLED 0: points unrolled (234 VGPRs, 2 waves per SIMD), 1: rolled (168 VGPRs, 3 waves per SIMD)
-__global__ __launch_bounds__(64, ROLLED ? 3 : 2) void assemble_direct_kernel(ElemView m, Material mat, double h, RowGroups rg,
+// MR: compressible Mooney-Rivlin (MooneyRivlin.cuh:113-225) instead of St.Venant-Kirchhoff.  The 81-entry tangent tensor
+// A = dP/dF is never formed: the block K_ij[d][e] = sum_JL A[d][J][e][L] h_iJ h_jL is a sum of outer products of
+//   p = F^-T h_i, fa = F h_i (row side, staged per (instance, point) with their scalar coefficients folded in) and
+//   q = F^-T h_j, fb = F h_j, fcb = F C h_j (column side, 27 multiply-adds per lane and point),
+// checked against the tensor form to round-off (tests/test_gpu_parity.py::test_hessian[mr|neo|mr_damped]); the
+// Kelvin-Voigt block has the same rank-1 structure and rides on the same vectors.
+template <int ROLLED, int EXP, int MR = 0>  // ROLLED 0: points unrolled (234 VGPRs, 2 waves per SIMD), 1: rolled (168 VGPRs, 3 waves per SIMD)
+__global__ __launch_bounds__(64, (ROLLED && !MR) ? 3 : 2) void assemble_direct_kernel(ElemView m, Material mat, double h, RowGroups rg,
                                                                const double* __restrict__ Fq,
                                                                const double* __restrict__ mval, double inv_h,
                                                                const int* __restrict__ fixed_slot,
@@ -1261,9 +1268,10 @@ __global__ __launch_bounds__(64, ROLLED ? 3 : 2) void assemble_direct_kernel(Ele
                                                                double* __restrict__ Hval, int store_mode_arg) {
   const int store_mode = EXP ? store_mode_arg : (store_mode_arg & 3);
   extern __shared__ __attribute__((aligned(16))) double lds_ad[];
-  double* rec = lds_ad;                          // [kAdInst][kNQ][kAdRec]
-  double* hraw = lds_ad + kAdRecTotal;           // [kAdInst][kNQ][4]: h_i of the pass's instances
-  double* acc = lds_ad + kAdRecTotal + kAdHraw;  // the group's rows, each in H's layout [d][3 deg]
+  constexpr int REC = MR ? kAdRecMR : kAdRec, REC_TOTAL = kAdInst * kNQ * REC;
+  double* rec = lds_ad;                        // [kAdInst][kNQ][REC]
+  double* hraw = lds_ad + REC_TOTAL;           // [kAdInst][kNQ][4]: h_i of the pass's instances
+  double* acc = lds_ad + REC_TOTAL + kAdHraw;  // the group's rows, each in H's layout [d][3 deg]
   // Blocks b, b + 8, ... share an XCD (round-robin dispatch).  XCD x owns groups [x Gper, (x+1) Gper) and its W resident
   // waves walk that range side by side: wave w takes groups w, w + W, w + 2W, ... -- at any time the XCD works on a
   // window of ~W consecutive groups, i.e. spatial neighbours whose elements overlap, so that the re-reads of an
@@ -1349,7 +1357,7 @@ __global__ __launch_bounds__(64, ROLLED ? 3 : 2) void assemble_direct_kernel(Ele
                     f45 = *reinterpret_cast<const double2*>(Fp + 4), f67 = *reinterpret_cast<const double2*>(Fp + 6);
       F[0] = f01.x; F[1] = f01.y; F[2] = f23.x; F[3] = f23.y; F[4] = f45.x; F[5] = f45.y; F[6] = f67.x; F[7] = f67.y;
       F[8] = Fp[8];
-      if (lane >= 32) s0 = m.detJ[(size_t)es * kNQ + qs];
+      if (MR ? lane < 32 : lane >= 32) s0 = m.detJ[(size_t)es * kNQ + qs];
     }
     // ---- (2) the next pass's indices ------------------------------------------------------------------------
     int code_i_n, pk_n, mb_n, code_s_n;
@@ -1380,7 +1388,55 @@ __global__ __launch_bounds__(64, ROLLED ? 3 : 2) void assemble_direct_kernel(Ele
     }
     wave_sync();  // the previous pass has consumed its records; the accumulators are clear; h_i is published
     // ---- (4) stage the 30 (instance, point) records ---------------------------------------------------------
-    if (stager) {
+    if (MR) {
+      if (stager && lane < 32) {
+        // one lane per (instance, point): invariants of the point, then the row-side vectors with coefficients folded in
+        double* R = rec + (ks * kNQ + qs) * REC;
+        const double* hp = hraw + ks * (kNQ * 4) + 4 * qs;
+        const double a0 = hp[0], a1 = hp[1], a2 = hp[2];
+        const double Fm[3][3] = {{F[0], F[1], F[2]}, {F[3], F[4], F[5]}, {F[6], F[7], F[8]}};
+        MRState ms;
+        mr_state(Fm, mat.mu10, mat.mu01, mat.kappa, ms);
+        const double dV = s0 * m.qw[qs], w = h * dV;
+        double pv[3], fa[3], fca[3];
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+          pv[i] = ms.G[i][0] * a0 + ms.G[i][1] * a1 + ms.G[i][2] * a2;
+          fa[i] = Fm[i][0] * a0 + Fm[i][1] * a1 + Fm[i][2] * a2;
+          fca[i] = ms.FC[i][0] * a0 + ms.FC[i][1] * a1 + ms.FC[i][2] * a2;
+        }
+        const double cX1 = -2.0 / 3.0 * ms.t1 * w, cX2 = -4.0 / 3.0 * ms.t2 * w, cXp = mat.kappa * (2.0 * ms.J - 1.0) * ms.J * w;
+        const double cY = (ms.t1 * ms.I1 / 3.0 + ms.t2 * 2.0 * ms.I2 / 3.0 - ms.t3) * w;
+        const double cZp = (-2.0 / 3.0 * ms.t1 - 4.0 / 3.0 * ms.t2 * ms.I1) * w;
+        const double cU = 2.0 * ms.t2 * w + mat.lamd * dV;   // fa (x) fb: elastic + lambda_d (FEAT10DataFunc.cuh:695-762)
+        const double cV = -ms.t2 * w + mat.eta * dV;         // fb (x) fa and (h_i.h_j) F F^T: elastic + eta
+        R[0] = a0; R[1] = a1; R[2] = a2;
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+          const double t1a = fa[i] - (ms.I1 / 3.0) * pv[i];
+          const double t2a = ms.I1 * fa[i] - fca[i] - (2.0 * ms.I2 / 3.0) * pv[i];
+          R[3 + i] = cX1 * t1a + cX2 * t2a + cXp * pv[i];
+          R[6 + i] = cY * pv[i];
+          R[9 + i] = cZp * pv[i] + cU * fa[i];
+          R[12 + i] = (4.0 / 3.0 * ms.t2 * w) * pv[i];
+          R[15 + i] = cV * fa[i];
+          R[18 + i] = fa[i];
+        }
+        R[21] = w * (ms.t1 + ms.t2 * ms.I1);
+        R[22] = -ms.t2 * w;
+        R[23] = 0.0;
+        R[24] = cV * ms.FFT[0][0]; R[25] = cV * ms.FFT[0][1]; R[26] = cV * ms.FFT[0][2];
+        R[27] = cV * ms.FFT[1][1]; R[28] = cV * ms.FFT[1][2]; R[29] = cV * ms.FFT[2][2];
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+          for (int jj = 0; jj < 3; jj++) {
+            R[30 + 3 * i + jj] = ms.G[i][jj];
+            R[39 + 3 * i + jj] = Fm[i][jj];
+            R[48 + 3 * i + jj] = ms.FC[i][jj];
+          }
+      }
+    } else if (stager) {
       double* R = rec + (ks * kNQ + qs) * kAdRec;
       if (lane < 32) {
         const double* hp = hraw + ks * (kNQ * 4) + 4 * qs;
@@ -1418,10 +1474,38 @@ __global__ __launch_bounds__(64, ROLLED ? 3 : 2) void assemble_direct_kernel(Ele
     // ---- (5) this lane's block: sum over the 5 points, add into the row accumulator --------------------------
     double a00 = 0, a01 = 0, a02 = 0, a10 = 0, a11 = 0, a12 = 0, a20 = 0, a21 = 0, a22 = 0;
     double cds = mh * inv_h;  // M/h on the xyz-diagonal (SyncedNewton.cu:214-259), carried by the block's first item
-    const double2* Rk = reinterpret_cast<const double2*>(rec + (size_t)min(k, kAdInst - 1) * kNQ * kAdRec);
+    const double2* Rk = reinterpret_cast<const double2*>(rec + (size_t)min(k, kAdInst - 1) * kNQ * REC);
     // ROLLED: one point per trip, h_j[q] read through the register index (166 VGPRs, 3 waves per SIMD); unrolled the
     // scheduler overlaps the points' LDS reads with arithmetic at 230 VGPRs, 2 waves per SIMD
     const int nq = (store_mode & 512) ? 0 : kNQ;
+    if (MR) {
+#pragma unroll 1
+      for (int q = 0; q < nq; q++) {
+        const double* R = rec + ((size_t)min(k, kAdInst - 1) * kNQ + q) * REC;
+        const double b0 = hj[q][0], b1 = hj[q][1], b2 = hj[q][2];
+        double qv[3], fb[3], fcb[3];
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+          qv[i] = R[30 + 3 * i] * b0 + R[31 + 3 * i] * b1 + R[32 + 3 * i] * b2;
+          fb[i] = R[39 + 3 * i] * b0 + R[40 + 3 * i] * b1 + R[41 + 3 * i] * b2;
+          fcb[i] = R[48 + 3 * i] * b0 + R[49 + 3 * i] * b1 + R[50 + 3 * i] * b2;
+        }
+        const double ab = R[0] * b0 + R[1] * b1 + R[2] * b2;
+        const double fafb = R[18] * fb[0] + R[19] * fb[1] + R[20] * fb[2];
+        cds += R[21] * ab + R[22] * fafb;
+        const double X0 = R[3], X1 = R[4], X2 = R[5], Y0 = R[6], Y1 = R[7], Y2 = R[8], Z0 = R[9], Z1 = R[10], Z2 = R[11];
+        const double W0 = R[12], W1 = R[13], W2 = R[14], V0 = R[15], V1 = R[16], V2 = R[17];
+        a00 += X0 * qv[0] + qv[0] * Y0 + Z0 * fb[0] + W0 * fcb[0] + fb[0] * V0 + ab * R[24];
+        a01 += X0 * qv[1] + qv[0] * Y1 + Z0 * fb[1] + W0 * fcb[1] + fb[0] * V1 + ab * R[25];
+        a02 += X0 * qv[2] + qv[0] * Y2 + Z0 * fb[2] + W0 * fcb[2] + fb[0] * V2 + ab * R[26];
+        a10 += X1 * qv[0] + qv[1] * Y0 + Z1 * fb[0] + W1 * fcb[0] + fb[1] * V0 + ab * R[25];
+        a11 += X1 * qv[1] + qv[1] * Y1 + Z1 * fb[1] + W1 * fcb[1] + fb[1] * V1 + ab * R[27];
+        a12 += X1 * qv[2] + qv[1] * Y2 + Z1 * fb[2] + W1 * fcb[2] + fb[1] * V2 + ab * R[28];
+        a20 += X2 * qv[0] + qv[2] * Y0 + Z2 * fb[0] + W2 * fcb[0] + fb[2] * V0 + ab * R[26];
+        a21 += X2 * qv[1] + qv[2] * Y1 + Z2 * fb[1] + W2 * fcb[1] + fb[2] * V1 + ab * R[28];
+        a22 += X2 * qv[2] + qv[2] * Y2 + Z2 * fb[2] + W2 * fcb[2] + fb[2] * V2 + ab * R[29];
+      }
+    } else
 #pragma unroll(ROLLED ? 1 : kNQ)
     for (int q = 0; q < nq; q++) {
       const double2* R2 = Rk + q * (kAdRec / 2);
@@ -1492,6 +1576,33 @@ __global__ __launch_bounds__(64, ROLLED ? 3 : 2) void assemble_direct_kernel(Ele
 void launch_assemble_direct(hipStream_t s, const ElemView& m, const Material& mat, double h, const RowGroups& rg,
                             const double* Fq, const double* mval, const int* fixed_slot, const double* nw,
                             double penalty, double* Hval) {
+  if (mat.model == kMooneyRivlin) {
+    // Mooney-Rivlin: the same walk with 60-double records (assemble_direct_kernel<1, 0, 1>); one form, no tuning knobs
+    const size_t lds = (size_t)(kAdInst * kNQ * kAdRecMR + kAdHraw + rg.acc_max) * sizeof(double);
+    const void* fn = (const void*)assemble_direct_kernel<1, 0, 1>;
+    static size_t lds_attr_mr = 0;
+    if (lds > 64 * 1024 && lds > lds_attr_mr) {
+      (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      lds_attr_mr = lds;
+    }
+    static int n_cu_mr = 0, occ_mr = 0;
+    static size_t occ_lds_mr = ~(size_t)0;
+    if (!n_cu_mr) {
+      int dev = 0;
+      (void)hipGetDevice(&dev);
+      (void)hipDeviceGetAttribute(&n_cu_mr, hipDeviceAttributeMultiprocessorCount, dev);
+      if (n_cu_mr <= 0) n_cu_mr = 256;
+    }
+    if (occ_lds_mr != lds) {
+      int o = 0;
+      occ_mr = (hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, fn, 64, lds) == hipSuccess && o > 0) ? o : 4;
+      occ_lds_mr = lds;
+    }
+    const int per_xcd = std::max(1, std::min((n_cu_mr / 8) * std::min(occ_mr, 8), (rg.G + 7) / 8));
+    hipLaunchKernelGGL((assemble_direct_kernel<1, 0, 1>), dim3(8 * per_xcd), dim3(64), lds, s, m, mat, h, rg, Fq, mval, 1.0 / h,
+                       fixed_slot, nw, penalty, Hval, 0);
+    return;
+  }
   const size_t lds = (size_t)(kAdRecTotal + kAdHraw + rg.acc_max) * sizeof(double);
   static size_t lds_attr = 0;
   if (lds > 64 * 1024 && lds > lds_attr) {
@@ -1778,6 +1889,9 @@ __global__ __launch_bounds__(64, 2) void assemble_affine_kernel(RowGroups4 rg, A
     double R0[9], D[4][9];
     // F of the point comes from the staged record; F F^T, tr E and with them B1 F F^T and C0 are formed here: 24 operations
     // per point instead of three more 16-byte reads and 48 more staged bytes per point and instance.
+    // D[r] is evaluated at the point where vertex (n + r) & 3 has L = 1/2 -- a lane-RELATIVE order (the four outer points
+    // of the Keast rule carry one weight, checked by the launcher), so that the share of the mid-edge column (n, n + r)
+    // sits in the same register of every lane and the two lanes of such a column can be paired by a quad permute below.
     auto block = [&](const int sdx, double (&out)[9]) __attribute__((always_inline)) {
       const double2* R2 = reinterpret_cast<const double2*>(Sk + 16 + 10 * sdx);
       const double2 r0 = R2[0], r1 = R2[1], r2 = R2[2], r3 = R2[3], r4 = R2[4];
@@ -1800,14 +1914,16 @@ __global__ __launch_bounds__(64, 2) void assemble_affine_kernel(RowGroups4 rg, A
         al = mid ? (B == p ? 2.0 : 2.0 / 3.0) : (A == p ? 1.0 : -1.0 / 3.0);
         be = mid ? (A == p ? 2.0 : 2.0 / 3.0) : 0.0;
       }
+      const int ci = sdx == 0 ? 0 : 1;  // the centroid point | the four outer points (one weight)
       const double h0 = al * gA[0] + be * gB[0], h1 = al * gA[1] + be * gB[1], h2 = al * gA[2] + be * gB[2];
       const double fi0 = F0 * h0 + F1 * h1 + F2 * h2, fi1 = F3 * h0 + F4 * h1 + F5 * h2, fi2 = F6 * h0 + F7 * h1 + F8 * h2;
       const double b0 = F0 * gn[0] + F1 * gn[1] + F2 * gn[2], b1 = F3 * gn[0] + F4 * gn[1] + F5 * gn[2],
                    b2 = F6 * gn[0] + F7 * gn[1] + F8 * gn[2];
       const double sv = h0 * gn[0] + h1 * gn[1] + h2 * gn[2];  // grad N_i . g_n
       const double tv = fi0 * b0 + fi1 * b1 + fi2 * b2;        // F grad N_i . F g_n
-      const double A1 = detJ * ac.cA[sdx], B1 = detJ * ac.cB[sdx], C1 = detJ * ac.cC[sdx];
-      const double C0 = detJ * ac.cL[sdx] * trE - C1;          // dV h (lambda tr E - mu)   (SVK.cuh:35-55)
+      const double A1 = detJ * (ci ? ac.cA[1] : ac.cA[0]), B1 = detJ * (ci ? ac.cB[1] : ac.cB[0]),
+                   C1 = detJ * (ci ? ac.cC[1] : ac.cC[0]);
+      const double C0 = detJ * (ci ? ac.cL[1] : ac.cL[0]) * trE - C1;  // dV h (lambda tr E - mu)   (SVK.cuh:35-55)
       const double cd = C0 * sv + C1 * tv;
       const double sb1 = sv * B1;                              // (grad N_i . g_n) B1 F F^T
       const double u0 = A1 * fi0, u1 = A1 * fi1, u2 = A1 * fi2;
@@ -1823,42 +1939,72 @@ __global__ __launch_bounds__(64, 2) void assemble_affine_kernel(RowGroups4 rg, A
       out[8] = u2 * b2 + w2 * fi2 + sb1 * T22 + cd;
     };
     block(0, R0);
-    block(1, D[0]);
-    block(2, D[1]);
-    block(3, D[2]);
-    block(4, D[3]);
+    block(1 + n, D[0]);
+    block(1 + ((n + 1) & 3), D[1]);
+    block(1 + ((n + 2) & 3), D[2]);
+    block(1 + ((n + 3) & 3), D[3]);
     // the next pass's records: issued after the block evaluations (36 registers less while they run; measured no slower
     // than before them): the adds, the rows streaming out and the next pass's top cover the round trip
     fetch(head_n);
     // M/h (SyncedNewton.cu:214-259): on an affine element M_e(i, j) = rho det J sum_q w_q N_i N_j (FEAT10Data.cu:206-278)
-    // is det J times a constant of the rule; the two lanes of a mid-edge column add half of it each
-    double cmv[4];
+    // is det J times a constant of the rule; the two lanes of a mid-edge column carry half of it each
+    double cmv[4];  // relative order: column vertex n, mid-edge (n, n + 1), (n, n + 2), (n, n + 3)
     {
-      const double2* cq = reinterpret_cast<const double2*>(cml + il * 16 + 4 * n);
-      const double2 c01 = cq[0], c23 = cq[1];
-      cmv[0] = detJ * c01.x; cmv[1] = detJ * c01.y; cmv[2] = detJ * c23.x; cmv[3] = detJ * c23.y;
+      const double* cq = cml + il * 16 + 4 * n;
+#pragma unroll
+      for (int r = 0; r < 4; r++) cmv[r] = detJ * cq[(n + r) & 3];
     }
     TLFEA_TICK(3)  // five block evaluations
-    // ---- (5) the lane's four blocks into the row accumulator ------------------------------------------------------
-    if (k < cnt && !(store_mode & 1024)) {
-      const int stride = head.y;
+    // ---- (5) the lane's blocks into the row accumulator ------------------------------------------------------------
+    // column "vertex n": 4/3 D_n - 1/3 S; column "mid-edge (n, p)": (4/3 D_p + 2/3 S + R0) of lane n PLUS the mirror image
+    // of lane p.  The two shares are paired in registers -- lane n takes lane n + 1's share of edge (n, n + 1) and, for
+    // n < 2, lane n + 2's share of edge (n, n + 2), by quad permutes -- so an instance costs 10 accumulator blocks
+    // (27 ds_add_f64 per lane at most) instead of 16 (36).
+    {
       double S1[9];
 #pragma unroll
       for (int t = 0; t < 9; t++) S1[t] = (D[0][t] + D[1][t]) + (D[2][t] + D[3][t]);
+#pragma unroll
+      for (int t = 0; t < 9; t++) {
+        const double dg = (t == 0 || t == 4 || t == 8) ? 1.0 : 0.0;
+        const double m2 = (2.0 / 3.0) * S1[t] + R0[t];
+        D[0][t] = (4.0 / 3.0) * D[0][t] - (1.0 / 3.0) * S1[t] + dg * cmv[0];
+        D[1][t] = (4.0 / 3.0) * D[1][t] + m2 + dg * cmv[1];
+        D[2][t] = (4.0 / 3.0) * D[2][t] + m2 + dg * cmv[2];
+        D[3][t] = (4.0 / 3.0) * D[3][t] + m2 + dg * cmv[3];
+      }
+      // quad permutes: lane n reads lane (n + 1) & 3 (ctrl 0x39 = [1,2,3,0]) / lane (n + 2) & 3 (0x4E = [2,3,0,1])
+      auto from_next = [](double v) __attribute__((always_inline)) {
+        const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), 0x39, 0xf, 0xf, false);
+        const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), 0x39, 0xf, 0xf, false);
+        return __hiloint2double(hi, lo);
+      };
+      auto from_opposite = [](double v) __attribute__((always_inline)) {
+        const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), 0x4E, 0xf, 0xf, false);
+        const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), 0x4E, 0xf, 0xf, false);
+        return __hiloint2double(hi, lo);
+      };
+#pragma unroll
+      for (int t = 0; t < 9; t++) {
+        D[1][t] += from_next(D[3][t]);      // lane n + 1's share towards n sits in ITS D[3]
+        D[2][t] += from_opposite(D[2][t]);  // lane n + 2's share towards n sits in ITS D[2]
+      }
+    }
+    if (k < cnt && !(store_mode & 1024)) {
+      const int stride = head.y;
+      const unsigned long long e64 = ((unsigned long long)(unsigned)ent.y << 32) | (unsigned)ent.x;
 #define TLFEA_LDS_ADD(p, v) (void)__hip_atomic_fetch_add((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
 #pragma unroll
-      for (int p = 0; p < 4; p++) {
-        const int word = ((p < 2 ? ent.x : ent.y) >> (16 * (p & 1))) & 0xffff;
+      for (int r = 0; r < 3; r++) {
+        if (r == 2 && n >= 2) break;        // edges (0, 2) and (1, 3) are added by lanes 0 and 1
+        const int pcol = (n + r) & 3;
+        const int word = (int)((e64 >> (16 * pcol)) & 0xffffull);
         double* ap = acc + 3 * word;
-        if (store_mode & 4096) ap = acc + 3 * (lane + 64 * p);  // timing experiment: no two lanes add to one address
-        const double ks = p == n ? -1.0 / 3.0 : 2.0 / 3.0, km = p == n ? 0.0 : 1.0;
+        if (store_mode & 4096) ap = acc + 3 * (lane + 64 * r);  // timing experiment: no two lanes add to one address
 #pragma unroll
-        for (int r = 0; r < 3; r++)
+        for (int rr = 0; rr < 3; rr++)
 #pragma unroll
-          for (int c = 0; c < 3; c++) {
-            const int t = 3 * r + c;
-            TLFEA_LDS_ADD(ap + r * stride + c, (4.0 / 3.0) * D[p][t] + (ks * S1[t] + km * R0[t]) + (r == c ? cmv[p] : 0.0));
-          }
+          for (int c = 0; c < 3; c++) TLFEA_LDS_ADD(ap + rr * stride + c, D[r][3 * rr + c]);
       }
 #undef TLFEA_LDS_ADD
     }

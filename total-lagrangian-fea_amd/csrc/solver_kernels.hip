@@ -16,6 +16,35 @@ namespace tlfea {
 // wave64 butterfly + one LDS hop: 1-2 barriers per workgroup sum instead of a 9-barrier tree (these
 // kernels are latency-, not bandwidth-bound on small meshes).  Orders are fixed -> bitwise reproducible.
 bool row_map_tiled();
+// XCD-aware row sweep of the two streaming kernels (polynomial step, SpMV).  Workgroups are dealt round-robin over the 8
+// XCDs, so the workgroups b with the same b & 7 share one L2.  They take ONE contiguous eighth of the rows and sweep it in
+// tiles together, so that each XCD's gathers stay inside its own eighth of the vector (plus the neighbouring planes).
+// Measured at config C (round 3, A/B on one box): the cache-resident vertex level gains 8 % (15.6 -> 14.3 us per step); the
+// fine level and the fp64 SpMV do NOT (262 -> 266 us, 752 -> 771 us: their 1.4x traffic is not cross-XCD duplication of the
+// vector), so the eighths are used between 64 k and 600 k rows only.  TLFEA_XCD_ROWS=0 | 2: never | on every size.
+static int xcd_rows_mode() {
+  static const int m = std::getenv("TLFEA_XCD_ROWS") ? std::atoi(std::getenv("TLFEA_XCD_ROWS")) : 1;
+  return m;
+}
+struct RowSweep {  // rows of this lane group: i = first, first + stride, ... < end
+  int first, end, stride;
+};
+__device__ __forceinline__ RowSweep row_sweep(int N, int G, int grp, int xcd) {
+  RowSweep r;
+  if (xcd && (gridDim.x & 7) == 0 && N >= 65536 && (xcd == 2 || N <= 600000)) {
+    const int nb = gridDim.x >> 3, lb = blockIdx.x >> 3, x = blockIdx.x & 7;
+    const int per = (((N + 7) >> 3) + G - 1) / G * G;  // an eighth, rounded to whole tiles
+    const int r0 = x * per;
+    r.end = min(N, r0 + per);
+    r.first = r0 + lb * G + grp;
+    r.stride = nb * G;
+  } else {
+    r.first = blockIdx.x * G + grp;
+    r.end = N;
+    r.stride = gridDim.x * G;
+  }
+  return r;
+}
 
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
@@ -201,9 +230,10 @@ __global__ __launch_bounds__(1024) void spmv_dir_dot_kernel(int N, Incidence inc
   // tiled: the workgroups sweep the rows together (kGroups rows each, round robin) so that the chip gathers from a
   // narrow window of the vector that stays in L2; otherwise one contiguous chunk per workgroup (see cheb_lp_kernel)
   const int rows_per_block = (N + gridDim.x - 1) / gridDim.x;
-  const int r0 = tiled ? blockIdx.x * kGroups : blockIdx.x * rows_per_block;
-  const int r1 = tiled ? N : min(N, r0 + rows_per_block);
-  const int stride = tiled ? gridDim.x * kGroups : kGroups;
+  const RowSweep rs = row_sweep(N, kGroups, hw, tiled >> 1);
+  const int r0 = (tiled & 1) ? rs.first - hw : blockIdx.x * rows_per_block;
+  const int r1 = (tiled & 1) ? rs.end : min(N, r0 + rows_per_block);
+  const int stride = (tiled & 1) ? rs.stride : kGroups;
   double pq = 0.0;
   for (int i = r0 + hw; i < r1; i += stride) {
     const int off0 = inc.off[i], deg = inc.off[i + 1] - off0, row = 3 * deg;
@@ -273,7 +303,7 @@ void launch_spmv_dir_dot(hipStream_t s, int N, const Incidence& inc, const doubl
                          const double* p_old, int first, const double* rz_part_old, const double* rz_part_new,
                          double* p_new, double* q, double* pq_part, bool fused, bool nt, const double* wown) {
   const dim3 g(spmv_grid(N)), b(1024);
-  const int tiled = row_map_tiled() ? 1 : 0;
+  const int tiled = (row_map_tiled() ? 1 : 0) | (xcd_rows_mode() << 1);
   static const int lanes = std::getenv("TLFEA_SPMV_LANES") ? std::atoi(std::getenv("TLFEA_SPMV_LANES")) : 32;
 #define TLFEA_SPMV(F, T, L)                                                                                       \
   hipLaunchKernelGGL((spmv_dir_dot_kernel<double, F, T, L>), g, b, 0, s, N, inc, Hval, z, p_old, first, rz_part_old,  \
@@ -293,7 +323,7 @@ void launch_spmv_dir_dot_f32(hipStream_t s, int N, const Incidence& inc, const f
                              const double* p_old, int first, const double* rz_part_old, const double* rz_part_new,
                              double* p_new, double* q, double* pq_part, bool fused, const double* wown) {
   const dim3 g(spmv_grid(N)), b(1024);
-  const int tiled = row_map_tiled() ? 1 : 0;
+  const int tiled = (row_map_tiled() ? 1 : 0) | (xcd_rows_mode() << 1);
   if (fused)
     hipLaunchKernelGGL((spmv_dir_dot_kernel<float, true, false, 32>), g, b, 0, s, N, inc, Hval32, z, p_old, first,
                        rz_part_old, rz_part_new, p_new, q, pq_part, tiled, wown);
@@ -896,8 +926,9 @@ __global__ __launch_bounds__(TPB) void cheb32_kernel(int N, Incidence inc, const
   constexpr int G = TPB / L;
   const int lane = threadIdx.x & (L - 1), grp = threadIdx.x / L;
   const int c = lane < 3 ? lane : 0;
-  const int r1 = N, stride = gridDim.x * G;
-  int i = blockIdx.x * G + grp;
+  const RowSweep rsw = row_sweep(N, G, grp, bnd.xcd);
+  const int r1 = rsw.end, stride = rsw.stride;
+  int i = rsw.first;
   double rz = 0.0;
   for (; i < r1; i += (TWO ? 2 : 1) * stride) {
     const bool two = TWO && i + stride < r1;
@@ -1037,6 +1068,7 @@ static void launch_cheb32_t(hipStream_t s, int N, const Incidence& inc, const vo
                             const float* Dinv_f, const double* sc, const float* d_old, const double* coef,
                             float* d_new, const float* z, float* z_new, const float* res, float* res_new,
                             const double* r, double* z_out, double* rz_part, bool last, C32Bnd bnd) {
+  bnd.xcd = xcd_rows_mode();
 #define TLFEA_C32_ARGS N, inc, (const Blk8<T>*)B8, (const T*)B1, Dinv_f, sc, d_old, coef, d_new, z, z_new, res, res_new, r, z_out, rz_part, bnd
   if (last) {
     constexpr int TPB = 1024, G = TPB / LL;

@@ -1226,6 +1226,13 @@ extern "C" double* tlfea_newton_velocity_guess_device_ptr(tlfea_newton_t s) { re
 // ---- work lists of the fused tangent + assembly kernel (T10) -------------------------------------------------------------
 // Both functions can run again after CalcDnDuPre re-referenced the mesh (refresh_geometry): the affine form's vertex
 // gradients, det J and its 'every element is straight-sided' decision are derived from the grad N / det J of ONE call.
+// per-point F records of the residual launch: [E][5][10] (affine form) or [E][Q][9] (general form) -- one buffer fits both
+// (the material, hence the form, may be switched between solves)
+static int ensure_fq(tlfea_newton_t s) {
+  if (s->d_Fq) return 0;
+  tlfea_t10_t d = s->d;
+  return dmalloc(&s->d_Fq, std::max((size_t)d->Epad * 50, (size_t)d->E * d->Q * 9));
+}
 static void free_ints(int** p, int n) {
   for (int k = 0; k < n; k++)
     if (p[k]) {
@@ -1255,6 +1262,9 @@ static int setup_affine_form(tlfea_newton_t s, bool* affine_out) {
     else if (n2 == 1 && n6 == 3 && av.qv[v2] < 0) av.qv[v2] = q;
     else rule_ok = false;
   }
+  // the kernel evaluates the four outer points in a lane-relative order: they must carry one weight (Keast: 9/20 x 1/6)
+  for (int p = 1; p < 4 && rule_ok; p++)
+    if (std::fabs(d->h_qw[av.qv[p]] - d->h_qw[av.qv[0]]) > 1e-15 * std::fabs(d->h_qw[av.qv[0]])) rule_ok = false;
   if (!rule_ok) return 0;
   double* d_dev = nullptr;
   if (!s->d_gvec) TRY(dmalloc(&s->d_gvec, (size_t)d->E * 16));
@@ -1303,9 +1313,7 @@ static int setup_affine_form(tlfea_newton_t s, bool* affine_out) {
     TRY(dmalloc(&s->d_cmass, 160));
     HIP_TRY(hipMemcpy(s->d_cmass, cm, sizeof(cm), hipMemcpyHostToDevice));
   }
-  if (s->d_Fq) (void)hipFree(s->d_Fq);
-  s->d_Fq = nullptr;
-  TRY(dmalloc(&s->d_Fq, (size_t)d->Epad * 50));  // [E][5][10]: F per point, centroid point first
+  TRY(ensure_fq(s));  // [E][5][10]: F per point, centroid point first
   s->rg_ok = s->affine_ok = *affine_out = true;
   return 0;
 }
@@ -1327,9 +1335,7 @@ static int setup_general_form(tlfea_newton_t s) {
     s->rg = RowGroups{rh.G(), d->E * d->S, rh.acc_max, s->d_rg[0], reinterpret_cast<const int4*>(s->d_rg[1]),
                       reinterpret_cast<const int4*>(s->d_rg[2]), s->d_rg[3], s->d_rg[4], s->d_rg[5]};
   }
-  if (s->d_Fq) (void)hipFree(s->d_Fq);
-  s->d_Fq = nullptr;
-  TRY(dmalloc(&s->d_Fq, (size_t)d->E * d->Q * 9));
+  TRY(ensure_fq(s));
   s->rg_ok = true;
   return 0;
 }
@@ -2058,9 +2064,24 @@ static bool lincons_on(tlfea_newton_t s) { return s->n_constraints > 0 && s->d->
 // the fused tangent + assembly kernel covers T10 with St.Venant-Kirchhoff (+ Kelvin-Voigt); Mooney-Rivlin and the
 // ANCF kinds keep the element-block buffer (tangent_blocks + assemble_rows)
 static bool use_direct(tlfea_newton_t s) {
-  return s->rg_ok && s->asm_mode != 1 && s->d->kind == kT10 && s->d->mat.model == kSVK;
+  if (!(s->rg_ok && s->asm_mode != 1 && s->d->kind == kT10)) return false;
+  if (s->d->mat.model == kSVK) return s->affine_ok || s->d_rg[0] != nullptr;
+  return s->d->mat.model == kMooneyRivlin && s->d_rg[0] != nullptr;   // general-form work lists (ensure_form_for_material)
 }
-static double fq_h(tlfea_newton_t s) { return s->affine_ok ? s->prm.time_step : 0.0; }
+// the affine-element form exists for St.Venant-Kirchhoff; Mooney-Rivlin takes the general form (its own instantiation)
+static bool affine_now(tlfea_newton_t s) { return s->affine_ok && s->d->mat.model == kSVK; }
+// Mooney-Rivlin on a mesh whose work lists were built for the affine form only: the general form's lists on first use
+static int ensure_form_for_material(tlfea_newton_t s) {
+  if (s->rg_ok && s->asm_mode != 1 && s->d->kind == kT10 && !affine_now(s) && !s->d_rg[0]) {
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    const bool keep_affine = s->affine_ok;
+    TRY(setup_general_form(s));
+    s->affine_ok = keep_affine;
+    if (!s->d_rg[0]) s->rg_ok = keep_affine;  // no general lists (odd mesh): Mooney-Rivlin keeps the two-kernel path
+  }
+  return 0;
+}
+static double fq_h(tlfea_newton_t s) { return affine_now(s) ? s->prm.time_step : 0.0; }
 static int fq_slots(tlfea_newton_t s);
 // residual launch of the Newton path (the point records it leaves for the fused assembly follow the assembly's form)
 static void launch_residual_newton(tlfea_newton_t s, double* Fq, const MassTerm* mt) {
@@ -2071,7 +2092,7 @@ static void launch_residual_newton(tlfea_newton_t s, double* Fq, const MassTerm*
 // record slots of the affine assembly: point q0 first, then the points where vertex 0, 1, 2, 3 has L = 1/2
 static int fq_slots(tlfea_newton_t s) {
   int w = 0;
-  if (s->affine_ok) {
+  if (affine_now(s)) {
     w |= 0 << (4 * s->av.q0);
     for (int p = 0; p < 4; p++) w |= (p + 1) << (4 * s->av.qv[p]);
   }
@@ -2081,7 +2102,7 @@ static void launch_fused(tlfea_newton_t s) {
   tlfea_t10_t d = s->d;
   const tlfea_newton_params& p = s->prm;
   const int* fixed = pinned_on(s) ? d->d_fixed_slot : nullptr;
-  if (s->affine_ok)
+  if (affine_now(s))
     launch_assemble_affine(s->stream, d->view(), d->mat, p.time_step, s->rg4, s->av, s->d_Fq, s->d_cmass,
                            d->mass_rho0 > 0.0 ? d->mass_rho0 : 0.0, fixed, s->d_nw, p.time_step * p.time_step * p.rho,
                            s->d_H);
@@ -2118,6 +2139,7 @@ static int fill_mass_term(tlfea_newton_t s, MassTerm& mt) {
 static int eval_gradient(tlfea_newton_t s, double* norm_g) {
   tlfea_t10_t d = s->d;
   TRY(refresh_geometry(s));
+  TRY(ensure_form_for_material(s));
   const tlfea_newton_params& p = s->prm;
   const bool mir = mass_in_residual(s);
   {
@@ -2164,6 +2186,9 @@ static int assemble(tlfea_newton_t s, bool fq_fresh = true) {
     const long seen = s->geom_gen_seen;
     TRY(refresh_geometry(s));
     if (seen != s->geom_gen_seen) fq_fresh = false;  // the point records follow the assembly's form: rewrite them
+    const bool had_general = s->d_rg[0] != nullptr;
+    TRY(ensure_form_for_material(s));
+    if (!had_general && s->d_rg[0]) fq_fresh = false;
   }
   const tlfea_newton_params& p = s->prm;
   const bool pinned = pinned_on(s);
@@ -3600,7 +3625,8 @@ extern "C" int tlfea_newton_get_precond(tlfea_newton_t s) {  // 1 Chebyshev poly
 extern "C" int tlfea_newton_get_assembly_mode(tlfea_newton_t s) {
   if (!s) return 0;
   if (tlfea_newton_analyze_hessian_sparsity(s)) return 0;
-  return use_direct(s) ? (s->affine_ok ? 3 : 2) : 1;
+  if (ensure_form_for_material(s)) return 0;
+  return (use_direct(s) && (affine_now(s) || s->d_rg[0])) ? (affine_now(s) ? 3 : 2) : 1;
 }
 extern "C" int tlfea_newton_get_linsolve_info(tlfea_newton_t s, int* cheb_degree, int* cheb_bits, int* cheb_vector_bits) {
   if (!s) return fail("null argument");
@@ -3803,6 +3829,7 @@ extern "C" int tlfea_newton_solve(tlfea_newton_t s) {
   TRY(begin_step(s));
   int n_outer = 0, n_newton = 0, pcg_total = 0;
   double norm_g = 0.0, norm_c = 0.0;
+  const int fail_hook = std::getenv("TLFEA_TEST_FAIL_LINSOLVE") ? std::atoi(std::getenv("TLFEA_TEST_FAIL_LINSOLVE")) : -1;
   auto run = [&]() -> int {
     for (int outer = 0; outer < p.max_outer; ++outer) {
       n_outer++;
@@ -3815,8 +3842,11 @@ extern "C" int tlfea_newton_solve(tlfea_newton_t s) {
         launch_axpy_neg(s->stream, n, s->d_g, s->d_b);                       // r = -g  (:494-502)
         TRY(assemble(s));                                                    // (:1080-1097)
         int iters = 0;
-        const int rc = pcg(s, s->d_b, s->d_dv, &iters, nullptr);             // cuDSS factor+solve (:1103-1114)
+        int rc = pcg(s, s->d_b, s->d_dv, &iters, nullptr);                   // cuDSS factor+solve (:1103-1114)
         pcg_total += iters;
+        // TLFEA_TEST_FAIL_LINSOLVE=k (tests only, like TLFEA_CHEB_LMAX_SCALE): the k-th linear solve of the step (0-based)
+        // is reported as failed after it ran, to exercise the roll-back of a step that fails in a LATER Newton iteration
+        if (!rc && fail_hook >= 0 && n_newton == fail_hook) rc = fail("linear solve failed (TLFEA_TEST_FAIL_LINSOLVE test hook)");
         if (rc) return rc;
         n_newton++;
         TRY(newton_update(s));                                               // v += dv ; x = x_prev + h v (:1116-1119)

@@ -213,6 +213,7 @@ struct C32Bnd {
   const double* bsum = nullptr;  // [3 slots] summed Hs d of the boundary rows
   const double* w = nullptr;     // [3N] weights of the r.z partials (last step), null = 1
   const double* zw = nullptr;    // device scalar: z^ += zw d' instead of z^ += d' (fourth-kind Chebyshev smoothers), null = 1
+  int xcd = 0;                   // set by the launcher: XCD-aware row sweep (solver_kernels.hip, row_sweep)
 };
 void launch_cheb32(hipStream_t s, int N, int nnz_coef, const Incidence& inc, const void* B8, const void* B1, int bits,
                    const float* Dinv_f, const double* sc, const float* d_old, const double* coef, float* d_new,

@@ -47,7 +47,8 @@ def build(config, cells=None, x_offset_cells=0, offset_cells=None):
     X[:, 0] += lx * ox / full_nx
     X[:, 1] += ly * oy / full_ny
     X[:, 2] += lz * oz / full_nz
-    mat = material(cfg["material"])
+    import os
+    mat = material(os.environ.get("TLFEA_BENCH_MATERIAL", cfg["material"]))  # A/B runs: e.g. neo-Hookean at config C's size
     n = X.shape[0]
     f_ext = np.zeros(3 * n)
     if config == "B":
