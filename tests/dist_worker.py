@@ -141,6 +141,106 @@ def oracle_dist_step(o, part, ex, prm, f_share):
     return n_outer, n_newton
 
 
+class HaloExchange:
+    """Ghost refresh of the overlapping partition with gloo on host arrays: for every peer, send the values of my owned nodes
+    it holds (send list, layers <= depth) and receive my ghosts it owns -- the lists of partition.HaloPartition as they are."""
+
+    def __init__(self, hp, torch, dist):
+        self.hp, self.torch, self.dist = hp, torch, dist
+
+    def refresh(self, vec, dim, depth=None):
+        hp, torch, dist = self.hp, self.torch, self.dist
+        D = hp.depth if depth is None else depth
+        v = vec.reshape(-1, dim)
+        ops, bufs = [], []
+        for k, p in enumerate(hp.peers):
+            sidx = hp.send[k][hp.send_layer[k] <= D]
+            ridx = hp.recv[k][hp.layer[hp.recv[k]] <= D]
+            if len(sidx):
+                ops.append(dist.P2POp(dist.isend, torch.from_numpy(np.ascontiguousarray(v[sidx])), p))
+            if len(ridx):
+                t = torch.empty((len(ridx), dim), dtype=torch.float64)
+                bufs.append((ridx, t))
+                ops.append(dist.P2POp(dist.irecv, t, p))
+        if ops:
+            for r in dist.batch_isend_irecv(ops):
+                r.wait()
+        for ridx, t in bufs:
+            v[ridx] = t.numpy()
+
+    def scalar_sum(self, x):
+        t = self.torch.tensor([x], dtype=self.torch.float64)
+        self.dist.all_reduce(t)
+        return float(t[0])
+
+
+def oracle_halo_step(o, hp, ex, prm):
+    """ALM/Newton step of SyncedNewton.cu:1032-1146 on an OVERLAPPED sub-mesh (partition.halo_partition), the oracle as
+    the local engine: every rank evaluates complete rows of grad L and H on its owned nodes from its own elements (no sums
+    over ranks), block-Jacobi PCG on the owned rows with the direction's first ghost layer refreshed per iteration, dot
+    products over owned DOFs summed with an all-reduce, and the Newton update refreshed on every ghost."""
+    import scipy.sparse as sp
+    N, h, rho = o.N, prm.time_step, prm.rho
+    no = hp.n_owned
+    own3 = np.zeros(3 * N)
+    own3[:3 * no] = 1.0
+    fixed = o.fixed
+    wc = np.repeat((hp.layer[fixed] == 0).astype(float), 3)
+    xp = (o.x.copy(), o.y.copy(), o.z.copy())
+    n_outer = n_newton = 0
+    for outer in range(prm.max_outer):
+        n_outer += 1
+        ng0 = -1.0
+        for it in range(prm.max_inner):
+            f_int = o.internal_force(o.v)
+            g = o.grad_L(f_int, h, rho)
+            ng = np.sqrt(ex.scalar_sum(float(np.sum(own3 * g * g))))
+            if ng0 < 0:
+                ng0 = ng
+            if ng < prm.inner_atol or (prm.inner_rtol > 0 and ng0 > 0 and ng <= prm.inner_rtol * ng0):
+                break
+            ro, ci, val = o.assemble_hessian(h, rho)
+            H = sp.csr_matrix((val, ci, ro), shape=(3 * N, 3 * N))
+            Ho = H[:3 * no]                                    # owned rows: complete
+            D = np.zeros((N, 3, 3))
+            for i in range(no):
+                D[i] = Ho[3 * i:3 * i + 3, 3 * i:3 * i + 3].toarray()
+            Dinv = np.zeros_like(D)
+            Dinv[:no] = np.linalg.inv(D[:no])
+            b = np.zeros(3 * N)
+            b[:3 * no] = -g[:3 * no]
+            x = np.zeros(3 * N)
+            r = b.copy()
+            z = np.einsum("nij,nj->ni", Dinv, r.reshape(N, 3)).reshape(-1)
+            p = z.copy()
+            rz = ex.scalar_sum(float(r @ z))
+            bb = ex.scalar_sum(float(b @ b))
+            for _ in range(20000):
+                ex.refresh(p, 3, depth=1)
+                q = np.zeros(3 * N)
+                q[:3 * no] = Ho @ p
+                alpha = rz / ex.scalar_sum(float(p[:3 * no] @ q[:3 * no]))
+                x[:3 * no] += alpha * p[:3 * no]
+                r -= alpha * q
+                z = np.einsum("nij,nj->ni", Dinv, r.reshape(N, 3)).reshape(-1)
+                rz_new = ex.scalar_sum(float(r @ z))
+                if ex.scalar_sum(float(r @ r)) <= 1e-26 * bb:
+                    break
+                p[:3 * no] = z[:3 * no] + (rz_new / rz) * p[:3 * no]
+                rz = rz_new
+            ex.refresh(x, 3)                                   # the update of a ghost is its owner's
+            n_newton += 1
+            o.v += x
+            o.x, o.y, o.z = xp[0] + h * o.v[0::3], xp[1] + h * o.v[1::3], xp[2] + h * o.v[2::3]
+        o.v_prev = o.v.copy()
+        c = o.constraint()
+        o.lam += rho * c
+        nc = np.sqrt(ex.scalar_sum(float(np.sum(wc * c * c)) if len(c) else 0.0))
+        if ex.scalar_sum(float(np.sum(wc))) > 0 and nc < prm.outer_tol:
+            break
+    return n_outer, n_newton
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--engine", default="oracle")
@@ -175,7 +275,6 @@ def main():
     m = helpers.MATERIALS["svk"]
     owner = par.rcb_owner(X, conn, world) if args.partitioner == "rcb" else par.slab_owner(X, conn, world)
     if args.mode == "halo":
-        assert args.engine == "hip"
         node_owner = par.node_owner_from_elements(X.shape[0], conn, owner, world)
         part = par.halo_partition(X, conn, node_owner, np.arange(X.shape[0]), rank, world, args.depth)
     else:
@@ -190,7 +289,12 @@ def main():
     f_share = part.local_nodal_vector(f_ext) if args.mode == "halo" else part.share_of_nodal_vector(f_ext)
     prm = orc.NewtonParams(1e-4, 0.0, 1e-6, 1e14, 5, 12, 1e-3)
 
-    if args.engine == "oracle":
+    if args.engine == "oracle" and args.mode == "halo":
+        o = helpers.make_oracle(part.X, part.conn, m, fixed_loc, f_share)
+        ex = HaloExchange(part, torch, dist)
+        counts = [oracle_halo_step(o, part, ex, prm) for _ in range(args.steps)]
+        x_loc = np.stack([o.x, o.y, o.z], axis=1)
+    elif args.engine == "oracle":
         o = helpers.make_oracle(part.X, part.conn, m, fixed_loc, f_share)
         ex = Exchange(part, torch, dist)
         counts = [oracle_dist_step(o, part, ex, prm, f_share) for _ in range(args.steps)]

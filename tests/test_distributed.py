@@ -311,3 +311,28 @@ def test_halo_structured_blocks_agree(world):
             assert np.array_equal(w["x0"][hp.send[k]], built[p][0]["x0"][q.recv[kq]])
     n_fixed = sum(len(w["fixed"][hp.layer[w["fixed"]] == 0]) for w, hp in built)
     assert n_fixed == (2 * cfg["cells"][1] * pg[1] + 1) * (2 * cfg["cells"][2] * pg[2] + 1)   # the x = 0 face, owned once
+
+
+@pytest.mark.parametrize("world,partitioner", [(2, "slab"), (3, "rcb")])
+def test_halo_gloo_oracle_engine(tmp_path, world, partitioner):
+    """CPU coverage of the overlapping partition (no GPU): every rank runs the oracle on its overlapped sub-mesh; the
+    exchange lists of partition.halo_partition drive gloo send / recv pairs (ghost refresh of the CG direction and of the
+    Newton update), dot products run over owned DOFs; owned AND ghost positions equal the un-partitioned oracle's."""
+    rep = launch(world, ["--engine", "oracle", "--mesh", "box", "--steps", "2", "--mode", "halo", "--depth", "2",
+                         "--partitioner", partitioner], tmp_path)
+    assert rep["ok"] and rep["n_iface"] > 0 and rep["max_dup"] <= 1e-12, rep
+
+
+@pytest.mark.gpu
+def test_bench_four_ranks_block_grid_rehearsal(tmp_path):
+    """bench.py --gpus 4: the block series (2 x 2 x 1 blocks of the config, three peers per rank: faces and the shared
+    edge) with the gloo rehearsal backend, four ranks on the one GPU of the test box."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=4", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "2", "--warmup",
+           "1", "--config", "S", "--max-pcg", "2000", "--halo-depth", "3"]
+    env = dict(os.environ, TLFEA_BENCH_BACKEND="gloo", OMP_NUM_THREADS="2", MASTER_ADDR="127.0.0.1")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["n_gpus"] == 4 and out["value"] > 0 and out["config"]["last_solve_converged"]
+    assert "2x2x1 grid" in out["config"]["workload"] and out["config"]["neighbour_exchanges_per_cg_iteration"] > 0
