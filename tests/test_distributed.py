@@ -329,7 +329,7 @@ def test_bench_four_ranks_block_grid_rehearsal(tmp_path):
     edge) with the gloo rehearsal backend, four ranks on the one GPU of the test box."""
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=4", "--master-addr", "127.0.0.1",
            "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "2", "--warmup",
-           "1", "--config", "S", "--max-pcg", "2000", "--halo-depth", "3"]
+           "1", "--config", "S", "--max-pcg", "2000", "--halo-depth", "4"]
     env = dict(os.environ, TLFEA_BENCH_BACKEND="gloo", OMP_NUM_THREADS="2", MASTER_ADDR="127.0.0.1")
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
