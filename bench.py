@@ -273,8 +273,12 @@ def main():
         # slots; same matrix stream, timed with the non-final ones), coarse level (kc - 1 launches).  They are reported
         # separately: the coarse level's 74 MB per launch live in the 256 MB Infinity Cache, so ITS rate is cache
         # bandwidth and must not be averaged into an HBM fraction.
-        ncs = pmg[2] - 1
-        st = dict(st, spmv=(st["spmv"][0], n_outer), cheb_step=(0.0, n_outer * 3), cheb_step_coarse=(0.0, n_outer * ncs))
+        cyc = s.GetPmgCycleInfo()
+        # two levels: kc - 1 vertex-level steps; three levels: 2 x vertex_terms smoothing passes on the vertex level and a
+        # degree-k3 polynomial on the (few thousand) rigid-body-mode nodes below it
+        ncs = 2 * cyc["vertex_terms"] if cyc["levels"] == 3 else pmg[2] - 1
+        st = dict(st, spmv=(st["spmv"][0], n_outer), cheb_step=(0.0, n_outer * (2 * cyc["fine_terms"] - 1)),
+                  cheb_step_coarse=(0.0, n_outer * ncs))
     else:
         st = dict(st, spmv=(st["spmv"][0], n_outer), cheb_step=(0.0, n_outer * (deg_eff - 1)))
     for k in ("residual", "tangent_blocks", "assemble_rows", "assemble_direct", "assemble_affine", "spmv", "cheb_step",
@@ -350,8 +354,13 @@ def main():
                    **(comm_report if world > 1 else {}),
                    "last_solve_rel_residual": float(lin_status["rel_res"]), "last_solve_converged": lin_status["converged"],
                    "preconditioner": ("block-Jacobi (3x3)" if deg_eff <= 1 else
-                                      (f"two-level p-multigrid V-cycle (T10 -> vertex mesh, {pmg[0]} coarse nodes, Galerkin "
-                                       f"coarse operator, 2-term Chebyshev smoothers, degree-{pmg[2]} coarse polynomial), "
+                                      ((f"three-level p-multigrid V-cycle (T10 -> vertex mesh of {pmg[0]} nodes -> rigid-body modes "
+                                        f"of aggregates, {cyc['level3_nodes']} nodes; Galerkin operators; Chebyshev smoothers of "
+                                        f"{cyc['fine_terms']} / {cyc['vertex_terms']} terms on the fine / vertex level, degree-"
+                                        f"{cyc['level3_degree']} polynomial on the third), " if cyc["levels"] == 3 else
+                                        f"two-level p-multigrid V-cycle (T10 -> vertex mesh, {pmg[0]} coarse nodes, Galerkin "
+                                        f"coarse operator, {cyc['fine_terms']}-term Chebyshev smoothers, degree-{pmg[2]} coarse "
+                                        f"polynomial), ")
                                        if pmg else f"Chebyshev degree {deg_eff} of block-Jacobi, ") + "steps stream a "
                                       f"{'scaled fp%d copy of H' % bits_eff if bits_eff != 64 else 'fp64 H'} "
                                       f"with fp{vec_bits} work vectors; "

@@ -302,6 +302,8 @@ typedef struct {
   const int *peers;
   const int *send_off, *send_nodes, *send_layer;
   const int *recv_off, *recv_nodes;
+  int rank, world; /* this rank and the number of ranks (world <= 0: unknown -- the replicated third multigrid level, which
+                      gathers a few numbers per rank through the all-reduce, is then left out) */
 } tlfea_halo_lists;
 int tlfea_newton_set_halo(tlfea_newton_t s, const int *node_layer /*N*/, int depth, const tlfea_halo_lists *lists,
                           tlfea_allreduce_fn allreduce, tlfea_halo_exchange_fn exchange, void *user,
@@ -323,6 +325,10 @@ int tlfea_rccl_comm_create_timeout(const char *id128, int rank, int world, doubl
  * issued INSIDE CG iterations (the per-iteration budget; the rest is per-solve set-up: diagonal blocks, lambda_max
  * estimates, the Newton update). */
 int tlfea_newton_get_comm_stats(tlfea_newton_t s, double *out8);
+/* Shape of the p-multigrid cycle a solve would run now (after the first solve or tlfea_newton_pmg_sizes): out6 = levels
+ * (0: polynomial preconditioner), fine smoother terms, vertex-level smoother terms (three levels), vertex-level polynomial
+ * degree (two levels), level-3 polynomial degree, level-3 nodes. */
+int tlfea_newton_pmg_cycle_info(tlfea_newton_t s, int *out6);
 
 /* ---- SyncedAdamWNocoopSolver (SyncedAdamWNocoop.cuh:22-198, SyncedAdamWNocoop.cu:262-500) ------------------------
  * First-order ALM solver on the same velocity unknowns: per inner iteration one AdamW moment update, x = x_prev + dt v,

@@ -323,6 +323,7 @@ def main():
         n_collectives = s.Collectives()
         comm_stats = s.GetCommStats()
         precond = s.GetPreconditioner()
+        pmg3 = s.GetPmgLevel3Info()[0] > 0 if precond == 2 else False
         x_loc = np.stack(d.RetrievePositionToCPU(), axis=1)
         del s
         d.Destroy()
@@ -356,7 +357,7 @@ def main():
                       n_iface=(sum(len(a) for a in part.recv) if args.mode == "halo" else part.n_global_iface))
         if args.engine != "oracle":
             report.update(collectives=n_collectives, pcg_iters=pcg_iters, precond=precond,
-                          newton=int(sum(c[1] for c in counts)), comm=comm_stats)
+                          newton=int(sum(c[1] for c in counts)), comm=comm_stats, pmg_levels=3 if pmg3 else 2)
         print(json.dumps(report), flush=True)
         if args.out:
             json.dump(report, open(args.out, "w"))

@@ -336,3 +336,24 @@ def test_bench_four_ranks_block_grid_rehearsal(tmp_path):
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert out["n_gpus"] == 4 and out["value"] > 0 and out["config"]["last_solve_converged"]
     assert "2x2x1 grid" in out["config"]["workload"] and out["config"]["neighbour_exchanges_per_cg_iteration"] > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,partitioner,depth", [(2, "slab", 8), (3, "rcb", 6)])
+def test_halo_three_level_cycle_replicated_coarsest_level(tmp_path, monkeypatch, world, partitioner, depth):
+    """The three-level cycle on the overlapping partition (forced on a small mesh): the third level lives on a regular grid
+    of bins every rank derives from coordinates alone, is REPLICATED (H3 and the level-3 residual are summed over the ranks'
+    owned rows with one all-reduce each, its polynomial runs with no exchange), the vertex level smooths with 6 terms
+    between ghost refreshes.  Same positions as the un-partitioned oracle, CG iterations within 1.2x of one rank running
+    the same cycle, exchange budget <= 12 per CG iteration."""
+    monkeypatch.setenv("TLFEA_PMG_LEVELS", "3")
+    monkeypatch.setenv("TLFEA_PMG_AGG", "bins")
+    rep = launch(world, ["--engine", "hip", "--mesh", "res4", "--steps", "1", "--mode", "halo", "--depth", str(depth),
+                         "--partitioner", partitioner], tmp_path)
+    assert rep["ok"] and rep["precond"] == 2 and rep["pmg_levels"] == 3, rep
+    one = launch(1, ["--engine", "hip", "--mesh", "res4", "--steps", "1", "--mode", "halo", "--depth", str(depth)], tmp_path)
+    assert one["ok"] and one["pmg_levels"] == 3 and rep["newton"] == one["newton"], (one, rep)
+    assert rep["pcg_iters"] <= 1.2 * one["pcg_iters"] + 2 * rep["newton"], (one["pcg_iters"], rep["pcg_iters"])
+    c = rep["comm"]
+    per_it = (c["exchanges_in_cg"] + c["allreduces_in_cg"]) / max(1, c["cg_iterations"])
+    assert per_it <= 12.0, rep

@@ -19,7 +19,7 @@ HALO_EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_
 
 class HaloListsC(C.Structure):  # tlfea_halo_lists
     _fields_ = [("n_peers", C.c_int), ("peers", c_ip), ("send_off", c_ip), ("send_nodes", c_ip), ("send_layer", c_ip),
-                ("recv_off", c_ip), ("recv_nodes", c_ip)]
+                ("recv_off", c_ip), ("recv_nodes", c_ip), ("rank", C.c_int), ("world", C.c_int)]
 
 
 class TlfeaError(RuntimeError):

@@ -402,5 +402,180 @@ inline bool agg_build(int Nc, const int* c_off, const int* c_cols, const double*
   return true;
 }
 
+// ---- third level on a REGULAR GRID OF BINS (round 3) -------------------------------------------------------------------
+// Aggregate = the vertex nodes inside one cell of a regular grid over the body (cell size a few vertex spacings, agreed by
+// all ranks).  Unlike the greedy aggregates above, the aggregate of a vertex is a function of its coordinates alone, so
+// every rank of a partitioned mesh derives the SAME level-3 space without communicating, the level-3 pattern is the fixed
+// 27-cell stencil of the grid, and the level is small enough to be REPLICATED: every rank sums its owned rows' share of
+// H3 = P2^T Hc P2 and of the restricted residual with one all-reduce each and runs the level-3 polynomial redundantly,
+// with no exchange inside it.  Empty cells stay in the numbering as inert identity rows.
+struct BinGrid {
+  double origin[3] = {0, 0, 0};
+  double size = 1.0;
+  int dims[3] = {1, 1, 1};
+  int cells() const { return dims[0] * dims[1] * dims[2]; }
+};
+
+// grid over a bounding box: cell size = factor x mean vertex spacing, never below the longest vertex edge (so that
+// neighbours sit in adjacent cells).  Multi-GPU: the caller reduces (lo, hi, sum_len, n_len, max_len) over ranks first.
+inline BinGrid bin_grid(const double lo[3], const double hi[3], double mean_len, double max_len, double factor) {
+  BinGrid g;
+  g.size = std::max(factor * mean_len, 1.0001 * max_len);
+  for (int d = 0; d < 3; d++) {
+    g.origin[d] = lo[d] - 1e-9 * g.size;
+    g.dims[d] = std::max(1, (int)std::floor((hi[d] - g.origin[d]) / g.size) + 1);
+  }
+  return g;
+}
+
+inline int bin_of(const BinGrid& g, double x, double y, double z) {
+  const double p[3] = {x, y, z};
+  int c[3];
+  for (int d = 0; d < 3; d++) c[d] = std::min(g.dims[d] - 1, std::max(0, (int)std::floor((p[d] - g.origin[d]) / g.size)));
+  return (c[2] * g.dims[1] + c[1]) * g.dims[0] + c[0];
+}
+
+// per cell over the OWNED vertices (owned == nullptr: all): count, sum x (3), sum x x^T (xx, xy, xz, yy, yz, zz)
+inline void bin_moments(int Nc, const double* X, const BinGrid& g, const char* owned, std::vector<int>& agg,
+                        std::vector<double>& mom) {
+  agg.resize((size_t)Nc);
+  mom.assign((size_t)10 * g.cells(), 0.0);
+  for (int i = 0; i < Nc; i++) {
+    const double x = X[i], y = X[(size_t)Nc + i], z = X[(size_t)2 * Nc + i];
+    const int a = agg[i] = bin_of(g, x, y, z);
+    if (owned && !owned[i]) continue;
+    double* m = mom.data() + (size_t)10 * a;
+    m[0] += 1.0; m[1] += x; m[2] += y; m[3] += z;
+    m[4] += x * x; m[5] += x * y; m[6] += x * z; m[7] += y * y; m[8] += y * z; m[9] += z * z;
+  }
+}
+
+// the level from the (globally summed) moments: rows = owned vertices only, pattern = the grid's 27-cell stencil
+inline bool agg_build_bins(int Nc, const int* c_off, const int* c_cols, const double* X, const BinGrid& g,
+                           const std::vector<int>& agg, const std::vector<double>& mom, const char* owned, AggHost& o) {
+  o = AggHost();
+  o.Nc = Nc;
+  const int Na = g.cells();
+  o.Na = Na;
+  o.N3 = 2 * Na;
+  o.agg = agg;
+  // members (restriction): owned vertices of every cell, ascending
+  o.mem_off.assign((size_t)Na + 1, 0);
+  for (int i = 0; i < Nc; i++)
+    if (!owned || owned[i]) o.mem_off[agg[i] + 1]++;
+  for (int a = 0; a < Na; a++) o.mem_off[a + 1] += o.mem_off[a];
+  o.mem.resize((size_t)o.mem_off[Na]);
+  {
+    std::vector<int> cur(o.mem_off.begin(), o.mem_off.end() - 1);
+    for (int i = 0; i < Nc; i++)
+      if (!owned || owned[i]) o.mem[cur[agg[i]]++] = i;
+  }
+  // centroids and usable rotations from the moments (the same numbers on every rank); active: 1 rotations usable,
+  // 0 not (collinear / too few members), -1 empty cell
+  std::vector<double> cen((size_t)3 * Na, 0.0);
+  o.active.assign((size_t)Na, -1);
+  for (int a = 0; a < Na; a++) {
+    const double* m = mom.data() + (size_t)10 * a;
+    const double n = m[0];
+    if (n < 0.5) continue;
+    const double c[3] = {m[1] / n, m[2] / n, m[3] / n};
+    for (int d = 0; d < 3; d++) cen[(size_t)3 * a + d] = c[d];
+    // S = sum (x - c)(x - c)^T; rotational inertia M = tr(S) I - S
+    const double S[3][3] = {{m[4] - n * c[0] * c[0], m[5] - n * c[0] * c[1], m[6] - n * c[0] * c[2]},
+                            {m[5] - n * c[0] * c[1], m[7] - n * c[1] * c[1], m[8] - n * c[1] * c[2]},
+                            {m[6] - n * c[0] * c[2], m[8] - n * c[1] * c[2], m[9] - n * c[2] * c[2]}};
+    const double trS = S[0][0] + S[1][1] + S[2][2];
+    double M[3][3];
+    for (int d = 0; d < 3; d++)
+      for (int e = 0; e < 3; e++) M[d][e] = (d == e ? trS : 0.0) - S[d][e];
+    const double det = M[0][0] * (M[1][1] * M[2][2] - M[1][2] * M[2][1]) - M[0][1] * (M[1][0] * M[2][2] - M[1][2] * M[2][0]) +
+                       M[0][2] * (M[1][0] * M[2][1] - M[1][1] * M[2][0]);
+    const double tr = M[0][0] + M[1][1] + M[2][2];
+    o.active[a] = (n >= 2.5 && tr > 0.0 && det > 1e-6 * tr * tr * tr / 27.0) ? 1 : 0;
+  }
+  o.rvec.assign((size_t)3 * Nc, 0.0);
+  for (int i = 0; i < Nc; i++) {
+    const int a = agg[i];
+    if (o.active[a] != 1) continue;
+    for (int d = 0; d < 3; d++) o.rvec[(size_t)3 * i + d] = X[(size_t)d * Nc + i] - cen[(size_t)3 * a + d];
+  }
+  // adjacency: the 27-cell stencil, clipped, ascending cell index -- identical on every rank
+  std::vector<int> aoff((size_t)Na + 1, 0), aadj;
+  aadj.reserve((size_t)27 * Na);
+  for (int a = 0; a < Na; a++) {
+    const int cx = a % g.dims[0], cy = (a / g.dims[0]) % g.dims[1], cz = a / (g.dims[0] * g.dims[1]);
+    for (int dz = -1; dz <= 1; dz++)
+      for (int dy = -1; dy <= 1; dy++)
+        for (int dx = -1; dx <= 1; dx++) {
+          const int x = cx + dx, y = cy + dy, z = cz + dz;
+          if (x < 0 || y < 0 || z < 0 || x >= g.dims[0] || y >= g.dims[1] || z >= g.dims[2]) continue;
+          aadj.push_back((z * g.dims[1] + y) * g.dims[0] + x);
+        }
+    aoff[a + 1] = (int)aadj.size();
+  }
+  o.n_pairs = (int)aadj.size();
+  o.pair_A.resize((size_t)o.n_pairs);
+  o.pair_pos.resize((size_t)o.n_pairs);
+  o.pair_B = aadj;
+  for (int a = 0; a < Na; a++)
+    for (int p = aoff[a]; p < aoff[a + 1]; p++) {
+      o.pair_A[p] = a;
+      o.pair_pos[p] = p - aoff[a];
+    }
+  o.off3.assign((size_t)o.N3 + 1, 0);
+  for (int a = 0; a < Na; a++)
+    for (int s2 = 0; s2 < 2; s2++) o.off3[2 * a + s2 + 1] = 2 * (aoff[a + 1] - aoff[a]);
+  for (int r = 0; r < o.N3; r++) o.off3[r + 1] += o.off3[r];
+  o.nnz3 = o.off3[o.N3];
+  o.cols3.resize((size_t)o.nnz3);
+  o.diag3.resize((size_t)o.N3);
+  for (int a = 0; a < Na; a++)
+    for (int s2 = 0; s2 < 2; s2++) {
+      const int r = 2 * a + s2;
+      for (int p = aoff[a]; p < aoff[a + 1]; p++) {
+        o.cols3[o.off3[r] + 2 * (p - aoff[a])] = 2 * aadj[p];
+        o.cols3[o.off3[r] + 2 * (p - aoff[a]) + 1] = 2 * aadj[p] + 1;
+        if (aadj[p] == a) o.diag3[r] = 2 * (p - aoff[a]) + s2;
+      }
+    }
+  // contributions: the vertex-level blocks (i, j) of OWNED rows i feed the pair (cell of i, cell of j)
+  o.pcon_off.assign((size_t)o.n_pairs + 1, 0);
+  const int nnz2 = c_off[Nc];
+  std::vector<int> blk_pair((size_t)nnz2, -1);
+  int n_con = 0;
+  for (int i = 0; i < Nc; i++) {
+    if (owned && !owned[i]) continue;
+    const int a = agg[i];
+    for (int k = c_off[i]; k < c_off[i + 1]; k++) {
+      const int b = agg[c_cols[k]];
+      const int* lo = aadj.data() + aoff[a];
+      const int* hi = aadj.data() + aoff[a + 1];
+      const int* pp = std::lower_bound(lo, hi, b);
+      if (pp == hi || *pp != b) return false;  // a vertex edge longer than a cell: the grid is too fine
+      blk_pair[k] = aoff[a] + (int)(pp - lo);
+      o.pcon_off[(size_t)blk_pair[k] + 1]++;
+      n_con++;
+    }
+  }
+  for (int p = 0; p < o.n_pairs; p++) o.pcon_off[p + 1] += o.pcon_off[p];
+  o.pcon_base.resize((size_t)std::max(1, n_con));
+  o.pcon_deg.resize((size_t)std::max(1, n_con));
+  o.pcon_i.resize((size_t)std::max(1, n_con));
+  o.pcon_j.resize((size_t)std::max(1, n_con));
+  {
+    std::vector<int> cur(o.pcon_off.begin(), o.pcon_off.end() - 1);
+    for (int i = 0; i < Nc; i++)
+      for (int k = c_off[i]; k < c_off[i + 1]; k++) {
+        if (blk_pair[k] < 0) continue;
+        const int u = cur[blk_pair[k]]++;
+        o.pcon_base[u] = 9 * c_off[i] + 3 * (k - c_off[i]);
+        o.pcon_deg[u] = c_off[i + 1] - c_off[i];
+        o.pcon_i[u] = i;
+        o.pcon_j[u] = c_cols[k];
+      }
+  }
+  return true;
+}
+
 }  // namespace tlfea
 #endif

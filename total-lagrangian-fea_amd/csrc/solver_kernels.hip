@@ -1363,11 +1363,14 @@ __global__ __launch_bounds__(128) void agg_galerkin_kernel(int n_pairs, const in
     }
   }
   const int A = pair_A[p], B = pair_B[p], pos = pair_pos[p];
-  if (A == B && !active[A]) {  // unusable rotations: identity keeps the level-3 matrix definite, the modes stay at zero
-#pragma unroll
+  if (A == B && active[A] <= 0) {  // unusable rotations (0) / empty grid cell (-1): identity keeps the level-3 matrix
+#pragma unroll                   // definite, the modes stay at zero (on several ranks the identities add up: harmless)
     for (int d = 0; d < 3; d++)
 #pragma unroll
-      for (int e = 0; e < 3; e++) rr[d][e] = (d == e) ? 1.0 : 0.0;
+      for (int e = 0; e < 3; e++) {
+        rr[d][e] = (d == e) ? 1.0 : 0.0;
+        if (active[A] < 0) tt[d][e] = (d == e) ? 1.0 : 0.0;
+      }
   }
 #pragma unroll
   for (int s2 = 0; s2 < 2; s2++) {
@@ -1438,6 +1441,65 @@ void launch_agg_restrict_init(hipStream_t s, int N3, const int* mem_off, const i
 }
 
 // corr^_2 = S_2^-1 P2 S_3 z^_3 ;  z^_2 += corr ; d_2 := corr
+// the same restriction in two launches (overlapping partition): this rank's share of the level-3 residual over its OWNED
+// member vertices as doubles -- summed over ranks by the caller -- then the level-3 start vectors from the sum
+__global__ __launch_bounds__(256) void agg_restrict_kernel(int N3, const int* __restrict__ mem_off,
+                                                          const int* __restrict__ mem, const double* __restrict__ rvec,
+                                                          const float* __restrict__ res2, const double* __restrict__ sc2,
+                                                          double* __restrict__ r3) {
+  const int lane = threadIdx.x & 15;
+  const int I = blockIdx.x * 16 + (threadIdx.x >> 4);
+  if (I >= N3) return;
+  const int A = I >> 1, rot = I & 1;
+  double r[3] = {0.0, 0.0, 0.0};
+  for (int t = mem_off[A] + lane; t < mem_off[A + 1]; t += 16) {
+    const int n = mem[t];
+    const double v[3] = {(double)res2[3 * n] / sc2[3 * n], (double)res2[3 * n + 1] / sc2[3 * n + 1],
+                         (double)res2[3 * n + 2] / sc2[3 * n + 2]};
+    if (rot) {
+      double c[3];
+      cross3(rvec + 3 * (size_t)n, v, c);
+      r[0] += c[0]; r[1] += c[1]; r[2] += c[2];
+    } else {
+      r[0] += v[0]; r[1] += v[1]; r[2] += v[2];
+    }
+  }
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) {
+    r[0] += __shfl_xor(r[0], o);
+    r[1] += __shfl_xor(r[1], o);
+    r[2] += __shfl_xor(r[2], o);
+  }
+  if (lane < 3) r3[3 * I + lane] = lane == 0 ? r[0] : (lane == 1 ? r[1] : r[2]);
+}
+__global__ __launch_bounds__(256) void agg_init3_kernel(int N3, const double* __restrict__ r3, const double* __restrict__ sc3,
+                                                       const float* __restrict__ Dinv3, const double* __restrict__ coef3,
+                                                       float* __restrict__ d3, float* __restrict__ z3,
+                                                       float* __restrict__ res3) {
+  const int I = blockIdx.x * 256 + threadIdx.x;
+  if (I >= N3) return;
+  const float inv_theta = (float)coef3[0];
+  const float rs0 = (float)(r3[3 * I] * sc3[3 * I]), rs1 = (float)(r3[3 * I + 1] * sc3[3 * I + 1]),
+              rs2 = (float)(r3[3 * I + 2] * sc3[3 * I + 2]);
+  const float* D = Dinv3 + (size_t)9 * I;
+#pragma unroll
+  for (int c = 0; c < 3; c++) {
+    const float v = (D[3 * c] * rs0 + D[3 * c + 1] * rs1 + D[3 * c + 2] * rs2) * inv_theta;
+    d3[3 * I + c] = v;
+    z3[3 * I + c] = v;
+  }
+  res3[3 * I] = rs0;
+  res3[3 * I + 1] = rs1;
+  res3[3 * I + 2] = rs2;
+}
+void launch_agg_restrict(hipStream_t s, int N3, const int* mem_off, const int* mem, const double* rvec, const float* res2,
+                         const double* sc2, double* r3) {
+  hipLaunchKernelGGL(agg_restrict_kernel, dim3((N3 + 15) / 16), dim3(256), 0, s, N3, mem_off, mem, rvec, res2, sc2, r3);
+}
+void launch_agg_init3(hipStream_t s, int N3, const double* r3, const double* sc3, const float* Dinv3, const double* coef3,
+                      float* d3, float* z3, float* res3) {
+  hipLaunchKernelGGL(agg_init3_kernel, dim3((N3 + 255) / 256), dim3(256), 0, s, N3, r3, sc3, Dinv3, coef3, d3, z3, res3);
+}
 __global__ __launch_bounds__(256) void agg_prolong_kernel(int Nc, const int* __restrict__ agg,
                                                          const double* __restrict__ rvec, const float* __restrict__ z3,
                                                          const double* __restrict__ sc3, const double* __restrict__ sc2,

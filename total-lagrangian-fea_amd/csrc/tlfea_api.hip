@@ -937,7 +937,9 @@ struct tlfea_newton_s {
     Incidence inc() const { return Incidence{nullptr, nullptr, nullptr, d_c_off, d_c_cols, d_c_diagpos}; }
     // third level: rigid-body-mode aggregates of the vertex level (pmg_host.h agg_build); N3 = 2 Na nodes
     struct Agg {
-      bool ok = false;
+      bool ok = false, bins = false;
+      double size_ratio = 0.0;  // bins: cell size in mean vertex edges (0: greedy aggregates, ~2.2)
+      double* d_r3 = nullptr;  // overlapping partition: this rank's share of the level-3 residual (summed over ranks)
       int Na = 0, N3 = 0, nnz3 = 0, n_pairs = 0;
       int *d_agg = nullptr, *d_active = nullptr, *d_mem_off = nullptr, *d_mem = nullptr, *d_off3 = nullptr,
           *d_cols3 = nullptr, *d_diag3 = nullptr, *d_pair_A = nullptr, *d_pair_pos = nullptr, *d_pair_B = nullptr,
@@ -1054,7 +1056,7 @@ struct tlfea_newton_s {
   };
   struct Halo {
     bool on = false, native = false;
-    int depth = 0;
+    int depth = 0, rank = 0, world = 0;
     std::vector<int> peers, layer, n_upto;   // n_upto[k] = local nodes of layers <= k (k = 0 .. depth)
     std::vector<int> n_upto_c;               // the same for the coarse (vertex) level
     HaloLevel lv[2];                         // 0 fine, 1 coarse
@@ -1098,7 +1100,7 @@ extern "C" int tlfea_newton_create(tlfea_t10_t data, int n_constraints, tlfea_ne
   TRY(dmalloc(&s->d_xp, (size_t)s->N)); TRY(dmalloc(&s->d_yp, (size_t)s->N)); TRY(dmalloc(&s->d_zp, (size_t)s->N));
   TRY(dmalloc(&s->d_parts, (size_t)6 * kNPart));
   TRY(dmalloc(&s->d_scal, (size_t)4));
-  HIP_TRY(hipHostMalloc((void**)&s->h_pin, (8 + 48 + 2 * 64) * sizeof(double)));
+  HIP_TRY(hipHostMalloc((void**)&s->h_pin, (8 + 128 + 2 * 64) * sizeof(double)));
   TRY(dmalloc(&s->d_coef, (size_t)2 * 64));
   if (const char* e = std::getenv("TLFEA_GRAPH")) s->use_graphs = std::atoi(e) != 0;
   TRY(dmalloc(&s->d_Dinv, (size_t)9 * s->N));
@@ -1157,7 +1159,7 @@ extern "C" int tlfea_newton_destroy(tlfea_newton_t s) {
     auto& g = m.agg;
     void* gg[] = {g.d_agg, g.d_active, g.d_mem_off, g.d_mem, g.d_off3, g.d_cols3, g.d_diag3, g.d_pair_A, g.d_pair_pos,
                   g.d_pair_B, g.d_pcon_off, g.d_pcon_base, g.d_pcon_deg, g.d_pcon_i, g.d_pcon_j, g.d_rvec, g.d_H3, g.d_D3,
-                  g.d_Dinv3, g.d_sc3, g.d_Dinv_s3, g.d_eigv3, g.d_q3, g.d_p3, g.d_B8, g.d_B1, g.d_f32};
+                  g.d_Dinv3, g.d_sc3, g.d_Dinv_s3, g.d_eigv3, g.d_q3, g.d_p3, g.d_B8, g.d_B1, g.d_f32, g.d_r3};
     for (void* q : gg)
       if (q) (void)hipFree(q);
   }
@@ -1726,6 +1728,8 @@ extern "C" int tlfea_newton_set_halo(tlfea_newton_t s, const int* node_layer, in
   h.on = true;
   h.native = exchange == rccl_halo_exchange_cb && allreduce == rccl_allreduce_cb;
   h.depth = depth;
+  h.rank = lists->rank;
+  h.world = lists->world;
   h.peers.assign(lists->peers, lists->peers + P);
   h.layer.assign(node_layer, node_layer + N);
   h.n_upto.assign(depth + 1, 0);
@@ -2459,10 +2463,9 @@ static int pmg_coarse_degree_eff(tlfea_newton_t s) {
 static const double kPmgKappaS = std::getenv("TLFEA_PMG_KAPPA_S") ? std::atof(std::getenv("TLFEA_PMG_KAPPA_S")) : 8.0;
 // terms of the fine smoother's Chebyshev polynomial (TLFEA_PMG_KS; 2 = the measured optimum): pre- and post-smoothing
 // cost ks fine passes each (ks - 1 steps + the residual / restart pass)
-static const int kPmgMaxKs = 6;
+static const int kPmgMaxKs = 12;
 static int pmg_ks(tlfea_newton_t s) {
   static const int forced = std::getenv("TLFEA_PMG_KS") ? std::atoi(std::getenv("TLFEA_PMG_KS")) : 0;
-  if (s->pmg.agg.ok) return 2;  // the three-level tables keep the fixed two-term layout
   return forced >= 1 ? std::min(forced, kPmgMaxKs) : 2;
 }
 // coefficient table of the cycle (device doubles): [0 .. 2 ks) init + steps of the fine smoother, then the residual pass
@@ -2471,6 +2474,23 @@ static int pmg_cf_resid(tlfea_newton_t s) { return 2 * pmg_ks(s); }
 static int pmg_cf_restart(tlfea_newton_t s) { return 2 * pmg_ks(s) + 2; }
 static int pmg_cf_beta(tlfea_newton_t s) { return 2 * pmg_ks(s) + 4; }                 // ks weights of z^ += beta_k d
 static int pmg_cf_coarse(tlfea_newton_t s) { return 2 * pmg_ks(s) + 4 + kPmgMaxKs; }
+// three levels: the vertex level smooths with ks2 terms (TLFEA_PMG_KS2, default 2) -- its table [steps | residual pass |
+// restart] sits where the two-level cycle keeps the vertex-level polynomial; the level-3 polynomial follows
+static int pmg_ks2(tlfea_newton_t s) {
+  static const int forced = std::getenv("TLFEA_PMG_KS2") ? std::atoi(std::getenv("TLFEA_PMG_KS2")) : 0;
+  if (forced >= 1) return std::min(forced, kPmgMaxKs);
+  // measured at config C with aggregates of ~2.2 mean vertex edges: 2 terms -> 80 ms, 4 -> 65, 6 -> 58, 10 -> 58, 12 -> 69.
+  // Larger aggregates (the grid of bins is coarsened to keep the replicated level small on many ranks) leave the
+  // smoother a wider band: terms in proportion to the aggregate size.
+  const double ratio = s->pmg.agg.size_ratio > 0.0 ? s->pmg.agg.size_ratio : 2.2;
+  return std::max(4, std::min(kPmgMaxKs, (int)std::lround(2.7 * ratio)));
+}
+static double pmg_kappa_s2(tlfea_newton_t s) {
+  static const double forced = std::getenv("TLFEA_PMG_KAPPA_S2") ? std::atof(std::getenv("TLFEA_PMG_KAPPA_S2")) : 0.0;
+  const int k = pmg_ks2(s);
+  return forced > 1.0 ? forced : 2.5 * k * k;  // 90 at 6 terms (measured optimum 60-100)
+}
+static int pmg_cf_level3(tlfea_newton_t s) { return pmg_cf_coarse(s) + 2 * pmg_ks2(s) + 4; }
 // Smoother polynomial (TLFEA_PMG_SMOOTHER): 1 = first-kind Chebyshev on [lmax / kappa_s, lmax] (the default),
 // 3 = fourth-kind Chebyshev (needs lmax only), 4 = fourth kind with the optimised weights of Lottes (2022),
 // "Optimal polynomial smoothers for multigrid V-cycles": the z^ update is weighted, z^_k = z^_{k-1} + beta_k d_{k-1}.
@@ -2485,11 +2505,15 @@ static int pmg_smoother_kind() {
 // gain, so two levels stay the default.  Below: smoother interval of the vertex level when it is not the coarsest,
 // degree / interval of the level-3 polynomial.
 static int pmg_levels_wanted(int n_vertex) {
-  (void)n_vertex;
+  // Round 3: with a 6-term vertex-level smoother (instead of the 2-term one of round 2) the third level pays: 58 ms
+  // against 80 ms per Newton iteration at config C, 23 CG iterations instead of 30 (profiles/r03_sweep_pmg3_*.txt).  Default
+  // from 20 000 vertex nodes up (below that the cycle is launch-latency-bound and the extra launches cost more than the
+  // shorter polynomial saves: config B 2 197 vertices); TLFEA_PMG_LEVELS=2|3 forces either.
   static const int forced = std::getenv("TLFEA_PMG_LEVELS") ? std::atoi(std::getenv("TLFEA_PMG_LEVELS")) : 0;
-  return forced == 3 ? 3 : 2;
+  static const int min_v = std::getenv("TLFEA_PMG_L3_MIN") ? std::atoi(std::getenv("TLFEA_PMG_L3_MIN")) : 20000;
+  if (forced == 2 || forced == 3) return forced;
+  return n_vertex >= min_v ? 3 : 2;
 }
-static const double kPmgKappaS2 = std::getenv("TLFEA_PMG_KAPPA_S2") ? std::atof(std::getenv("TLFEA_PMG_KAPPA_S2")) : 16.0;
 static int pmg_level3_degree(int n3) {
   static const int forced = std::getenv("TLFEA_PMG_KC3") ? std::atoi(std::getenv("TLFEA_PMG_KC3")) : 0;
   if (forced > 1) return std::min(forced, kPmgMaxCoarseDeg - 4);
@@ -2549,7 +2573,7 @@ static int pmg_prepare(tlfea_newton_t s) {
   TRY(dmalloc(&m.d_sc_c, nc)); TRY(dmalloc(&m.d_Dinv_s_c, (size_t)9 * m.Nc));
   TRY(dmalloc(&m.d_eigv_c, nc)); TRY(dmalloc(&m.d_q_c, nc)); TRY(dmalloc(&m.d_p_c, nc));
   TRY(dmalloc(&m.d_f32c, 6 * nc + (size_t)9 * m.Nc));
-  TRY(dmalloc(&m.d_coef, (size_t)3 * kPmgMaxKs + 4 + 2 * kPmgMaxCoarseDeg));
+  TRY(dmalloc(&m.d_coef, (size_t)5 * kPmgMaxKs + 8 + 2 * kPmgMaxCoarseDeg));
   m.ok = true;
   if (s->verbose) std::printf("p-multigrid: %d fine nodes -> %d vertex nodes, %d coarse blocks\n", d->N, m.Nc, m.nnz_c);
   if (s->ar) {
@@ -2608,7 +2632,7 @@ static int pmg_prepare(tlfea_newton_t s) {
   if (s->halo.on) {
     // Overlapping partition: the coarse level inherits owners and layers (a vertex is adjacent to the vertices of its
     // elements: the same graph distance).  Coarse exchange lists = the fine lists restricted to vertex nodes.
-    if (pmg_levels_wanted(m.Nc) == 3) return fail("p-multigrid: the third level is single-GPU only");
+    // (the third level is not partitioned yet: the multi-GPU cycle stays at two levels)
     auto& hl = s->halo;
     const auto& Lf = hl.lv[0];
     auto& Lc = hl.lv[1];
@@ -2655,7 +2679,10 @@ static int pmg_prepare(tlfea_newton_t s) {
       std::printf("p-multigrid: overlapped coarse level, %d owned of %d local vertices (%d over all ranks)\n", hl.n_upto_c[0],
                   m.Nc, m.Nc_glob);
   }
-  if (pmg_levels_wanted(m.Nc) == 3) {
+  // third level: single GPU (greedy aggregates, or the grid of bins with TLFEA_PMG_AGG=bins) and the overlapping
+  // partition (bins: the level is replicated on every rank, see pmg_host.h)
+  const bool l3_halo = s->halo.on && s->halo.world > 0;
+  if ((!dist_on(s) || l3_halo) && pmg_levels_wanted(s->halo.on ? m.Nc_glob : m.Nc) == 3) {
     // reference coordinates of the vertex nodes (slot 0 of a coarse node's children is the vertex itself)
     std::vector<double> xf((size_t)3 * d->N), Xv((size_t)3 * m.Nc);
     D2H(xf.data(), d->d_xt, (size_t)d->N);
@@ -2667,10 +2694,101 @@ static int pmg_prepare(tlfea_newton_t s) {
     }
     AggHost a;
     auto& g = m.agg;
-    if (agg_build(m.Nc, h.c_off.data(), h.c_cols.data(), Xv.data(), a)) {
+    // aggregates: the grid of bins everywhere (one cycle on one GPU and on many; measured equal to the greedy aggregates of
+    // round 2 at config C: 59.0 vs 58.5 ms); TLFEA_PMG_AGG=greedy keeps those on one GPU
+    static const bool bins_env = !(std::getenv("TLFEA_PMG_AGG") && std::string(std::getenv("TLFEA_PMG_AGG")) == "greedy");
+    bool built = false;
+    if (l3_halo || bins_env) {
+      // --- grid of bins.  Agreed numbers: bounding box, mean / longest vertex edge (over owned rows), then the moments ---
+      std::vector<char> owned;
+      if (s->halo.on) {
+        owned.resize((size_t)m.Nc);
+        for (int I = 0; I < m.Nc; I++) owned[I] = s->halo.layer[h.child[h.child_off[I]]] == 0;
+      }
+      const char* own = s->halo.on ? owned.data() : nullptr;
+      double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300}, sum_len = 0.0, n_len = 0.0, max_len = 0.0;
+      for (int I = 0; I < m.Nc; I++) {
+        if (own && !own[I]) continue;
+        for (int c = 0; c < 3; c++) {
+          lo[c] = std::min(lo[c], Xv[(size_t)c * m.Nc + I]);
+          hi[c] = std::max(hi[c], Xv[(size_t)c * m.Nc + I]);
+        }
+        for (int k = h.c_off[I]; k < h.c_off[I + 1]; k++) {
+          const int J = h.c_cols[k];
+          if (J == I) continue;
+          double l2 = 0.0;
+          for (int c = 0; c < 3; c++) l2 += (Xv[(size_t)c * m.Nc + I] - Xv[(size_t)c * m.Nc + J]) * (Xv[(size_t)c * m.Nc + I] - Xv[(size_t)c * m.Nc + J]);
+          const double l = std::sqrt(l2);
+          sum_len += l; n_len += 1.0; max_len = std::max(max_len, l);
+        }
+      }
+      double n_own_glob = s->halo.on ? 0.0 : (double)m.Nc;
+      if (s->halo.on) {
+        // gather-by-sum: rank r fills slots [9 r, 9 r + 9) of a zero vector, the all-reduce hands every rank all of them
+        const int W = s->halo.world, R = s->halo.rank;
+        if (9 * W > 2 * kNPart) return fail("p-multigrid: too many ranks for the level-3 set-up buffer");
+        std::vector<double> v((size_t)9 * W, 0.0);
+        const double mine[9] = {lo[0], lo[1], lo[2], hi[0], hi[1], hi[2], sum_len, n_len, max_len};
+        std::copy(mine, mine + 9, v.begin() + (size_t)9 * R);
+        HIP_TRY(hipMemcpy(s->halo.d_red, v.data(), v.size() * sizeof(double), hipMemcpyHostToDevice));
+        TRY(call_allreduce(s, s->halo.d_red, 9 * W));
+        HIP_TRY(hipStreamSynchronize(s->stream));
+        HIP_TRY(hipMemcpy(v.data(), s->halo.d_red, v.size() * sizeof(double), hipMemcpyDeviceToHost));
+        sum_len = n_len = max_len = 0.0;
+        for (int r = 0; r < W; r++) {
+          for (int c = 0; c < 3; c++) {
+            lo[c] = std::min(lo[c], v[(size_t)9 * r + c]);
+            hi[c] = std::max(hi[c], v[(size_t)9 * r + 3 + c]);
+          }
+          sum_len += v[(size_t)9 * r + 6];
+          n_len += v[(size_t)9 * r + 7];
+          max_len = std::max(max_len, v[(size_t)9 * r + 8]);
+        }
+        n_own_glob = (double)m.Nc_glob;
+      }
+      static const double factor = std::getenv("TLFEA_PMG_BIN") ? std::atof(std::getenv("TLFEA_PMG_BIN")) : 2.0;
+      static const double max_bins = std::getenv("TLFEA_PMG_BINS_MAX") ? std::atof(std::getenv("TLFEA_PMG_BINS_MAX")) : 12000.0;
+      const double mean_len = n_len > 0.0 ? sum_len / n_len : 1.0;
+      BinGrid grid = bin_grid(lo, hi, mean_len, max_len, factor);
+      // the replicated level stays small: at most max_bins cells, whatever the number of ranks
+      while ((double)grid.cells() > max_bins) grid = bin_grid(lo, hi, mean_len, max_len, (grid.size / mean_len) * 1.1);
+      std::vector<int> agg;
+      std::vector<double> mom;
+      bin_moments(m.Nc, Xv.data(), grid, own, agg, mom);
+      if (s->halo.on) {
+        double* d_m = nullptr;
+        TRY(dmalloc(&d_m, mom.size()));
+        HIP_TRY(hipMemcpy(d_m, mom.data(), mom.size() * sizeof(double), hipMemcpyHostToDevice));
+        TRY(call_allreduce(s, d_m, (int)mom.size()));
+        HIP_TRY(hipStreamSynchronize(s->stream));
+        HIP_TRY(hipMemcpy(mom.data(), d_m, mom.size() * sizeof(double), hipMemcpyDeviceToHost));
+        (void)hipFree(d_m);
+      }
+      built = agg_build_bins(m.Nc, h.c_off.data(), h.c_cols.data(), Xv.data(), grid, agg, mom, own, a);
+      g.bins = built;
+      g.size_ratio = built ? grid.size / mean_len : 0.0;
+      if (s->verbose)
+        std::printf("p-multigrid: third level on a %d x %d x %d grid of bins (cell %.3g = %.2f mean vertex edges; %.0f owned vertices "
+                    "over all ranks)%s\n", grid.dims[0], grid.dims[1], grid.dims[2], grid.size, grid.size / mean_len, n_own_glob,
+                    built ? "" : " -- FAILED, two levels");
+      if (s->halo.on) {
+        // every rank must take the same branch: agree that ALL built the level
+        double okv = built ? 0.0 : 1.0;
+        HIP_TRY(hipMemcpy(s->halo.d_red, &okv, sizeof(double), hipMemcpyHostToDevice));
+        TRY(call_allreduce(s, s->halo.d_red, 1));
+        HIP_TRY(hipStreamSynchronize(s->stream));
+        HIP_TRY(hipMemcpy(&okv, s->halo.d_red, sizeof(double), hipMemcpyDeviceToHost));
+        built = built && okv < 0.5;
+      }
+    } else {
+      built = agg_build(m.Nc, h.c_off.data(), h.c_cols.data(), Xv.data(), a);
+    }
+    if (built) {
       g.Na = a.Na; g.N3 = a.N3; g.nnz3 = a.nnz3; g.n_pairs = a.n_pairs;
       TRY(upload_vec(&g.d_agg, a.agg)); TRY(upload_vec(&g.d_active, a.active)); TRY(upload_vec(&g.d_rvec, a.rvec));
-      TRY(upload_vec(&g.d_mem_off, a.mem_off)); TRY(upload_vec(&g.d_mem, a.mem));
+      TRY(upload_vec(&g.d_mem_off, a.mem_off));
+      if (a.mem.empty()) a.mem.push_back(0);
+      TRY(upload_vec(&g.d_mem, a.mem));
       TRY(upload_vec(&g.d_off3, a.off3)); TRY(upload_vec(&g.d_cols3, a.cols3)); TRY(upload_vec(&g.d_diag3, a.diag3));
       TRY(upload_vec(&g.d_pair_A, a.pair_A)); TRY(upload_vec(&g.d_pair_pos, a.pair_pos)); TRY(upload_vec(&g.d_pair_B, a.pair_B));
       TRY(upload_vec(&g.d_pcon_off, a.pcon_off)); TRY(upload_vec(&g.d_pcon_base, a.pcon_base));
@@ -2681,6 +2799,7 @@ static int pmg_prepare(tlfea_newton_t s) {
       TRY(dmalloc(&g.d_sc3, n3)); TRY(dmalloc(&g.d_Dinv_s3, (size_t)9 * g.N3));
       TRY(dmalloc(&g.d_eigv3, n3)); TRY(dmalloc(&g.d_q3, n3)); TRY(dmalloc(&g.d_p3, n3));
       TRY(dmalloc(&g.d_f32, 6 * n3 + (size_t)9 * g.N3));
+      if (s->halo.on) TRY(dmalloc(&g.d_r3, n3));
       g.ok = true;
       if (s->verbose)
         std::printf("p-multigrid: third level, %d aggregates with rigid-body modes (%d nodes, %d blocks)\n", g.Na, g.N3, g.nnz3);
@@ -2718,6 +2837,9 @@ static int pmg_build_level(tlfea_newton_t s) {
     auto& g = m.agg;
     launch_agg_galerkin(s->stream, g.n_pairs, g.d_pair_A, g.d_pair_pos, g.d_pair_B, g.d_pcon_off, g.d_pcon_base,
                         g.d_pcon_deg, g.d_pcon_i, g.d_pcon_j, g.d_rvec, g.d_active, g.d_off3, m.d_Hc, g.d_H3);
+    // overlapping partition: every rank summed the vertex-level rows it OWNS; the level is replicated, so the shares are
+    // added once per Newton iteration (identical bits on every rank afterwards: the level-3 polynomial needs no exchange)
+    if (s->halo.on) TRY(call_allreduce(s, g.d_H3, 9 * g.nnz3));
     if (g.bits_alloc != bits) {
       if (g.d_B8) (void)hipFree(g.d_B8);
       if (g.d_B1) (void)hipFree(g.d_B1);
@@ -2783,7 +2905,7 @@ static int pmg_coefficients(tlfea_newton_t s) {
     h[2 * ks] = 0.0; h[2 * ks + 1] = 0.0;
     h[2 * ks + 2] = 0.0; h[2 * ks + 3] = 1.0 / theta;
     for (int k = 0; k < kPmgMaxKs; k++) h[2 * ks + 4 + k] = 1.0;
-    if (pmg_smoother_kind() != 1 && !m.agg.ok) {
+    if (pmg_smoother_kind() != 1) {
       // fourth kind: d0 = 4/(3 rho) D^-1 r ; d_k = (2k-1)/(2k+3) d_{k-1} + (8k+4)/((2k+3) rho) D^-1 r_k ; z_k = z_{k-1} + beta_k d_{k-1}
       static const double kOpt[4][4] = {{1.12500000000000, 0, 0, 0},
                                         {1.02387287570313, 1.26408905371085, 0, 0},
@@ -2821,27 +2943,33 @@ static int pmg_coefficients(tlfea_newton_t s) {
     TRY(fetch_scalar(s, s->d_scal, &s3));
     if (!(s3 > 0.0)) return fail("p-multigrid: level-3 lambda_max estimate failed");
     g.lam3 = std::sqrt(s3);
+    const int ks2 = pmg_ks2(s), o2 = pmg_cf_coarse(s), o3 = pmg_cf_level3(s);
     {
-      const double b = s->lam_safety * m.lam_c, a = b / kPmgKappaS2;
+      const double b = s->lam_safety * m.lam_c, a = b / pmg_kappa_s2(s);
       const double theta = 0.5 * (b + a), delta = 0.5 * (b - a), sigma = theta / delta;
-      const double rho0 = 1.0 / sigma, rho1 = 1.0 / (2.0 * sigma - rho0);
-      h[8] = 1.0 / theta; h[9] = 0.0;
-      h[10] = rho1 * rho0; h[11] = 2.0 * rho1 / delta;
-      h[12] = 0.0; h[13] = 0.0;
-      h[14] = 0.0; h[15] = 1.0 / theta;
+      double rho = 1.0 / sigma;
+      h[o2] = 1.0 / theta; h[o2 + 1] = 0.0;
+      for (int k = 1; k < ks2; k++) {
+        const double rho_new = 1.0 / (2.0 * sigma - rho);
+        h[o2 + 2 * k] = rho_new * rho;
+        h[o2 + 2 * k + 1] = 2.0 * rho_new / delta;
+        rho = rho_new;
+      }
+      h[o2 + 2 * ks2] = 0.0; h[o2 + 2 * ks2 + 1] = 0.0;
+      h[o2 + 2 * ks2 + 2] = 0.0; h[o2 + 2 * ks2 + 3] = 1.0 / theta;
     }
     const int k3 = pmg_level3_degree(g.N3);
     const double b = s->lam_safety * g.lam3, a = b / pmg_kappa_level3(k3);
     const double theta = 0.5 * (b + a), delta = 0.5 * (b - a), sigma = theta / delta;
     double rho = 1.0 / sigma;
-    h[16] = 1.0 / theta; h[17] = 0.0;
+    h[o3] = 1.0 / theta; h[o3 + 1] = 0.0;
     for (int k = 1; k < k3; k++) {
       const double rho_new = 1.0 / (2.0 * sigma - rho);
-      h[16 + 2 * k] = rho_new * rho;
-      h[16 + 2 * k + 1] = 2.0 * rho_new / delta;
+      h[o3 + 2 * k] = rho_new * rho;
+      h[o3 + 2 * k + 1] = 2.0 * rho_new / delta;
       rho = rho_new;
     }
-    HIP_TRY(hipMemcpyAsync(m.d_coef, h, (size_t)(16 + 2 * k3) * sizeof(double), hipMemcpyHostToDevice, s->stream));
+    HIP_TRY(hipMemcpyAsync(m.d_coef, h, (size_t)(o3 + 2 * k3) * sizeof(double), hipMemcpyHostToDevice, s->stream));
     return 0;
   }
   const int kc = pmg_coarse_degree_eff(s), oc = pmg_cf_coarse(s);
@@ -2940,7 +3068,7 @@ static int pmg_apply(tlfea_newton_t s, const double* d_r, double* d_z, double* r
   // r.z slots weigh owned DOFs only.
   const bool hal = s->halo.on;
   const int Nf = hal ? s->halo.rows(halo_dr(s)) : N;
-  const bool weighted = pmg_smoother_kind() != 1 && !m.agg.ok;  // fourth-kind smoother: z^ += beta_k d
+  const bool weighted = pmg_smoother_kind() != 1;  // fourth-kind smoother: z^ += beta_k d
   const double* betas = cf + pmg_cf_beta(s);
   auto fine = [&](const double* co, bool last, const double* zw) {  // one fine pass; the ping-pong partners swap roles
     C32Bnd bnd = hal ? C32Bnd{nullptr, nullptr, s->d_w} : C32Bnd();
@@ -2964,25 +3092,47 @@ static int pmg_apply(tlfea_newton_t s, const double* d_r, double* d_z, double* r
     float *a_d = g.d_f32, *a_d2 = a_d + n3, *a_z = a_d2 + n3, *a_z2 = a_z + n3, *a_r = a_z2 + n3, *a_r2 = a_r + n3;
     const float* Dinv_f3 = a_r2 + n3;
     const Incidence inc_3 = g.inc();
-#define TLFEA_L2(dold, co, dnew, zold, znew, rold, rnew)                                                                  \
-  launch_cheb32(s->stream, Nc, m.nnz_c, inc_c, m.d_B8c, m.d_B1c, bits, Dinv_fc, m.d_sc_c, dold, co, dnew, zold, znew, rold, \
-                rnew, d_r, d_z, rz_part, false)
-    TLFEA_L2(c_d, cf + 10, c_d2, c_z, c_z2, c_r, c_r2);   // Chebyshev step
-    TLFEA_L2(c_d2, cf + 12, c_d, c_z2, c_z, c_r2, c_r);   // (0,0): residual of the result; z^, res^ back in c_z, c_r
-    launch_agg_restrict_init(s->stream, g.N3, g.d_mem_off, g.d_mem, g.d_rvec, c_r, m.d_sc_c, g.d_sc3, Dinv_f3, cf + 16, a_d,
-                             a_z, a_r);
+    const int ks2 = pmg_ks2(s), o3 = pmg_cf_level3(s);
+    // Overlapping partition: as in the two-level branch below -- a refresh makes the vertex-level vectors exact on every
+    // ghost layer, a product gives up one (the first after a refresh two) -- with the third level REPLICATED: its residual
+    // is summed over the ranks' owned members (one small all-reduce), its polynomial runs redundantly with no exchange,
+    // and its correction is exact on every vertex a rank holds (so it does not touch the validity count).
+    const int G = s->halo.depth;
+    int valid = 0;
+    auto mid = [&](const double* co) -> int {  // one vertex-level pass; the ping-pong partners swap roles
+      if (hal && valid < 1) {
+        TRY(halo_refresh_f32(s, 1, G, 3, c_d, c_z, c_r));
+        valid = G - 1;
+      }
+      launch_cheb32(s->stream, Nc, m.nnz_c, inc_c, m.d_B8c, m.d_B1c, bits, Dinv_fc, m.d_sc_c, c_d, co, c_d2, c_z, c_z2, c_r, c_r2,
+                    d_r, d_z, rz_part, false);
+      valid--;
+      std::swap(c_d, c_d2);
+      std::swap(c_z, c_z2);
+      std::swap(c_r, c_r2);
+      return 0;
+    };
+    for (int k = 1; k < ks2; k++) TRY(mid(cf + o_c + 2 * k));   // Chebyshev steps of the pre-smoother
+    TRY(mid(cf + o_c + 2 * ks2));                               // (0,0): residual of the result
+    if (hal) {
+      launch_agg_restrict(s->stream, g.N3, g.d_mem_off, g.d_mem, g.d_rvec, c_r, m.d_sc_c, g.d_r3);
+      TRY(call_allreduce(s, g.d_r3, 3 * g.N3));
+      launch_agg_init3(s->stream, g.N3, g.d_r3, g.d_sc3, Dinv_f3, cf + o3, a_d, a_z, a_r);
+    } else
+    launch_agg_restrict_init(s->stream, g.N3, g.d_mem_off, g.d_mem, g.d_rvec, c_r, m.d_sc_c, g.d_sc3, Dinv_f3, cf + o3, a_d, a_z,
+                             a_r);
     const int k3 = pmg_level3_degree(g.N3);
     for (int k = 1; k < k3; k++) {
-      launch_cheb32(s->stream, g.N3, g.nnz3, inc_3, g.d_B8, g.d_B1, bits, Dinv_f3, g.d_sc3, a_d, cf + 16 + 2 * k, a_d2, a_z,
+      launch_cheb32(s->stream, g.N3, g.nnz3, inc_3, g.d_B8, g.d_B1, bits, Dinv_f3, g.d_sc3, a_d, cf + o3 + 2 * k, a_d2, a_z,
                     a_z2, a_r, a_r2, d_r, d_z, rz_part, false);
       std::swap(a_d, a_d2);
       std::swap(a_z, a_z2);
       std::swap(a_r, a_r2);
     }
     launch_agg_prolong(s->stream, Nc, g.d_agg, g.d_rvec, a_z, g.d_sc3, m.d_sc_c, c_z, c_d);  // z^ += corr ; d := corr
-    TLFEA_L2(c_d, cf + 14, c_d2, c_z, c_z2, c_r, c_r2);   // (0, 1/theta): res^ -= Hs corr, restart
-    TLFEA_L2(c_d2, cf + 10, c_d, c_z2, c_z, c_r2, c_r);   // second term; the vertex-level result is in c_z
-#undef TLFEA_L2
+    TRY(mid(cf + o_c + 2 * ks2 + 2));                           // (0, 1/theta): res^ -= Hs corr, restart
+    for (int k = 1; k < ks2; k++) TRY(mid(cf + o_c + 2 * k));   // the remaining terms; the vertex-level result is in c_z
+    if (hal && valid < ks + 1) TRY(halo_refresh_f32(s, 1, ks + 1, 3, c_z));  // the prolongation needs ks + 1 layers
   } else {
     const int kc = pmg_coarse_degree_eff(s);
     // Overlapping partition: the restricted residual is exact on the owned vertices only.  A refresh makes the three
@@ -3617,6 +3767,21 @@ extern "C" int tlfea_newton_pmg3_retrieve(tlfea_newton_t s, int* agg, double* rv
   return 0;
 }
 
+// shape of the p-multigrid cycle a solve would run now: out6 = levels (0: none), fine smoother terms, vertex-level smoother
+// terms (three levels) or 0, vertex-level polynomial degree (two levels) or 0, level-3 polynomial degree or 0, level-3 nodes
+extern "C" int tlfea_newton_pmg_cycle_info(tlfea_newton_t s, int* out6) {
+  if (!s || !out6) return fail("null argument");
+  for (int k = 0; k < 6; k++) out6[k] = 0;
+  if (precond_eff(s) != 2 || !s->pmg.ok) return 0;
+  const bool l3 = s->pmg.agg.ok;
+  out6[0] = l3 ? 3 : 2;
+  out6[1] = pmg_ks(s);
+  out6[2] = l3 ? pmg_ks2(s) : 0;
+  out6[3] = l3 ? 0 : pmg_coarse_degree_eff(s);
+  out6[4] = l3 ? pmg_level3_degree(s->pmg.agg.N3) : 0;
+  out6[5] = l3 ? s->pmg.agg.N3 : 0;
+  return 0;
+}
 extern "C" int tlfea_newton_pmg_coarse_degree(tlfea_newton_t s) { return s && s->pmg.ok ? pmg_coarse_degree_eff(s) : 0; }
 extern "C" int tlfea_newton_get_precond(tlfea_newton_t s) {  // 1 Chebyshev polynomial, 2 p-multigrid (what a solve would use now)
   if (!s) return -1;

@@ -240,6 +240,10 @@ void launch_agg_galerkin(hipStream_t s, int n_pairs, const int* pair_A, const in
 void launch_agg_restrict_init(hipStream_t s, int N3, const int* mem_off, const int* mem, const double* rvec,
                               const float* res2, const double* sc2, const double* sc3, const float* Dinv3,
                               const double* coef3, float* d3, float* z3, float* res3);
+void launch_agg_restrict(hipStream_t s, int N3, const int* mem_off, const int* mem, const double* rvec, const float* res2,
+                         const double* sc2, double* r3);
+void launch_agg_init3(hipStream_t s, int N3, const double* r3, const double* sc3, const float* Dinv3, const double* coef3,
+                      float* d3, float* z3, float* res3);
 void launch_agg_prolong(hipStream_t s, int Nc, const int* agg, const double* rvec, const float* z3, const double* sc3,
                         const double* sc2, float* z2, float* d2);
 void launch_pmg_prolong(hipStream_t s, int N, const int* par0, const int* par1, const float* z_c, const double* sc_c,

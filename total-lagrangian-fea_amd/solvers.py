@@ -93,6 +93,13 @@ class SyncedNewtonSolver:
         check(self._lib.tlfea_newton_pmg_retrieve(self._h, ip(par0), ip(par1), ip(c_off), ip(c_cols), dp(Hc)))
         return par0, par1, c_off, c_cols, Hc
 
+    def GetPmgCycleInfo(self):
+        """dict(levels, fine_terms, vertex_terms, vertex_degree, level3_degree, level3_nodes) of the cycle in use (levels 0:
+        polynomial preconditioner)"""
+        out = (C.c_int * 6)()
+        check(self._lib.tlfea_newton_pmg_cycle_info(self._h, out))
+        return dict(zip(("levels", "fine_terms", "vertex_terms", "vertex_degree", "level3_degree", "level3_nodes"), list(out)))
+
     def GetPmgLevel3Info(self):
         """(aggregates, 3x3 blocks, polynomial degree) of the third level, (0, 0, 0) when the cycle has two levels"""
         na, nnz, deg = C.c_int(), C.c_int(), C.c_int()
@@ -289,7 +296,7 @@ class SyncedNewtonSolver:
         so, ro = off(part.send), off(part.recv)
         sn, sl, rn = cat(part.send), cat(part.send_layer), cat(part.recv)
         layer = np.ascontiguousarray(part.layer, dtype=np.int32)
-        lists = HaloListsC(P, ip(peers), ip(so), ip(sn), ip(sl), ip(ro), ip(rn))
+        lists = HaloListsC(P, ip(peers), ip(so), ip(sn), ip(sl), ip(ro), ip(rn), int(part.rank), int(part.world))
         self._halo_keep = (peers, so, ro, sn, sl, rn, layer, lists)
         if rccl_comm is not None:
             self._lib.tlfea_rccl_allreduce_fn.restype = C.c_void_p
