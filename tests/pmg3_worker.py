@@ -57,13 +57,16 @@ def main(mesh):
                     rows.append(3 * i + a); cols.append(6 * A + 3 + b); vals.append(S[a, b])
     P2 = sp.csr_matrix((vals, (rows, cols)), shape=(3 * nc, 6 * na))
     ref = (P2.T @ A1 @ P2).toarray()
-    for A in np.where(active == 0)[0]:
+    for A in np.where(active <= 0)[0]:          # unusable rotations (0) and empty grid cells (-1): identity rows
         ref[6 * A + 3:6 * A + 6, 6 * A + 3:6 * A + 6] = np.eye(3)
+    for A in np.where(active < 0)[0]:
+        ref[6 * A:6 * A + 3, 6 * A:6 * A + 3] = np.eye(3)
     dev = dof_csr(off3, cols3, H3, 2 * na).toarray()
     out["galerkin_relerr"] = float(np.abs(dev - ref).max() / np.abs(ref).max())
     out["pattern_covers"] = bool(np.all((np.abs(ref) > 0) <= (dof_csr(off3, cols3, np.ones_like(H3), 2 * na).toarray() > 0)))
     out["sizes"] = [int(np.bincount(agg).min()), int(np.bincount(agg).max())]
     out["inactive"] = int((active == 0).sum())
+    out["empty_cells"] = int((active < 0).sum())
     sym = np.abs(dev - dev.T).max() / np.abs(dev).max()
     out["symmetry"] = float(sym)
     w = np.linalg.eigvalsh(0.5 * (dev + dev.T))
