@@ -539,6 +539,20 @@ void launch_cheb_step(hipStream_t s, int N, const Incidence& inc, const double* 
 // 16/32-byte record and the 9th in a side array, so ONE lane streams one block with two loads and gathers its
 // three vector entries; the steps work in the scaled space (d^ = S^-1 d, res^ = S res) and the last one returns
 // z = S z^.
+// 8-bit storage of the scaled matrix (experiment, TLFEA_FINE_BITS=8): OCP e4m3 as gfx950 converts it in hardware
+// (3 mantissa bits: 6 % relative error per entry, entries of S H S lie in [-1, 1])
+struct Fp8 {
+  unsigned char x;
+  Fp8() = default;
+  __device__ __forceinline__ Fp8(int) : x(0) {}
+  __device__ __forceinline__ explicit Fp8(double h) {
+    // stored times 256: e4m3 is normal down to 2^-6, so entries keep 3 mantissa bits down to 2^-14 of the diagonal
+    x = (unsigned char)(__builtin_amdgcn_cvt_pk_fp8_f32((float)h * 256.f, 0.f, 0, false) & 0xff);
+  }
+  __device__ __forceinline__ explicit operator float() const {
+    return __builtin_amdgcn_cvt_f32_fp8((int)x, 0) * 0.00390625f;
+  }
+};
 template <typename HT>
 struct alignas(8 * sizeof(HT)) Blk8 {
   HT v[8];
@@ -607,7 +621,9 @@ __global__ __launch_bounds__(256) void lp_convert_kernel(int N, Incidence inc, c
 void launch_lp_convert(hipStream_t s, int N, const Incidence& inc, const double* Hval, const double* sc, const int* own,
                        const double* Dglob, void* B8, void* B1, int bits) {
   const dim3 g((N + 7) / 8), b(256);
-  if (bits == 16)
+  if (bits == 8)
+    hipLaunchKernelGGL((lp_convert_kernel<Fp8>), g, b, 0, s, N, inc, Hval, sc, own, Dglob, (Blk8<Fp8>*)B8, (Fp8*)B1);
+  else if (bits == 16)
     hipLaunchKernelGGL((lp_convert_kernel<_Float16>), g, b, 0, s, N, inc, Hval, sc, own, Dglob, (Blk8<_Float16>*)B8,
                        (_Float16*)B1);
   else
@@ -1099,7 +1115,9 @@ void launch_cheb32(hipStream_t s, int N, int nnz_coef, const Incidence& inc, con
   if (forced == 8 || forced == 16 || forced == 32) L = forced;
 #define TLFEA_C32(T, LL) \
   launch_cheb32_t<T, LL>(s, N, inc, B8, B1, Dinv_f, sc, d_old, coef, d_new, z, z_new, res, res_new, r, z_out, rz_part, last, bnd)
-  if (bits == 16) {
+  if (bits == 8) {
+    TLFEA_C32(Fp8, 16);   // fine level of T10 meshes only (the experiment's scope)
+  } else if (bits == 16) {
     if (L == 32) TLFEA_C32(_Float16, 32);
     else if (L == 8) TLFEA_C32(_Float16, 8);
     else TLFEA_C32(_Float16, 16);

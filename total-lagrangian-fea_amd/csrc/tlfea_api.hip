@@ -2248,17 +2248,24 @@ static int cheb_bits_eff(tlfea_newton_t s) {
   return s->lin.cheb_bits == 0 ? 16 : s->lin.cheb_bits;
 }
 
-// (re)build the low-precision copy from the current H and block diagonal (d_D, d_Dinv must be current)
+// storage of the FINE level's streamed copy inside the p-multigrid cycle: TLFEA_FINE_BITS=8 (experiment) stores it as
+// fp8 e4m3 -- 13 instead of 22 bytes per block in the cycle's four fine passes; the coarser levels keep fp16
 static int precond_eff(tlfea_newton_t s);
+static int fine_bits(tlfea_newton_t s) {
+  static const int forced = std::getenv("TLFEA_FINE_BITS") ? std::atoi(std::getenv("TLFEA_FINE_BITS")) : 0;
+  const int bits = cheb_bits_eff(s);
+  return (forced == 8 && bits == 16 && precond_eff(s) == 2 && !s->ar) ? 8 : bits;
+}
+// (re)build the low-precision copy from the current H and block diagonal (d_D, d_Dinv must be current)
 static int lp_build(tlfea_newton_t s) {
   tlfea_t10_t d = s->d;
-  const int bits = cheb_bits_eff(s);
+  const int bits = fine_bits(s);
   if (bits == 64) return 0;
   if (s->lp_bits_alloc != bits) {
     if (s->d_B8) (void)hipFree(s->d_B8);
     if (s->d_B1) (void)hipFree(s->d_B1);
     s->d_B8 = s->d_B1 = nullptr;
-    const size_t eb = bits / 8;
+    const size_t eb = std::max(1, bits / 8);
     HIP_TRY(hipMalloc(&s->d_B8, (size_t)d->nnz_coef * 8 * eb));
     HIP_TRY(hipMalloc(&s->d_B1, (size_t)d->nnz_coef * eb));
     s->lp_bits_alloc = bits;
@@ -2386,7 +2393,7 @@ static int cheb_apply(tlfea_newton_t s, const double* d_r, double* d_z, double* 
     for (int k = 1; k < deg; k++) {
       const bool last = (k == deg - 1);
       if (hal) TRY(halo_refresh_f32(s, 0, 1, 3, f_d));
-      launch_cheb32(s->stream, Nr, d->nnz_coef, d->inc(), s->d_B8, s->d_B1, bits, Dinv_f, sc, f_d, s->d_coef + 2 * k, f_d2,
+      launch_cheb32(s->stream, Nr, d->nnz_coef, d->inc(), s->d_B8, s->d_B1, fine_bits(s), Dinv_f, sc, f_d, s->d_coef + 2 * k, f_d2,
                     f_z, f_z2, f_r, f_r2, d_r, d_z, rz_part, last, bnd);
       std::swap(f_d, f_d2);
       std::swap(f_z, f_z2);
@@ -3073,8 +3080,8 @@ static int pmg_apply(tlfea_newton_t s, const double* d_r, double* d_z, double* r
   auto fine = [&](const double* co, bool last, const double* zw) {  // one fine pass; the ping-pong partners swap roles
     C32Bnd bnd = hal ? C32Bnd{nullptr, nullptr, s->d_w} : C32Bnd();
     bnd.zw = weighted ? zw : nullptr;
-    launch_cheb32(s->stream, Nf, d->nnz_coef, inc_f, s->d_B8, s->d_B1, bits, Dinv_f, s->d_sc, f_d, co, f_d2, f_z, f_z2, f_r, f_r2,
-                  d_r, d_z, rz_part, last, bnd);
+    launch_cheb32(s->stream, Nf, d->nnz_coef, inc_f, s->d_B8, s->d_B1, fine_bits(s), Dinv_f, s->d_sc, f_d, co, f_d2, f_z, f_z2, f_r,
+                  f_r2, d_r, d_z, rz_part, last, bnd);
     std::swap(f_d, f_d2);
     std::swap(f_z, f_z2);
     std::swap(f_r, f_r2);
@@ -3867,7 +3874,7 @@ extern "C" int tlfea_newton_time_kernels(tlfea_newton_t s, int reps, double* out
         const int kc = pmg_coarse_degree_eff(s), bits = cheb_bits_eff(s);
         auto fine = [&](int a) {
           const int b = 1 - a;
-          launch_cheb32(s->stream, N, d->nnz_coef, d->inc(), s->d_B8, s->d_B1, bits, f + 6 * n, s->d_sc, f + a * n,
+          launch_cheb32(s->stream, N, d->nnz_coef, d->inc(), s->d_B8, s->d_B1, fine_bits(s), f + 6 * n, s->d_sc, f + a * n,
                         m.d_coef + 2, f + b * n, f + (2 + a) * n, f + (2 + b) * n, f + (4 + a) * n, f + (4 + b) * n, s->d_r,
                         s->d_zv, part(s, 0), false);
         };
@@ -3892,7 +3899,7 @@ extern "C" int tlfea_newton_time_kernels(tlfea_newton_t s, int reps, double* out
         const size_t n = 3 * (size_t)N;                          // cheb_apply (each step reads what the last one wrote)
         float* f = s->d_f32;
         const int a = r & 1, b = 1 - a;
-        launch_cheb32(s->stream, N, d->nnz_coef, d->inc(), s->d_B8, s->d_B1, cheb_bits_eff(s), f + 6 * n, s->d_sc,
+        launch_cheb32(s->stream, N, d->nnz_coef, d->inc(), s->d_B8, s->d_B1, fine_bits(s), f + 6 * n, s->d_sc,
                       f + a * n, s->d_coef + 2, f + b * n, f + (2 + a) * n, f + (2 + b) * n, f + (4 + a) * n,
                       f + (4 + b) * n, s->d_r, s->d_zv, part(s, 0), false);
       } else if (cheb_bits_eff(s) != 64 && s->d_B8)
