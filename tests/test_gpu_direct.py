@@ -1,7 +1,11 @@
-"""Sparse direct linear solve (tlfea_linsolve_opts.method = 1): rocSOLVER's Cholesky re-factorisation on the ordering and
-factor pattern of csrc/direct_host.h -- the counterpart of the reference's cuDSS analysis-once / refactor-per-iteration
-(SyncedNewton.cu:995-1029, 1103-1114).  Checked against the oracle's direct solve and against the iterative path."""
+"""Sparse direct linear solve (tlfea_linsolve_opts.method = 1): the engine's own multifrontal Cholesky (csrc/mf_host.h plan,
+csrc/direct_kernels.hip) -- the counterpart of the reference's cuDSS analysis-once / refactor-per-iteration
+(SyncedNewton.cu:995-1029, 1103-1114).  Checked against the oracle's direct solve and against the iterative path.
+The rocSOLVER backend (TLFEA_DIRECT_BACKEND=rocsolver) stays available and is tested in its own process only."""
 import importlib
+import os
+import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -10,22 +14,9 @@ from oracle import orc
 from tests.helpers import MATERIALS, fixed_x0, load_mesh, make_gpu, make_oracle
 from tests.test_gpu_parity import disp_err_ok
 
-import os
-
 tl = importlib.import_module("total-lagrangian-fea_amd")
-# Opt-in (TLFEA_TEST_DIRECT=1), for two measured reasons (round 3, gpurun_out -> profiles/r03_direct_solver_tests.log):
-#  * resolving rocSOLVER maps librocsolver + librocsparse + librocblas (1.4 GB of code objects): on a fresh GPU box the
-#    two smallest cases take 437 s in a child process (260 s for all five in round 2) -- half of the 900 s the round-end
-#    suite is given;
-#  * a process that has mapped /opt/rocm's copies of those libraries and LATER imports torch (whose wheel carries its own)
-#    crashes inside the import (segmentation fault in the GPU suite when these ran in-process ahead of a torch test).
-# tools/verify_head.sh runs this file in its own process at round end and the log is committed under profiles/.
-# method = 1 is the exact option for small systems, not a fast path: re-factor + solve 0.35 s at 12 675 DOF, 2.6 s at
-# config B (profiles/r02_direct_solver_timing.txt).
-pytestmark = [pytest.mark.gpu,
-              pytest.mark.skipif(not os.environ.get("TLFEA_TEST_DIRECT"),
-                                 reason="opt-in TLFEA_TEST_DIRECT=1: cold load of rocSOLVER/rocSPARSE takes 4-7 minutes on a "
-                                        "fresh box; run in its own process (see profiles/r03_direct_solver_tests.log)")]
+pytestmark = [pytest.mark.gpu]
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def pair(mesh, mat):
@@ -90,3 +81,70 @@ def test_direct_and_iterative_solutions_agree(mesh):
     assert np.array_equal(xd, xd2)
     del s
     d.Destroy()
+
+
+def test_direct_large_front_config_b():
+    """Config B's cube (46 875 DOF): the top separator is a ~1 900-DOF dense front, i.e. ~40 panel steps on one front and
+    update grids of several hundred tiles -- the multi-tile paths the small meshes do not reach."""
+    X, conn = tl.mesh_utils.structured_t10_box(12, 12, 12)
+    fixed = np.where(X[:, 2] < 1e-12)[0].astype(np.int32)
+    d = make_gpu(X, conn, MATERIALS["neo"], fixed)
+    x = X + 5e-3 * np.sin(np.pi * X)
+    d.UpdatePositions(x[:, 0], x[:, 1], x[:, 2])
+    s = tl.SyncedNewtonSolver(d, d.get_n_constraint())
+    s.SetParameters(tl.SyncedNewtonParams(1e-4, 1e-6, 1e-4, 1e14, 5, 10, 1e-3))
+    s.AssembleHessian()
+    b = np.random.default_rng(11).normal(size=3 * X.shape[0])
+    s.SetLinSolveOpts(tl.LinSolveOpts(method=1))
+    xd, it_d, rel_d = s.LinearSolve(b)
+    assert it_d == 1 and rel_d < 1e-10, rel_d
+    assert np.linalg.norm(s.ApplyHessian(xd) - b) <= 1e-10 * np.linalg.norm(b)
+    s.SetLinSolveOpts(tl.LinSolveOpts(1e-13, 20000, 10))
+    xi, _, _ = s.LinearSolve(b)
+    assert np.linalg.norm(xd - xi) <= 1e-7 * np.linalg.norm(xi)
+    del s
+    d.Destroy()
+
+
+def test_direct_reports_indefinite_matrix():
+    """A pivot that is not positive fails the call with a message (cuDSS reports the same through its info query)."""
+    X, conn = load_mesh("res2")
+    d = make_gpu(X, conn, MATERIALS["svk"], fixed_x0(X))
+    s = tl.SyncedNewtonSolver(d, d.get_n_constraint())
+    s.SetParameters(tl.SyncedNewtonParams(-1e-4, 0.0, 1e-4, 1e14, 5, 10, 1e-3))   # negative step: H = M/h + hK is indefinite
+    s.AssembleHessian()
+    s.SetLinSolveOpts(tl.LinSolveOpts(method=1))
+    with pytest.raises(RuntimeError, match="not positive"):
+        s.LinearSolve(np.ones(3 * X.shape[0]))
+    del s
+    d.Destroy()
+
+
+@pytest.mark.skipif(not os.environ.get("TLFEA_TEST_DIRECT"),
+                    reason="opt-in TLFEA_TEST_DIRECT=1: the rocSOLVER backend maps librocsolver/librocsparse/librocblas "
+                           "(1.4 GB of code objects, 4-7 minutes cold on a fresh box; profiles/r03_direct_solver_tests.log)")
+def test_rocsolver_backend_in_its_own_process():
+    """The rocSOLVER backend against the engine's own factorisation, in a child process (a process that has mapped
+    /opt/rocm's rocBLAS must not import torch afterwards)."""
+    code = (
+        "import importlib, numpy as np, os\n"
+        "from tests.helpers import MATERIALS, fixed_x0, load_mesh, make_gpu\n"
+        "tl = importlib.import_module('total-lagrangian-fea_amd')\n"
+        "X, conn = load_mesh('res2')\n"
+        "d = make_gpu(X, conn, MATERIALS['svk'], fixed_x0(X))\n"
+        "s = tl.SyncedNewtonSolver(d, d.get_n_constraint())\n"
+        "s.SetParameters(tl.SyncedNewtonParams(1e-4, 1e-6, 1e-4, 1e14, 5, 10, 1e-3))\n"
+        "s.AssembleHessian()\n"
+        "b = np.random.default_rng(3).normal(size=3 * X.shape[0])\n"
+        "s.SetLinSolveOpts(tl.LinSolveOpts(method=1))\n"
+        "x, it, rel = s.LinearSolve(b)\n"
+        "np.save(os.environ['OUT'], x)\n"
+        "assert rel < 1e-9\n")
+    outs = []
+    for be in ("native", "rocsolver"):
+        out = os.path.join(ROOT, "gpurun_out", f"direct_{be}.npy")
+        os.makedirs(os.path.dirname(out), exist_ok=True)
+        env = dict(os.environ, TLFEA_DIRECT_BACKEND=be, OUT=out)
+        subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, check=True, timeout=840)
+        outs.append(np.load(out))
+    assert np.linalg.norm(outs[0] - outs[1]) <= 1e-9 * np.linalg.norm(outs[1])

@@ -1,0 +1,342 @@
+// direct_kernels.hip -- the engine's own sparse direct solve on gfx950: multifrontal Cholesky of H on the plan of
+// mf_host.h.  What it replaces: cuDSS REFACTORIZATION + SOLVE in the reference's Newton loop (SyncedNewton.cu:1103-1114).
+//
+// A level of the dissection tree is a batch of independent dense fronts (column-major, lower triangle used) that live in
+// HBM / L2 (a T10 leaf front is ~400 DOF = 1.3 MB: no front fits the LDS).  Per level:
+//   zero the level's workspace -> scatter H's lower node blocks -> extend-add child 0, then child 1 (fixed order) ->
+//   panel steps of kMfNB = 48 columns over the fronts that still have columns:
+//     panel  : every workgroup re-factors the 48x48 diagonal block in LDS (one wavefront, left-looking: 1128 fused
+//              multiply-adds -- cheaper than a launch that would do it once) and solves its 256 rows of the panel against
+//              it, one row per lane held in registers (L21 = F21 L11^-T); the panel goes to the factor's storage
+//     update : F22 -= L21 L21^T on 64x64 tiles, 4x4 per lane from LDS-staged panels (fp64 vector FMA: the MI355X's fp64
+//              matrix rate equals its vector rate, so MFMA would buy nothing here)
+//   what remains below/right of the own columns is the update matrix the parent adds into its front.
+// Solve: forward by levels (front vector = right-hand side of the own DOFs + the children's remainders, through the same
+// maps), backward from the root; one workgroup per front.  No atomics anywhere: same H, same bits.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+
+#include "tlfea_internal.h"
+
+namespace tlfea {
+
+namespace {
+constexpr int NB = kMfNB;
+
+__device__ __forceinline__ void wave_sync_d() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// 3x3 node blocks of H (row-major inside a node row, stride sld) -> the front (column-major, stride dld)
+__global__ void mf_scatter_h_kernel(int n, const long long* __restrict__ src, const int* __restrict__ sld,
+                                    const long long* __restrict__ dst, const int* __restrict__ dld,
+                                    const double* __restrict__ H, double* __restrict__ W) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= 9LL * n) return;
+  const int ent = (int)(t / 9), de = (int)(t % 9), d = de / 3, e = de % 3;
+  W[dst[ent] + d + (long long)e * dld[ent]] = H[src[ent] + (long long)d * sld[ent] + e];
+}
+
+// parent front += the child's update matrix (rows/columns below its own), node block by node block
+__global__ __launch_bounds__(256) void mf_extend_add_kernel(const MfFrontDev* __restrict__ fr, const int* __restrict__ lvl,
+                                                           int slot, double* __restrict__ Wp,
+                                                           const double* __restrict__ Wc, const int* __restrict__ map) {
+  const MfFrontDev f = fr[lvl[blockIdx.z]];
+  const int c = slot ? f.child1 : f.child0;
+  if (c < 0) return;
+  const MfFrontDev ch = fr[c];
+  const int mu = (ch.m - ch.k) / 3;
+  const int i = blockIdx.x * 16 + (threadIdx.x & 15), j = blockIdx.y * 16 + (threadIdx.x >> 4);
+  if (i >= mu || j > i) return;
+  const int* mp = map + ch.map_off;
+  const double* U = Wc + ch.F_off + (ch.k + 3 * i) + (long long)(ch.k + 3 * j) * ch.m;
+  double* A = Wp + f.F_off + 3LL * mp[i] + 3LL * mp[j] * f.m;
+#pragma unroll
+  for (int e = 0; e < 3; e++)
+#pragma unroll
+    for (int d = 0; d < 3; d++)
+      if (i > j || d >= e) A[d + (long long)e * f.m] += U[d + (long long)e * ch.m];
+}
+
+__global__ __launch_bounds__(256) void mf_panel_kernel(const MfFrontDev* __restrict__ fr, const int* __restrict__ lvl, int j0,
+                                                      const double* __restrict__ W, double* __restrict__ Ls,
+                                                      int* __restrict__ err) {
+  const MfFrontDev f = fr[lvl[blockIdx.y]];
+  const int m = f.m, k = f.k;
+  if (k <= j0) return;
+  const int jb = min(NB, k - j0);
+  const int r0 = j0 + jb + blockIdx.x * 256;
+  if (blockIdx.x > 0 && r0 >= m) return;
+  __shared__ double A[NB][NB + 1];
+  __shared__ double dinv[NB];
+  const double* F = W + f.F_off;
+  double* L = Ls + f.L_off;
+  const int tid = threadIdx.x;
+  // the diagonal block, padded with the identity to NB columns
+  for (int idx = tid; idx < NB * NB; idx += 256) {
+    const int r = idx % NB, c = idx / NB;
+    A[r][c] = (r < jb && c < jb && r >= c) ? F[(long long)(j0 + r) + (long long)(j0 + c) * m] : (r == c ? 1.0 : 0.0);
+  }
+  __syncthreads();
+  if (tid < 64) {  // one wavefront, lane r owns row r: left-looking Cholesky
+    const int r = tid;
+#pragma unroll 1
+    for (int c = 0; c < NB; c++) {  // (rolled: unrolled over c and p the compiler spills ~1900 VGPRs)
+      double s = 0.0;
+      if (r >= c && r < NB) {
+        s = A[r][c];
+#pragma unroll 4
+        for (int p = 0; p < c; p++) s -= A[r][p] * A[c][p];
+      }
+      wave_sync_d();
+      if (r == c) {
+        if (!(s > 0.0)) {
+          *err = 1;  // not positive definite: the caller reports it; keep the arithmetic finite
+          s = 1.0;
+        }
+        const double piv = sqrt(s);
+        A[c][c] = piv;
+        dinv[c] = 1.0 / piv;
+      }
+      wave_sync_d();
+      if (r > c && r < NB) A[r][c] = s * dinv[c];
+      wave_sync_d();
+    }
+  }
+  __syncthreads();
+  if (blockIdx.x == 0)
+    for (int idx = tid; idx < NB * NB; idx += 256) {
+      const int r = idx % NB, c = idx / NB;
+      if (r < jb && c <= r) L[(long long)(j0 + r) + (long long)(j0 + c) * m] = A[r][c];
+    }
+  const int rr = r0 + tid;
+  if (rr >= m) return;
+  double X[NB];
+  {
+    const double* Fp = F + (long long)rr + (long long)j0 * m;
+#pragma unroll
+    for (int c = 0; c < NB; c++) {
+      X[c] = c < jb ? *Fp : 0.0;
+      if (c + 1 < jb) Fp += m;
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < NB; c++) {
+    double s = X[c];
+    // volatile: the broadcast LDS reads of row c stay next to their use (hoisted above the loop nest they spill 1900 VGPRs)
+    const volatile double* Ac = A[c];
+#pragma unroll
+    for (int p = 0; p < c; p++) s -= X[p] * Ac[p];
+    X[c] = s * dinv[c];
+  }
+  // unconditional stores, last column first: the padding columns (X = 0) land on column jb - 1 BEFORE its own value does
+  // (a store per column under `if (c < jb)` makes the compiler spill ~1900 VGPRs)
+  double* Lp = L + (long long)rr + (long long)j0 * m;
+#pragma unroll
+  for (int c = NB - 1; c >= 0; c--) Lp[(long long)min(c, jb - 1) * m] = X[c];
+}
+
+__global__ __launch_bounds__(256) void mf_update_kernel(const MfFrontDev* __restrict__ fr, const int* __restrict__ lvl, int j0,
+                                                       double* __restrict__ W, const double* __restrict__ Ls) {
+  const MfFrontDev f = fr[lvl[blockIdx.z]];
+  const int m = f.m, k = f.k;
+  if (k <= j0) return;
+  const int jb = min(NB, k - j0), base = j0 + jb;
+  const int I = blockIdx.x, J = blockIdx.y;
+  if (J > I || base + I * 64 >= m) return;
+  __shared__ double Pi[NB][64], Pj[NB][64];
+  const double* L = Ls + f.L_off;
+  double* F = W + f.F_off;
+  const int tid = threadIdx.x;
+  for (int idx = tid; idx < NB * 64; idx += 256) {
+    const int c = idx >> 6, r = idx & 63;
+    const int gi = base + I * 64 + r, gj = base + J * 64 + r;
+    Pi[c][r] = (c < jb && gi < m) ? L[(long long)gi + (long long)(j0 + c) * m] : 0.0;
+    Pj[c][r] = (c < jb && gj < m) ? L[(long long)gj + (long long)(j0 + c) * m] : 0.0;
+  }
+  __syncthreads();
+  const int tx = tid & 15, ty = tid >> 4;
+  double acc[4][4] = {};
+  for (int c = 0; c < jb; c++) {
+    double a[4], b[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      a[i] = Pi[c][4 * tx + i];
+      b[i] = Pj[c][4 * ty + i];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+      for (int j = 0; j < 4; j++) acc[i][j] += a[i] * b[j];
+  }
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int gj = base + J * 64 + 4 * ty + j;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int gi = base + I * 64 + 4 * tx + i;
+      if (gi < m && gj <= gi) F[(long long)gi + (long long)gj * m] -= acc[i][j];
+    }
+  }
+}
+
+__global__ __launch_bounds__(512) void mf_forward_kernel(const MfFrontDev* __restrict__ fr, const int* __restrict__ lvl,
+                                                        const double* __restrict__ Ls, const int* __restrict__ map,
+                                                        const int* __restrict__ order, const double* __restrict__ b,
+                                                        double* __restrict__ v, double* __restrict__ y) {
+  const MfFrontDev f = fr[lvl[blockIdx.x]];
+  const int m = f.m, k = f.k, tid = threadIdx.x, nt = blockDim.x;
+  double* w = v + f.v_off;
+  const double* L = Ls + f.L_off;
+  for (int i = tid; i < m; i += nt) w[i] = i < k ? b[3 * order[f.c0 + i / 3] + i % 3] : 0.0;
+  __syncthreads();
+  for (int s = 0; s < 2; s++) {
+    const int c = s ? f.child1 : f.child0;
+    if (c < 0) continue;
+    const MfFrontDev ch = fr[c];
+    const double* vc = v + ch.v_off + ch.k;
+    const int* mp = map + ch.map_off;
+    for (int i = tid; i < ch.m - ch.k; i += nt) w[3 * mp[i / 3] + i % 3] += vc[i];
+    __syncthreads();
+  }
+  __shared__ double ys[NB];
+  for (int j0 = 0; j0 < k; j0 += NB) {
+    const int jb = min(NB, k - j0);
+    if (tid < 64) {  // the block's triangle: one wavefront, lane r owns row r
+      const int r = tid;
+      double val = r < jb ? w[j0 + r] : 0.0;
+      for (int c = 0; c < jb; c++) {
+        const double yc = __shfl(val, c) / L[(long long)(j0 + c) + (long long)(j0 + c) * m];
+        if (r == c) val = yc;
+        else if (r > c && r < jb) val -= L[(long long)(j0 + r) + (long long)(j0 + c) * m] * yc;
+      }
+      if (r < jb) {
+        ys[r] = val;
+        w[j0 + r] = val;
+      }
+    }
+    __syncthreads();
+    for (int r = j0 + jb + tid; r < m; r += nt) {
+      double s = 0.0;
+      for (int c = 0; c < jb; c++) s += L[(long long)r + (long long)(j0 + c) * m] * ys[c];
+      w[r] -= s;
+    }
+    __syncthreads();
+  }
+  for (int i = tid; i < k; i += nt) y[3LL * f.c0 + i] = w[i];
+}
+
+__global__ __launch_bounds__(512) void mf_backward_kernel(const MfFrontDev* __restrict__ fr, const int* __restrict__ lvl,
+                                                         const double* __restrict__ Ls, const int* __restrict__ rows,
+                                                         const double* __restrict__ y, double* __restrict__ xp,
+                                                         double* __restrict__ v) {
+  const MfFrontDev f = fr[lvl[blockIdx.x]];
+  const int m = f.m, k = f.k, tid = threadIdx.x, nt = blockDim.x;
+  double* w = v + f.v_off;
+  const double* L = Ls + f.L_off;
+  for (int i = tid; i < m; i += nt) w[i] = i < k ? y[3LL * f.c0 + i] : xp[3LL * rows[f.rows_off + i / 3] + i % 3];
+  __syncthreads();
+  __shared__ double ys[NB];
+  const int wave = tid >> 6, lane = tid & 63, nw = nt >> 6;
+  for (int j0 = ((k - 1) / NB) * NB; j0 >= 0 && k > 0; j0 -= NB) {
+    const int jb = min(NB, k - j0);
+    for (int c = wave; c < jb; c += nw) {  // column c against everything already solved below the block
+      const double* Lc = L + (long long)(j0 + c) * m;
+      double s = 0.0;
+      for (int r = j0 + jb + lane; r < m; r += 64) s += Lc[r] * w[r];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
+      if (lane == 0) ys[c] = w[j0 + c] - s;
+    }
+    __syncthreads();
+    if (tid < 64) {
+      const int r = tid;
+      double val = r < jb ? ys[r] : 0.0;
+      for (int c = jb - 1; c >= 0; c--) {
+        const double xc = __shfl(val, c) / L[(long long)(j0 + c) + (long long)(j0 + c) * m];
+        if (r == c) val = xc;
+        else if (r < c) val -= L[(long long)(j0 + c) + (long long)(j0 + r) * m] * xc;
+      }
+      if (r < jb) w[j0 + r] = val;
+    }
+    __syncthreads();
+  }
+  for (int i = tid; i < k; i += nt) xp[3LL * f.c0 + i] = w[i];
+}
+
+__global__ void mf_unpermute_kernel(int N, const int* __restrict__ order, const double* __restrict__ xp,
+                                    double* __restrict__ x) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= N) return;
+  const int o = order[p];
+  x[3 * o] = xp[3 * p];
+  x[3 * o + 1] = xp[3 * p + 1];
+  x[3 * o + 2] = xp[3 * p + 2];
+}
+}  // namespace
+
+// numeric factorisation of the H whose values are at `H` (the engine's layout); err is set when a pivot is not positive
+void launch_mf_factor(hipStream_t s, const MfPlan& P, const MfDev& D, const double* H) {
+  const int nl = P.n_levels();
+  (void)hipMemsetAsync(D.err, 0, sizeof(int), s);
+  for (int l = 0; l < nl; l++) {
+    const int par = (nl - 1 - l) & 1;
+    double* W = D.F[par];
+    const double* Wc = D.F[1 - par];
+    const int* lvl = D.lvl + P.level_off[l];
+    const int nfl = P.level_off[l + 1] - P.level_off[l];
+    (void)hipMemsetAsync(W, 0, (size_t)P.level_F[l] * sizeof(double), s);
+    const int ne = P.hent_off[l + 1] - P.hent_off[l];
+    if (ne > 0) {
+      const long long th = 9LL * ne;
+      hipLaunchKernelGGL(mf_scatter_h_kernel, dim3((unsigned)((th + 255) / 256)), dim3(256), 0, s, ne,
+                         D.hsrc + P.hent_off[l], D.hsld + P.hent_off[l], D.hdst + P.hent_off[l], D.hdld + P.hent_off[l], H, W);
+    }
+    for (int slot = 0; slot < 2; slot++) {
+      int mu = 0;
+      for (int t = 0; t < nfl; t++) {
+        const MfFront& F = P.fronts[P.level_fronts[(size_t)P.level_off[l] + t]];
+        if (F.child[slot] >= 0) {
+          const MfFront& C = P.fronts[F.child[slot]];
+          mu = std::max(mu, C.nrows - (C.c1 - C.c0));
+        }
+      }
+      if (mu <= 0) continue;
+      const unsigned g = (unsigned)((mu + 15) / 16);
+      for (int z0 = 0; z0 < nfl; z0 += 32768)
+        hipLaunchKernelGGL(mf_extend_add_kernel, dim3(g, g, (unsigned)std::min(32768, nfl - z0)), dim3(256), 0, s, D.fr,
+                           lvl + z0, slot, W, Wc, D.map);
+    }
+    for (int t = P.step_off[l]; t < P.step_off[l + 1]; t++) {
+      const MfLevelStep& st = P.steps[t];
+      const unsigned rt = (unsigned)std::max(1, (st.max_below + 255) / 256), ut = (unsigned)((st.max_below + 63) / 64);
+      for (int z0 = 0; z0 < st.n_active; z0 += 32768) {
+        const unsigned nz = (unsigned)std::min(32768, st.n_active - z0);
+        hipLaunchKernelGGL(mf_panel_kernel, dim3(rt, nz), dim3(256), 0, s, D.fr, lvl + z0, st.j0, W, D.L, D.err);
+        if (ut > 0)
+          hipLaunchKernelGGL(mf_update_kernel, dim3(ut, ut, nz), dim3(256), 0, s, D.fr, lvl + z0, st.j0, W, D.L);
+      }
+    }
+  }
+}
+
+// x = H^-1 b with the factor of the last launch_mf_factor (b, x in the engine's DOF order; x may alias b)
+void launch_mf_solve(hipStream_t s, const MfPlan& P, const MfDev& D, const double* b, double* x) {
+  const int nl = P.n_levels();
+  for (int l = 0; l < nl; l++) {
+    const int nfl = P.level_off[l + 1] - P.level_off[l];
+    hipLaunchKernelGGL(mf_forward_kernel, dim3((unsigned)nfl), dim3(512), 0, s, D.fr, D.lvl + P.level_off[l], D.L, D.map,
+                       D.order, b, D.v, D.y);
+  }
+  for (int l = nl - 1; l >= 0; l--) {
+    const int nfl = P.level_off[l + 1] - P.level_off[l];
+    hipLaunchKernelGGL(mf_backward_kernel, dim3((unsigned)nfl), dim3(512), 0, s, D.fr, D.lvl + P.level_off[l], D.L, D.rows,
+                       D.y, D.xp, D.v);
+  }
+  hipLaunchKernelGGL(mf_unpermute_kernel, dim3((unsigned)((P.N + 255) / 256)), dim3(256), 0, s, P.N, D.order, D.xp, x);
+}
+
+}  // namespace tlfea

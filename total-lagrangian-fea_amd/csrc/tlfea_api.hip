@@ -991,10 +991,15 @@ struct tlfea_newton_s {
   // sparse direct solve (lin.method == 1): rocSOLVER re-factorisation on a host-computed ordering + factor pattern
   struct Direct {
     bool tried = false, ok = false;
+    int backend = 0;  // 0: the engine's multifrontal Cholesky (direct_kernels.hip), 1: rocSOLVER (TLFEA_DIRECT_BACKEND=rocsolver)
     int n = 0, nnzT = 0;
     void *blas = nullptr, *rfinfo = nullptr;
     int *d_ptrA = nullptr, *d_indA = nullptr, *d_ptrT = nullptr, *d_indT = nullptr, *d_pivQ = nullptr;
     double* d_valT = nullptr;
+    MfPlan plan;      // host plan (levels, panel steps); the device copies below
+    MfDev dev{};
+    std::vector<void*> owned;  // device allocations of the native backend
+    double factor_ms = 0.0, solve_ms = 0.0;
   } direct;
   double* d_mbuf = nullptr;   // T10: per (element, node) force row | inertia row M_e (v - v_prev) / h of the residual launch
   int mass_mode = 0;          // TLFEA_MASS=csr: always the mass CSR product in grad_kernel
@@ -3387,6 +3392,12 @@ RocsolverApi& rocsolver_api() {
 static void direct_destroy(tlfea_newton_t s) {
   auto& m = s->direct;
   if (!m.tried) return;  // never used: do not resolve (dlopen) rocSOLVER / rocBLAS just to tear nothing down
+  for (void* q : m.owned)
+    if (q) (void)hipFree(q);
+  if (m.backend == 0) {
+    m = tlfea_newton_s::Direct();
+    return;
+  }
   RocsolverApi& a = rocsolver_api();
   if (m.rfinfo && a.lib) (void)a.rf_destroy(m.rfinfo);
   if (m.blas && a.lib) (void)a.blas_destroy(m.blas);
@@ -3404,12 +3415,90 @@ static void direct_destroy(tlfea_newton_t s) {
       std::fflush(stderr);                                                   \
     }                                                                        \
   } while (0)
+// the engine's own backend: plan on the host (mf_host.h), everything else on the device
+template <typename T>
+static int mf_upload(tlfea_newton_s::Direct& m, const std::vector<T>& h, const T** out) {
+  T* p = nullptr;
+  HIP_TRY(hipMalloc(&p, std::max<size_t>(1, h.size()) * sizeof(T)));
+  m.owned.push_back(p);
+  if (!h.empty()) HIP_TRY(hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+  *out = p;
+  return 0;
+}
+static int direct_prepare_native(tlfea_newton_t s, const std::vector<double>& X) {
+  auto& m = s->direct;
+  tlfea_t10_t d = s->d;
+  const int N = s->N;
+  size_t free_b = 0, total_b = 0;
+  HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+  static const long long forced = std::getenv("TLFEA_DIRECT_MAX_NNZ") ? std::atoll(std::getenv("TLFEA_DIRECT_MAX_NNZ")) : 0;
+  const long long max_doubles = forced > 0 ? forced : (long long)(0.8 * (double)free_b / sizeof(double));
+  static const int leaf = std::getenv("TLFEA_DIRECT_LEAF") ? std::atoi(std::getenv("TLFEA_DIRECT_LEAF")) : 32;
+  if (!mf_plan_build(N, d->h_off.data(), d->h_cols.data(), X.data(), X.data() + N, X.data() + 2 * (size_t)N, leaf, max_doubles,
+                     m.plan))
+    return fail("sparse direct solve: the Cholesky factor and front workspaces of this mesh do not fit the device memory "
+                "that is free (TLFEA_DIRECT_MAX_NNZ overrides the bound, in doubles); use the iterative solver");
+  const MfPlan& P = m.plan;
+  std::vector<MfFrontDev> fr(P.fronts.size());
+  for (size_t f = 0; f < P.fronts.size(); f++) {
+    const MfFront& F = P.fronts[f];
+    fr[f] = MfFrontDev{F.F_off, F.L_off, F.v_off, F.map_off, F.row_off, 3 * F.nrows, 3 * (F.c1 - F.c0), F.c0,
+                       F.child[0], F.child[1], 0};
+  }
+  MfDev& D = m.dev;
+  TRY(mf_upload(m, fr, &D.fr));
+  TRY(mf_upload(m, P.level_fronts, &D.lvl));
+  TRY(mf_upload(m, P.map, &D.map));
+  TRY(mf_upload(m, P.rows, &D.rows));
+  TRY(mf_upload(m, P.order, &D.order));
+  TRY(mf_upload(m, P.h_src, &D.hsrc));
+  TRY(mf_upload(m, P.h_dst, &D.hdst));
+  TRY(mf_upload(m, P.h_sld, &D.hsld));
+  TRY(mf_upload(m, P.h_dld, &D.hdld));
+  auto dalloc = [&](double** p, long long n) {
+    HIP_TRY(hipMalloc(p, (size_t)std::max(1LL, n) * sizeof(double)));
+    m.owned.push_back(*p);
+    return 0;
+  };
+  TRY(dalloc(&D.L, P.L_total));
+  TRY(dalloc(&D.F[0], P.F_cap[0]));
+  TRY(dalloc(&D.F[1], P.F_cap[1]));
+  TRY(dalloc(&D.v, P.v_total));
+  TRY(dalloc(&D.y, 3LL * N));
+  TRY(dalloc(&D.xp, 3LL * N));
+  HIP_TRY(hipMalloc(&D.err, sizeof(int)));
+  m.owned.push_back(D.err);
+  m.n = 3 * N;
+  m.ok = true;
+  if (s->verbose)
+    std::printf("sparse direct solve: %d DOF, %zu fronts in %d levels, factor %.3g doubles (%.1f x the lower triangle of H), "
+                "workspaces %.3g doubles, %.3g flop per factorisation\n",
+                m.n, P.fronts.size(), P.n_levels(), (double)P.L_total, (double)P.L_total / (0.5 * s->h_nnz),
+                (double)(P.F_cap[0] + P.F_cap[1]), (double)P.flops);
+  return 0;
+}
+
 static int direct_prepare(tlfea_newton_t s) {
   auto& m = s->direct;
   if (m.tried) return m.ok ? 0 : fail("sparse direct solve is not available (see the earlier message)");
   m.tried = true;
   tlfea_t10_t d = s->d;
   if (dist_on(s)) return fail("sparse direct solve: single-GPU path only");
+  {
+    const char* be = std::getenv("TLFEA_DIRECT_BACKEND");
+    m.backend = (be && std::string(be) == "rocsolver") ? 1 : 0;
+  }
+  if (m.backend == 0) {
+    const int N0 = s->N;
+    std::vector<double> X0(3 * (size_t)N0);
+    D2H(X0.data(), d->d_xt, (size_t)N0);
+    D2H(X0.data() + N0, d->d_yt, (size_t)N0);
+    D2H(X0.data() + 2 * (size_t)N0, d->d_zt, (size_t)N0);
+    if (d->kind != kT10)  // ANCF: the 4 coefficient vectors of a node share its position
+      for (int i = 0; i < N0; i++)
+        for (int c = 0; c < 3; c++) X0[(size_t)c * N0 + i] = X0[(size_t)c * N0 + (i / 4) * 4];
+    return direct_prepare_native(s, X0);
+  }
   DTRACE("resolving rocsolver");
   RocsolverApi& a = rocsolver_api();
   DTRACE("resolved");
@@ -3469,10 +3558,20 @@ static int direct_prepare(tlfea_newton_t s) {
 static int direct_solve(tlfea_newton_t s, const double* d_b, double* d_x, int* iters_out, double* rel_out) {
   TRY(direct_prepare(s));
   auto& m = s->direct;
-  RocsolverApi& a = rocsolver_api();
+  static RocsolverApi none;
+  RocsolverApi& a = m.backend == 1 ? rocsolver_api() : none;
   tlfea_t10_t d = s->d;
   StageTimer t(s, 4);
   const size_t nb = (size_t)m.n * sizeof(double);
+  if (m.backend == 0) {
+    launch_mf_factor(s->stream, m.plan, m.dev, s->d_H);
+    launch_mf_solve(s->stream, m.plan, m.dev, d_b, d_x);
+    int bad = 0;
+    HIP_TRY(hipMemcpyAsync(&bad, m.dev.err, sizeof(int), hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    HIP_TRY(hipGetLastError());
+    if (bad) return fail("sparse direct solve: a pivot of the Cholesky factorisation is not positive (H not positive definite)");
+  } else {
   int rc = a.refactchol(m.blas, m.n, s->h_nnz, m.d_ptrA, m.d_indA, s->d_H, m.nnzT, m.d_ptrT, m.d_indT, m.d_valT, m.d_pivQ,
                         m.rfinfo);
   if (rc) return fail("rocsolver_dcsrrf_refactchol failed with status " + std::to_string(rc) + " (H not positive definite?)");
@@ -3481,6 +3580,7 @@ static int direct_solve(tlfea_newton_t s, const double* d_b, double* d_x, int* i
   rc = a.solve(m.blas, m.n, 1, m.nnzT, m.d_ptrT, m.d_indT, m.d_valT, nullptr, m.d_pivQ, d_x, m.n, m.rfinfo);
   if (rc) return fail("rocsolver_dcsrrf_solve failed with status " + std::to_string(rc));
   DTRACE("solve enqueued");
+  }
   // r = b - H x, ||r|| / ||b||
   HIP_TRY(hipMemsetAsync(s->d_parts, 0, (size_t)5 * kNPart * sizeof(double), s->stream));
   launch_spmv_dir_dot(s->stream, s->N, d->inc(), s->d_H, d_x, s->d_p, 1, part(s, 1), part(s, 0), s->d_p2, s->d_q, part(s, 2),

@@ -6,6 +6,8 @@
 #include <cstddef>
 #include <cstdint>
 
+#include "mf_host.h"
+
 namespace tlfea {
 
 constexpr int kNQ = 5;      // T10: Keast 5-point rule (quadrature_utils.h:134)
@@ -279,5 +281,23 @@ void launch_pack(hipStream_t s, int n, int dim, const int* node, const int* slot
 void launch_unpack(hipStream_t s, int n, int dim, const int* node, const int* slot, const double* buf, double* dst);
 void launch_extract_diag(hipStream_t s, int N, const Incidence& inc, const double* Hval, double* D);
 void launch_invert_diag(hipStream_t s, int N, const double* D, double* Dinv);
+
+// ---- sparse direct solve (direct_kernels.hip on the plan of mf_host.h) ------------------------------------------------
+struct MfFrontDev {  // a front as the kernels see it (DOF units)
+  long long F_off, L_off, v_off, map_off, rows_off;
+  int m, k, c0, child0, child1, pad;
+};
+struct MfDev {
+  const MfFrontDev* fr;
+  const int *lvl, *map, *rows, *order;
+  const long long *hsrc, *hdst;
+  const int *hsld, *hdld;
+  double* L;
+  double* F[2];
+  double *v, *y, *xp;
+  int* err;
+};
+void launch_mf_factor(hipStream_t s, const MfPlan& P, const MfDev& D, const double* H);
+void launch_mf_solve(hipStream_t s, const MfPlan& P, const MfDev& D, const double* b, double* x);
 
 }  // namespace tlfea
