@@ -111,7 +111,7 @@ def test_direct_reports_indefinite_matrix():
     X, conn = load_mesh("res2")
     d = make_gpu(X, conn, MATERIALS["svk"], fixed_x0(X))
     s = tl.SyncedNewtonSolver(d, d.get_n_constraint())
-    s.SetParameters(tl.SyncedNewtonParams(-1e-4, 0.0, 1e-4, 1e14, 5, 10, 1e-3))   # negative step: H = M/h + hK is indefinite
+    s.SetParameters(tl.SyncedNewtonParams(1e-4, 0.0, 1e-4, 1e14, 5, 10, -1e-3))   # negative step: H = M/h + hK is indefinite
     s.AssembleHessian()
     s.SetLinSolveOpts(tl.LinSolveOpts(method=1))
     with pytest.raises(RuntimeError, match="not positive"):

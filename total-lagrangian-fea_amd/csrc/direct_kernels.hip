@@ -16,6 +16,8 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
+#include <vector>
 
 #include "tlfea_internal.h"
 
@@ -139,14 +141,15 @@ __global__ __launch_bounds__(256) void mf_panel_kernel(const MfFrontDev* __restr
   for (int c = NB - 1; c >= 0; c--) Lp[(long long)min(c, jb - 1) * m] = X[c];
 }
 
+// inside a super-panel [S0, S0 + KS): the panel at j0 is taken out of the super-panel's remaining columns only (all rows)
 __global__ __launch_bounds__(256) void mf_update_kernel(const MfFrontDev* __restrict__ fr, const int* __restrict__ lvl, int j0,
-                                                       double* __restrict__ W, const double* __restrict__ Ls) {
+                                                       int s1, double* __restrict__ W, const double* __restrict__ Ls) {
   const MfFrontDev f = fr[lvl[blockIdx.z]];
   const int m = f.m, k = f.k;
   if (k <= j0) return;
-  const int jb = min(NB, k - j0), base = j0 + jb;
+  const int jb = min(NB, k - j0), base = j0 + jb, ccap = min(s1, k);
   const int I = blockIdx.x, J = blockIdx.y;
-  if (J > I || base + I * 64 >= m) return;
+  if (J > I || base + I * 64 >= m || base + J * 64 >= ccap) return;
   __shared__ double Pi[NB][64], Pj[NB][64];
   const double* L = Ls + f.L_off;
   double* F = W + f.F_off;
@@ -178,7 +181,64 @@ __global__ __launch_bounds__(256) void mf_update_kernel(const MfFrontDev* __rest
 #pragma unroll
     for (int i = 0; i < 4; i++) {
       const int gi = base + I * 64 + 4 * tx + i;
-      if (gi < m && gj <= gi) F[(long long)gi + (long long)gj * m] -= acc[i][j];
+      if (gi < m && gj <= gi && gj < ccap) F[(long long)gi + (long long)gj * m] -= acc[i][j];
+    }
+  }
+}
+
+// after a super-panel [S0, S1 = min(S0 + KS, k)): everything to the right of it, F[r, c] -= L[r, S0:S1] L[c, S0:S1]^T for
+// r >= c >= S1, in 128x128 tiles, 8x8 per lane, the K range staged through LDS in chunks of 16 columns -- the trailing
+// matrix is read and written once per super-panel instead of once per panel
+constexpr int WT = 128, KC = 16;
+__global__ __launch_bounds__(256) void mf_update_wide_kernel(const MfFrontDev* __restrict__ fr, const int* __restrict__ lvl,
+                                                            int S0, int KS, double* __restrict__ W,
+                                                            const double* __restrict__ Ls) {
+  const MfFrontDev f = fr[lvl[blockIdx.z]];
+  const int m = f.m, k = f.k;
+  if (k <= S0) return;
+  const int S1 = min(S0 + KS, k), base = S1;
+  const int I = blockIdx.x, J = blockIdx.y;
+  if (J > I || base + I * WT >= m) return;
+  __shared__ double Pi[KC][WT], Pj[KC][WT];
+  const double* L = Ls + f.L_off;
+  double* F = W + f.F_off;
+  const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+  const int lr = tid & 127, lc = tid >> 7;  // loader: row of the tile, first of its 8 chunk columns (stride 2)
+  const int gi = base + I * WT + lr, gj = base + J * WT + lr;
+  double acc[8][8] = {};
+  for (int c0 = S0; c0 < S1; c0 += KC) {
+#pragma unroll
+    for (int q = 0; q < KC / 2; q++) {
+      const int c = lc + 2 * q;
+      const bool in = c0 + c < S1;
+      Pi[c][lr] = (in && gi < m) ? L[(long long)gi + (long long)(c0 + c) * m] : 0.0;
+      Pj[c][lr] = (in && gj < m) ? L[(long long)gj + (long long)(c0 + c) * m] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int c = 0; c < KC; c++) {
+      double a[8], b[8];
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        a[i] = Pi[c][4 * tx + i];
+        a[4 + i] = Pi[c][64 + 4 * tx + i];
+        b[i] = Pj[c][4 * ty + i];
+        b[4 + i] = Pj[c][64 + 4 * ty + i];
+      }
+#pragma unroll
+      for (int i = 0; i < 8; i++)
+#pragma unroll
+        for (int j = 0; j < 8; j++) acc[i][j] += a[i] * b[j];
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    const int cj = base + J * WT + (j < 4 ? 4 * ty + j : 64 + 4 * ty + j - 4);
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const int ri = base + I * WT + (i < 4 ? 4 * tx + i : 64 + 4 * tx + i - 4);
+      if (ri < m && cj <= ri) F[(long long)ri + (long long)cj * m] -= acc[i][j];
     }
   }
 }
@@ -267,6 +327,119 @@ __global__ __launch_bounds__(512) void mf_backward_kernel(const MfFrontDev* __re
   for (int i = tid; i < k; i += nt) xp[3LL * f.c0 + i] = w[i];
 }
 
+// ---- the same solves, panel step by panel step, for levels whose fronts are too large for one workgroup each ----------
+// w = [right-hand side of the own DOFs; 0], then += the children's remainders (one launch per child slot: fixed order)
+__global__ __launch_bounds__(256) void mf_fwd_init_kernel(const MfFrontDev* __restrict__ fr, const int* __restrict__ lvl,
+                                                         const int* __restrict__ order, const double* __restrict__ b,
+                                                         double* __restrict__ v) {
+  const MfFrontDev f = fr[lvl[blockIdx.y]];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= f.m) return;
+  v[f.v_off + i] = i < f.k ? b[3 * order[f.c0 + i / 3] + i % 3] : 0.0;
+}
+__global__ __launch_bounds__(256) void mf_fwd_child_kernel(const MfFrontDev* __restrict__ fr, const int* __restrict__ lvl,
+                                                          int slot, const int* __restrict__ map, double* __restrict__ v) {
+  const MfFrontDev f = fr[lvl[blockIdx.y]];
+  const int c = slot ? f.child1 : f.child0;
+  if (c < 0) return;
+  const MfFrontDev ch = fr[c];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= ch.m - ch.k) return;
+  v[f.v_off + 3 * map[ch.map_off + i / 3] + i % 3] += v[ch.v_off + ch.k + i];
+}
+// block j0: every workgroup solves the 48x48 triangle (one wavefront), then takes the block out of its 256 rows below
+__global__ __launch_bounds__(256) void mf_fwd_step_kernel(const MfFrontDev* __restrict__ fr, const int* __restrict__ lvl, int j0,
+                                                         const double* __restrict__ Ls, double* __restrict__ v,
+                                                         double* __restrict__ y) {
+  const MfFrontDev f = fr[lvl[blockIdx.y]];
+  const int m = f.m, k = f.k, tid = threadIdx.x;
+  if (k <= j0) return;
+  const int jb = min(NB, k - j0);
+  const int r0 = j0 + jb + blockIdx.x * 256;
+  if (blockIdx.x > 0 && r0 >= m) return;
+  double* w = v + f.v_off;
+  const double* L = Ls + f.L_off;
+  __shared__ double ys[NB];
+  if (tid < 64) {
+    const int r = tid;
+    double val = r < jb ? w[j0 + r] : 0.0;
+    for (int c = 0; c < jb; c++) {
+      const double yc = __shfl(val, c) / L[(long long)(j0 + c) + (long long)(j0 + c) * m];
+      if (r == c) val = yc;
+      else if (r > c && r < jb) val -= L[(long long)(j0 + r) + (long long)(j0 + c) * m] * yc;
+    }
+    if (r < jb) {
+      ys[r] = val;
+      if (blockIdx.x == 0) y[3LL * f.c0 + j0 + r] = val;
+    }
+  }
+  __syncthreads();
+  const int rr = r0 + tid;
+  if (rr >= m) return;
+  const double* Lr = L + (long long)rr + (long long)j0 * m;
+  double s = 0.0;
+  for (int c = 0; c < jb; c++) s += Lr[(long long)c * m] * ys[c];
+  w[rr] -= s;
+}
+// backward: w = [y of the own DOFs; x of the ancestors' rows], then w1 -= L21^T w2 (a wavefront per column)
+__global__ __launch_bounds__(256) void mf_bwd_gather_kernel(const MfFrontDev* __restrict__ fr, const int* __restrict__ lvl,
+                                                           const int* __restrict__ rows, const double* __restrict__ y,
+                                                           const double* __restrict__ xp, double* __restrict__ v) {
+  const MfFrontDev f = fr[lvl[blockIdx.y]];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= f.m) return;
+  v[f.v_off + i] = i < f.k ? y[3LL * f.c0 + i] : xp[3LL * rows[f.rows_off + i / 3] + i % 3];
+}
+__global__ __launch_bounds__(256) void mf_bwd_below_kernel(const MfFrontDev* __restrict__ fr, const int* __restrict__ lvl,
+                                                          const double* __restrict__ Ls, double* __restrict__ v) {
+  const MfFrontDev f = fr[lvl[blockIdx.y]];
+  const int m = f.m, k = f.k;
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (c >= k || m == k) return;
+  double* w = v + f.v_off;
+  const double* Lc = Ls + f.L_off + (long long)c * m;
+  double s = 0.0;
+  for (int r = k + lane; r < m; r += 64) s += Lc[r] * w[r];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
+  if (lane == 0) w[c] -= s;
+}
+// block j0 (descending): every workgroup solves the transposed triangle, then takes the block out of its 256 columns
+// to the left (a lane per column: the block's 48 entries of a column are contiguous)
+__global__ __launch_bounds__(256) void mf_bwd_step_kernel(const MfFrontDev* __restrict__ fr, const int* __restrict__ lvl, int j0,
+                                                         const double* __restrict__ Ls, double* __restrict__ v,
+                                                         double* __restrict__ xp) {
+  const MfFrontDev f = fr[lvl[blockIdx.y]];
+  const int m = f.m, k = f.k, tid = threadIdx.x;
+  if (k <= j0) return;
+  const int jb = min(NB, k - j0);
+  const int cb = blockIdx.x * 256;
+  if (blockIdx.x > 0 && cb >= j0) return;
+  double* w = v + f.v_off;
+  const double* L = Ls + f.L_off;
+  __shared__ double xs[NB];
+  if (tid < 64) {
+    const int r = tid;
+    double val = r < jb ? w[j0 + r] : 0.0;
+    for (int c = jb - 1; c >= 0; c--) {
+      const double xc = __shfl(val, c) / L[(long long)(j0 + c) + (long long)(j0 + c) * m];
+      if (r == c) val = xc;
+      else if (r < c) val -= L[(long long)(j0 + c) + (long long)(j0 + r) * m] * xc;
+    }
+    if (r < jb) {
+      xs[r] = val;
+      if (blockIdx.x == 0) xp[3LL * f.c0 + j0 + r] = val;
+    }
+  }
+  __syncthreads();
+  const int j = cb + tid;
+  if (j >= j0) return;
+  const double* Lc = L + (long long)j * m + j0;
+  double s = 0.0;
+  for (int r = 0; r < jb; r++) s += Lc[r] * xs[r];
+  w[j] -= s;
+}
+
 __global__ void mf_unpermute_kernel(int N, const int* __restrict__ order, const double* __restrict__ xp,
                                     double* __restrict__ x) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -281,6 +454,8 @@ __global__ void mf_unpermute_kernel(int N, const int* __restrict__ order, const 
 // numeric factorisation of the H whose values are at `H` (the engine's layout); err is set when a pivot is not positive
 void launch_mf_factor(hipStream_t s, const MfPlan& P, const MfDev& D, const double* H) {
   const int nl = P.n_levels();
+  // super-panel: the trailing matrix is updated once per KS columns (a multiple of the panel width)
+  static const int KS = NB * std::max(1, std::getenv("TLFEA_DIRECT_SUPER") ? std::atoi(std::getenv("TLFEA_DIRECT_SUPER")) : 8);
   (void)hipMemsetAsync(D.err, 0, sizeof(int), s);
   for (int l = 0; l < nl; l++) {
     const int par = (nl - 1 - l) & 1;
@@ -312,12 +487,28 @@ void launch_mf_factor(hipStream_t s, const MfPlan& P, const MfDev& D, const doub
     }
     for (int t = P.step_off[l]; t < P.step_off[l + 1]; t++) {
       const MfLevelStep& st = P.steps[t];
+      const int S0 = (st.j0 / KS) * KS, s1 = S0 + KS;
       const unsigned rt = (unsigned)std::max(1, (st.max_below + 255) / 256), ut = (unsigned)((st.max_below + 63) / 64);
+      const unsigned ct = (unsigned)((s1 - st.j0 - NB + 63) / 64 + 1);  // column tiles left in the super-panel
       for (int z0 = 0; z0 < st.n_active; z0 += 32768) {
         const unsigned nz = (unsigned)std::min(32768, st.n_active - z0);
         hipLaunchKernelGGL(mf_panel_kernel, dim3(rt, nz), dim3(256), 0, s, D.fr, lvl + z0, st.j0, W, D.L, D.err);
-        if (ut > 0)
-          hipLaunchKernelGGL(mf_update_kernel, dim3(ut, ut, nz), dim3(256), 0, s, D.fr, lvl + z0, st.j0, W, D.L);
+        if (ut > 0 && st.j0 + NB < s1)
+          hipLaunchKernelGGL(mf_update_kernel, dim3(ut, std::min(ut, ct), nz), dim3(256), 0, s, D.fr, lvl + z0, st.j0, s1, W,
+                             D.L);
+      }
+      if (st.j0 + NB >= s1 || t + 1 == P.step_off[l + 1]) {  // the super-panel is complete: take it out of the rest
+        const MfLevelStep& s0 = P.steps[P.step_off[l] + S0 / NB];
+        int below = 0;
+        for (int q = 0; q < s0.n_active; q++) {
+          const MfFront& F = P.fronts[P.level_fronts[(size_t)P.level_off[l] + q]];
+          below = std::max(below, 3 * F.nrows - std::min(s1, 3 * (F.c1 - F.c0)));
+        }
+        const unsigned wt = (unsigned)((below + WT - 1) / WT);
+        if (wt > 0)
+          for (int z0 = 0; z0 < s0.n_active; z0 += 32768)
+            hipLaunchKernelGGL(mf_update_wide_kernel, dim3(wt, wt, (unsigned)std::min(32768, s0.n_active - z0)), dim3(256), 0, s,
+                               D.fr, lvl + z0, S0, KS, W, D.L);
       }
     }
   }
@@ -326,15 +517,51 @@ void launch_mf_factor(hipStream_t s, const MfPlan& P, const MfDev& D, const doub
 // x = H^-1 b with the factor of the last launch_mf_factor (b, x in the engine's DOF order; x may alias b)
 void launch_mf_solve(hipStream_t s, const MfPlan& P, const MfDev& D, const double* b, double* x) {
   const int nl = P.n_levels();
+  // a level whose largest front has at most this many DOF rows runs one workgroup per front; above, step by step
+  static const int one_wg_rows = std::getenv("TLFEA_DIRECT_ONE_WG_ROWS") ? std::atoi(std::getenv("TLFEA_DIRECT_ONE_WG_ROWS")) : 768;
+  std::vector<int> m_max((size_t)nl, 0), mu_max((size_t)nl, 0), k_max((size_t)nl, 0);
+  for (int l = 0; l < nl; l++)
+    for (int t = P.level_off[l]; t < P.level_off[l + 1]; t++) {
+      const MfFront& F = P.fronts[P.level_fronts[t]];
+      m_max[l] = std::max(m_max[l], 3 * F.nrows);
+      k_max[l] = std::max(k_max[l], 3 * (F.c1 - F.c0));
+      for (int c : F.child)
+        if (c >= 0) mu_max[l] = std::max(mu_max[l], 3 * (P.fronts[c].nrows - (P.fronts[c].c1 - P.fronts[c].c0)));
+    }
   for (int l = 0; l < nl; l++) {
-    const int nfl = P.level_off[l + 1] - P.level_off[l];
-    hipLaunchKernelGGL(mf_forward_kernel, dim3((unsigned)nfl), dim3(512), 0, s, D.fr, D.lvl + P.level_off[l], D.L, D.map,
-                       D.order, b, D.v, D.y);
+    const unsigned nfl = (unsigned)(P.level_off[l + 1] - P.level_off[l]);
+    const int* lvl = D.lvl + P.level_off[l];
+    if (m_max[l] <= one_wg_rows) {
+      hipLaunchKernelGGL(mf_forward_kernel, dim3(nfl), dim3(512), 0, s, D.fr, lvl, D.L, D.map, D.order, b, D.v, D.y);
+      continue;
+    }
+    hipLaunchKernelGGL(mf_fwd_init_kernel, dim3((unsigned)((m_max[l] + 255) / 256), nfl), dim3(256), 0, s, D.fr, lvl, D.order, b,
+                       D.v);
+    if (mu_max[l] > 0)
+      for (int slot = 0; slot < 2; slot++)
+        hipLaunchKernelGGL(mf_fwd_child_kernel, dim3((unsigned)((mu_max[l] + 255) / 256), nfl), dim3(256), 0, s, D.fr, lvl, slot,
+                           D.map, D.v);
+    for (int t = P.step_off[l]; t < P.step_off[l + 1]; t++) {
+      const MfLevelStep& st = P.steps[t];
+      hipLaunchKernelGGL(mf_fwd_step_kernel, dim3((unsigned)std::max(1, (st.max_below + 255) / 256), (unsigned)st.n_active),
+                         dim3(256), 0, s, D.fr, lvl, st.j0, D.L, D.v, D.y);
+    }
   }
   for (int l = nl - 1; l >= 0; l--) {
-    const int nfl = P.level_off[l + 1] - P.level_off[l];
-    hipLaunchKernelGGL(mf_backward_kernel, dim3((unsigned)nfl), dim3(512), 0, s, D.fr, D.lvl + P.level_off[l], D.L, D.rows,
+    const unsigned nfl = (unsigned)(P.level_off[l + 1] - P.level_off[l]);
+    const int* lvl = D.lvl + P.level_off[l];
+    if (m_max[l] <= one_wg_rows) {
+      hipLaunchKernelGGL(mf_backward_kernel, dim3(nfl), dim3(512), 0, s, D.fr, lvl, D.L, D.rows, D.y, D.xp, D.v);
+      continue;
+    }
+    hipLaunchKernelGGL(mf_bwd_gather_kernel, dim3((unsigned)((m_max[l] + 255) / 256), nfl), dim3(256), 0, s, D.fr, lvl, D.rows,
                        D.y, D.xp, D.v);
+    hipLaunchKernelGGL(mf_bwd_below_kernel, dim3((unsigned)((k_max[l] + 3) / 4), nfl), dim3(256), 0, s, D.fr, lvl, D.L, D.v);
+    for (int t = P.step_off[l + 1] - 1; t >= P.step_off[l]; t--) {
+      const MfLevelStep& st = P.steps[t];
+      hipLaunchKernelGGL(mf_bwd_step_kernel, dim3((unsigned)std::max(1, (st.j0 + 255) / 256), (unsigned)st.n_active), dim3(256),
+                         0, s, D.fr, lvl, st.j0, D.L, D.v, D.xp);
+    }
   }
   hipLaunchKernelGGL(mf_unpermute_kernel, dim3((unsigned)((P.N + 255) / 256)), dim3(256), 0, s, P.N, D.order, D.xp, x);
 }
