@@ -15,8 +15,13 @@ tl = importlib.import_module("total-lagrangian-fea_amd")
 from tests.helpers import MATERIALS, fixed_x0, load_mesh, make_gpu  # noqa: E402
 
 cases = [("beam_3x2x1", None), ("res2", None), ("bunny", None), ("box 6x6x12", (6, 6, 12)), ("config B", (12, 12, 12))]
-if "big" in sys.argv:
+if "big" in sys.argv or "only-big" in sys.argv:
     cases += [("box 20^3", (20, 20, 20)), ("box 30^3", (30, 30, 30)), ("bar 60x20x20", (60, 20, 20))]
+if "only-big" in sys.argv:
+    cases = cases[-3:-1]
+if "only-b" in sys.argv:
+    cases = cases[4:5]
+os.environ.setdefault("TLFEA_DIRECT_TRACE", "1")
 for name, cells in cases:
     if cells:
         X, conn = tl.mesh_utils.structured_t10_box(*cells)

@@ -32,6 +32,11 @@ __device__ __forceinline__ void wave_sync_d() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+__device__ __forceinline__ double readlane_d(double v, int lane) {  // lane: compile-time constant after unrolling
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  return __hiloint2double(hi, lo);
+}
+
 // 3x3 node blocks of H (row-major inside a node row, stride sld) -> the front (column-major, stride dld)
 __global__ void mf_scatter_h_kernel(int n, const long long* __restrict__ src, const int* __restrict__ sld,
                                     const long long* __restrict__ dst, const int* __restrict__ dld,
@@ -83,29 +88,33 @@ __global__ __launch_bounds__(256) void mf_panel_kernel(const MfFrontDev* __restr
     A[r][c] = (r < jb && c < jb && r >= c) ? F[(long long)(j0 + r) + (long long)(j0 + c) * m] : (r == c ? 1.0 : 0.0);
   }
   __syncthreads();
-  if (tid < 64) {  // one wavefront, lane r owns row r: left-looking Cholesky
-    const int r = tid;
-#pragma unroll 1
-    for (int c = 0; c < NB; c++) {  // (rolled: unrolled over c and p the compiler spills ~1900 VGPRs)
-      double s = 0.0;
-      if (r >= c && r < NB) {
-        s = A[r][c];
-#pragma unroll 4
-        for (int p = 0; p < c; p++) s -= A[r][p] * A[c][p];
+  if (tid < 64) {
+    // one wavefront, lane r holds row r in registers: right-looking Cholesky, the column's entries of the other rows come
+    // by v_readlane (compile-time lanes) -- no LDS round trip inside the 48-step dependent chain
+    const int r = tid, rl = min(r, NB - 1);
+    double a[NB];
+#pragma unroll
+    for (int c = 0; c < NB; c++) a[c] = A[rl][c];
+    bool bad = false;
+#pragma unroll
+    for (int c = 0; c < NB; c++) {
+      double d = readlane_d(a[c], c);
+      if (!(d > 0.0)) {
+        bad = true;  // not positive definite: the caller reports it; keep the arithmetic finite
+        d = 1.0;
       }
-      wave_sync_d();
-      if (r == c) {
-        if (!(s > 0.0)) {
-          *err = 1;  // not positive definite: the caller reports it; keep the arithmetic finite
-          s = 1.0;
-        }
-        const double piv = sqrt(s);
-        A[c][c] = piv;
-        dinv[c] = 1.0 / piv;
-      }
-      wave_sync_d();
-      if (r > c && r < NB) A[r][c] = s * dinv[c];
-      wave_sync_d();
+      const double inv = 1.0 / sqrt(d);
+      const double l = a[c] * inv;  // (the pivot lane gets d / sqrt(d): the diagonal entry, to the last bit or one off)
+      a[c] = l;
+#pragma unroll
+      for (int q = c + 1; q < NB; q++) a[q] -= l * readlane_d(l, q);  // (entries right of the diagonal: unused)
+      __builtin_amdgcn_sched_barrier(0);  // keeps one column's broadcasts (2 SGPRs each) in flight, not all 1128
+    }
+    if (bad && r == 0) *err = 1;
+    if (r < NB) {
+#pragma unroll
+      for (int c = 0; c < NB; c++) A[r][c] = a[c];  // (right of the diagonal: never read)
+      dinv[r] = 1.0 / A[r][r];
     }
   }
   __syncthreads();
@@ -128,11 +137,11 @@ __global__ __launch_bounds__(256) void mf_panel_kernel(const MfFrontDev* __restr
 #pragma unroll
   for (int c = 0; c < NB; c++) {
     double s = X[c];
-    // volatile: the broadcast LDS reads of row c stay next to their use (hoisted above the loop nest they spill 1900 VGPRs)
-    const volatile double* Ac = A[c];
+    const double* Ac = A[c];
 #pragma unroll
     for (int p = 0; p < c; p++) s -= X[p] * Ac[p];
     X[c] = s * dinv[c];
+    asm volatile("" ::: "memory");  // row c's broadcast LDS reads are issued together, but not hoisted above earlier rows
   }
   // unconditional stores, last column first: the padding columns (X = 0) land on column jb - 1 BEFORE its own value does
   // (a store per column under `if (c < jb)` makes the compiler spill ~1900 VGPRs)
@@ -141,39 +150,47 @@ __global__ __launch_bounds__(256) void mf_panel_kernel(const MfFrontDev* __restr
   for (int c = NB - 1; c >= 0; c--) Lp[(long long)min(c, jb - 1) * m] = X[c];
 }
 
-// inside a super-panel [S0, S0 + KS): the panel at j0 is taken out of the super-panel's remaining columns only (all rows)
+// F[r, c] -= sum over panel columns p in [cb, ce) of L[r, p] L[c, p], 64x64 tiles of the rows/columns from `ce` on:
+//   wide = 0, inside a super-panel [S0, s1): the panel at j0 is taken out of the super-panel's remaining columns only
+//   wide = 1, a completed super-panel [j0, min(s1, k)) out of everything to its right -- the 64-tile form of
+//             mf_update_wide_kernel, for trailing matrices of too few 128-tiles to fill the chip
 __global__ __launch_bounds__(256) void mf_update_kernel(const MfFrontDev* __restrict__ fr, const int* __restrict__ lvl, int j0,
-                                                       int s1, double* __restrict__ W, const double* __restrict__ Ls) {
+                                                       int s1, int wide, double* __restrict__ W,
+                                                       const double* __restrict__ Ls) {
   const MfFrontDev f = fr[lvl[blockIdx.z]];
   const int m = f.m, k = f.k;
   if (k <= j0) return;
-  const int jb = min(NB, k - j0), base = j0 + jb, ccap = min(s1, k);
+  const int cb = j0, ce = wide ? min(s1, k) : j0 + min(NB, k - j0), base = ce, ccap = wide ? m : min(s1, k);
   const int I = blockIdx.x, J = blockIdx.y;
   if (J > I || base + I * 64 >= m || base + J * 64 >= ccap) return;
   __shared__ double Pi[NB][64], Pj[NB][64];
   const double* L = Ls + f.L_off;
   double* F = W + f.F_off;
   const int tid = threadIdx.x;
-  for (int idx = tid; idx < NB * 64; idx += 256) {
-    const int c = idx >> 6, r = idx & 63;
-    const int gi = base + I * 64 + r, gj = base + J * 64 + r;
-    Pi[c][r] = (c < jb && gi < m) ? L[(long long)gi + (long long)(j0 + c) * m] : 0.0;
-    Pj[c][r] = (c < jb && gj < m) ? L[(long long)gj + (long long)(j0 + c) * m] : 0.0;
-  }
-  __syncthreads();
   const int tx = tid & 15, ty = tid >> 4;
   double acc[4][4] = {};
-  for (int c = 0; c < jb; c++) {
-    double a[4], b[4];
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-      a[i] = Pi[c][4 * tx + i];
-      b[i] = Pj[c][4 * ty + i];
+  for (int c0 = cb; c0 < ce; c0 += NB) {
+    const int jb = min(NB, ce - c0);
+    if (c0 > cb) __syncthreads();
+    for (int idx = tid; idx < NB * 64; idx += 256) {
+      const int c = idx >> 6, r = idx & 63;
+      const int gi = base + I * 64 + r, gj = base + J * 64 + r;
+      Pi[c][r] = (c < jb && gi < m) ? L[(long long)gi + (long long)(c0 + c) * m] : 0.0;
+      Pj[c][r] = (c < jb && gj < m) ? L[(long long)gj + (long long)(c0 + c) * m] : 0.0;
     }
+    __syncthreads();
+    for (int c = 0; c < jb; c++) {
+      double a[4], b[4];
 #pragma unroll
-    for (int i = 0; i < 4; i++)
+      for (int i = 0; i < 4; i++) {
+        a[i] = Pi[c][4 * tx + i];
+        b[i] = Pj[c][4 * ty + i];
+      }
 #pragma unroll
-      for (int j = 0; j < 4; j++) acc[i][j] += a[i] * b[j];
+      for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] += a[i] * b[j];
+    }
   }
 #pragma unroll
   for (int j = 0; j < 4; j++) {
@@ -360,13 +377,20 @@ __global__ __launch_bounds__(256) void mf_fwd_step_kernel(const MfFrontDev* __re
   double* w = v + f.v_off;
   const double* L = Ls + f.L_off;
   __shared__ double ys[NB];
+  __shared__ double T[NB][NB + 1];  // the block's triangle, staged by all lanes (read one entry at a time from HBM/L2 inside
+                                    // the substitution's dependent chain it cost ~40 us per step)
+  for (int idx = tid; idx < NB * NB; idx += 256) {
+    const int r = idx % NB, c = idx / NB;
+    if (r < jb && c <= r) T[r][c] = L[(long long)(j0 + r) + (long long)(j0 + c) * m];
+  }
+  __syncthreads();
   if (tid < 64) {
     const int r = tid;
     double val = r < jb ? w[j0 + r] : 0.0;
     for (int c = 0; c < jb; c++) {
-      const double yc = __shfl(val, c) / L[(long long)(j0 + c) + (long long)(j0 + c) * m];
+      const double yc = __shfl(val, c) / T[c][c];
       if (r == c) val = yc;
-      else if (r > c && r < jb) val -= L[(long long)(j0 + r) + (long long)(j0 + c) * m] * yc;
+      else if (r > c && r < jb) val -= T[r][c] * yc;
     }
     if (r < jb) {
       ys[r] = val;
@@ -418,13 +442,19 @@ __global__ __launch_bounds__(256) void mf_bwd_step_kernel(const MfFrontDev* __re
   double* w = v + f.v_off;
   const double* L = Ls + f.L_off;
   __shared__ double xs[NB];
+  __shared__ double T[NB][NB + 1];
+  for (int idx = tid; idx < NB * NB; idx += 256) {
+    const int r = idx % NB, c = idx / NB;
+    if (r < jb && c <= r) T[r][c] = L[(long long)(j0 + r) + (long long)(j0 + c) * m];
+  }
+  __syncthreads();
   if (tid < 64) {
     const int r = tid;
     double val = r < jb ? w[j0 + r] : 0.0;
     for (int c = jb - 1; c >= 0; c--) {
-      const double xc = __shfl(val, c) / L[(long long)(j0 + c) + (long long)(j0 + c) * m];
+      const double xc = __shfl(val, c) / T[c][c];
       if (r == c) val = xc;
-      else if (r < c) val -= L[(long long)(j0 + c) + (long long)(j0 + r) * m] * xc;
+      else if (r < c) val -= T[c][r] * xc;
     }
     if (r < jb) {
       xs[r] = val;
@@ -494,8 +524,8 @@ void launch_mf_factor(hipStream_t s, const MfPlan& P, const MfDev& D, const doub
         const unsigned nz = (unsigned)std::min(32768, st.n_active - z0);
         hipLaunchKernelGGL(mf_panel_kernel, dim3(rt, nz), dim3(256), 0, s, D.fr, lvl + z0, st.j0, W, D.L, D.err);
         if (ut > 0 && st.j0 + NB < s1)
-          hipLaunchKernelGGL(mf_update_kernel, dim3(ut, std::min(ut, ct), nz), dim3(256), 0, s, D.fr, lvl + z0, st.j0, s1, W,
-                             D.L);
+          hipLaunchKernelGGL(mf_update_kernel, dim3(ut, std::min(ut, ct), nz), dim3(256), 0, s, D.fr, lvl + z0, st.j0, s1, 0,
+                             W, D.L);
       }
       if (st.j0 + NB >= s1 || t + 1 == P.step_off[l + 1]) {  // the super-panel is complete: take it out of the rest
         const MfLevelStep& s0 = P.steps[P.step_off[l] + S0 / NB];
@@ -504,11 +534,17 @@ void launch_mf_factor(hipStream_t s, const MfPlan& P, const MfDev& D, const doub
           const MfFront& F = P.fronts[P.level_fronts[(size_t)P.level_off[l] + q]];
           below = std::max(below, 3 * F.nrows - std::min(s1, 3 * (F.c1 - F.c0)));
         }
-        const unsigned wt = (unsigned)((below + WT - 1) / WT);
+        const unsigned wt = (unsigned)((below + WT - 1) / WT), wt64 = (unsigned)((below + 63) / 64);
+        // 128-tiles when they fill the chip (the lower triangle of the largest front x the fronts), 64-tiles below that
+        const bool big = (double)wt * (wt + 1) / 2 * s0.n_active >= 2.0 * 256;
         if (wt > 0)
-          for (int z0 = 0; z0 < s0.n_active; z0 += 32768)
-            hipLaunchKernelGGL(mf_update_wide_kernel, dim3(wt, wt, (unsigned)std::min(32768, s0.n_active - z0)), dim3(256), 0, s,
-                               D.fr, lvl + z0, S0, KS, W, D.L);
+          for (int z0 = 0; z0 < s0.n_active; z0 += 32768) {
+            const unsigned nz = (unsigned)std::min(32768, s0.n_active - z0);
+            if (big)
+              hipLaunchKernelGGL(mf_update_wide_kernel, dim3(wt, wt, nz), dim3(256), 0, s, D.fr, lvl + z0, S0, KS, W, D.L);
+            else
+              hipLaunchKernelGGL(mf_update_kernel, dim3(wt64, wt64, nz), dim3(256), 0, s, D.fr, lvl + z0, S0, s1, 1, W, D.L);
+          }
       }
     }
   }

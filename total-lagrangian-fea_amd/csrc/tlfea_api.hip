@@ -3470,7 +3470,7 @@ static int direct_prepare_native(tlfea_newton_t s, const std::vector<double>& X)
   m.owned.push_back(D.err);
   m.n = 3 * N;
   m.ok = true;
-  if (s->verbose)
+  if (s->verbose || std::getenv("TLFEA_DIRECT_TRACE"))
     std::printf("sparse direct solve: %d DOF, %zu fronts in %d levels, factor %.3g doubles (%.1f x the lower triangle of H), "
                 "workspaces %.3g doubles, %.3g flop per factorisation\n",
                 m.n, P.fronts.size(), P.n_levels(), (double)P.L_total, (double)P.L_total / (0.5 * s->h_nnz),
