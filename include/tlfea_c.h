@@ -41,8 +41,9 @@ typedef struct {
 /* Linear-solve options.  The reference calls cuDSS (sparse Cholesky, SyncedNewton.cu:995-1029,
  * 1103-1114); this engine solves the same SPD system H dv = -g on the device: by default with CG in fp64 on H,
  * preconditioned by a two-level p-multigrid cycle (T10) or a Chebyshev polynomial of the block-Jacobi-scaled
- * operator (all kinds), both streaming a scaled fp16 copy of H with fp32 work vectors; method = 1 selects a sparse
- * direct solve (rocSOLVER re-factorisation).  rel_tol is on ||r||/||b|| of the fp64 system. */
+ * operator (all kinds), both streaming a scaled fp16 copy of H with fp32 work vectors; method = 1 selects the sparse
+ * direct solve (the engine's multifrontal Cholesky: analysis once per mesh, re-factorisation + solve per call, as the
+ * reference drives cuDSS).  rel_tol is on ||r||/||b|| of the fp64 system. */
 typedef struct {
   double rel_tol;    /* default 1e-12 */
   int max_iter;      /* default 20000 (outer CG iterations) */
@@ -58,7 +59,7 @@ typedef struct {
   int precond;       /* 0 (default) = auto, 1 = Chebyshev polynomial of block-Jacobi, 2 = two-level p-multigrid (T10 on one
                         GPU: quadratic tets -> their vertex mesh, Galerkin coarse operator, polynomial smoothers and
                         coarse solve; auto picks it wherever it exists) */
-  int method;        /* 0 (default) = preconditioned CG; 1 = sparse direct (tlfea_newton_set_direct_solver, where built) */
+  int method;        /* 0 (default) = preconditioned CG; 1 = sparse direct (single GPU) */
   int on_unconverged;/* a CG solve that ends above rel_tol (max_iter reached, or breakdown after the interval widenings):
                         0 (default) = the call fails, nothing is applied to v and x (the reference aborts when cuDSS
                         fails, SyncedNewton.cu:995-1029); 1 = accept the iterate (experiments with a capped iteration

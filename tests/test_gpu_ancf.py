@@ -193,6 +193,33 @@ def test_newton_steps(pname, steps):
     d.Destroy()
 
 
+@pytest.mark.parametrize("pname,steps", [("beam3243", 2), ("plate3443", 1)])
+def test_newton_steps_with_the_direct_solver(pname, steps):
+    """The same steps with the engine's multifrontal Cholesky as the linear solve (LinSolveOpts.method = 1; the reference's
+    cuDSS path, SyncedNewton.cu:1103-1114): the 4 coefficient vectors of an ANCF node share its position in the
+    dissection, the H pattern is the shells' 100+ blocks per row."""
+    o, d = make_pair(PROBLEMS[pname](), SVK_D)
+    s = tl.SyncedNewtonSolver(d, d.get_n_constraint())
+    s.Setup()
+    s.SetParameters(tl.SyncedNewtonParams(1e-4, 0.0, 1e-6, 1e14, 5, 10, 1e-3))
+    s.SetLinSolveOpts(tl.LinSolveOpts(method=1))
+    s.AnalyzeHessianSparsity()
+    oprm = orc.NewtonParams(1e-4, 0.0, 1e-6, 1e14, 5, 10, 1e-3)
+    X0 = np.stack([o.xt, o.yt, o.zt], axis=1)
+    for _ in range(steps):
+        s.Solve()
+        st_o = o.newton_step(oprm)
+        st_g = s.GetStats()
+        xg = np.stack(d.RetrievePositionToCPU(), axis=1)
+        xo = np.stack([o.x, o.y, o.z], axis=1)
+        assert disp_err_ok(xg, xo, X0), (st_g, st_o)
+        assert st_g["outer"] == st_o[0] and st_g["newton"] == st_o[1]
+        ls = s.GetLinSolveStatus()
+        assert ls["all_converged"] and ls["worst_rel_res"] < 1e-9, ls
+    del s
+    d.Destroy()
+
+
 def test_full_size_config_d_properties():
     """BASELINE config D (512 x 500 ANCF-3443 shells = 256 000 elements, 3.08 M DOF, 48 force points per element): the
     oracle does not finish at this size in test time, so parity rests on size-independent properties -- the internal
