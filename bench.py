@@ -89,6 +89,8 @@ def main():
                          "the block series (2x1x1, 2x2x1, 2x2x2 blocks of the config: N = 8 is BASELINE's config E)")
     ap.add_argument("--precond", type=int, default=0, choices=(0, 1, 2),
                     help="0 auto, 1 Chebyshev polynomial, 2 two-level p-multigrid (T10, one GPU)")
+    ap.add_argument("--linsolve-method", type=int, default=0, choices=(0, 1),
+                    help="0 preconditioned CG (the benchmarked default), 1 the sparse direct solve (experiments; one GPU)")
     ap.add_argument("--cheb-kappa", type=float, default=0.0, help="polynomial interval [lmax/kappa, lmax] (0 = default)")
     ap.add_argument("--cheb-bits", type=int, default=0, choices=(0, 16, 32, 64),
                     help="matrix precision streamed by the Chebyshev steps (0 = auto = fp16 scaled copy)")
@@ -157,7 +159,7 @@ def main():
     d, s = wl.make_engine(tl, w)
     # a capped iteration count (--max-pcg, kernel experiments) accepts iterates above rel_tol; the default fails loudly
     s.SetLinSolveOpts(tl.LinSolveOpts(args.rel_tol, args.max_pcg, 25, args.cheb_deg, args.cheb_kappa, args.cheb_bits,
-                                      args.precond, 0, int(args.max_pcg != 50000)))
+                                      args.precond, args.linsolve_method, int(args.max_pcg != 50000)))
     if world > 1:
         comm = None
         if backend == "nccl" and not args.torch_collectives and not os.environ.get("TLFEA_BENCH_TORCH_COLLECTIVES"):
@@ -341,8 +343,9 @@ def main():
         "metric": "T10-tet element-updates/sec per Newton step", "value": round(value, 1), "unit": "element-updates/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"config {args.config}: {w['desc']}, {E} elements / {N} nodes per GPU, "
-                               f"implicit Newton iteration incl. PCG solve (rel_tol {args.rel_tol:g})" +
+        "config": {"workload": f"config {args.config}: {w['desc']}, {E} elements / {N} nodes per GPU, " +
+                               (f"implicit Newton iteration incl. PCG solve (rel_tol {args.rel_tol:g})" if args.linsolve_method == 0
+                                else "implicit Newton iteration incl. sparse direct solve") +
                                (f"; {world} blocks in a {'x'.join(str(v) for v in w['grid'])} grid = one body of "
                                 f"{'x'.join(str(c * g) for c, g in zip(cfg['cells'], w['grid']))} cells ({E * world} elements"
                                 f"{', BASELINE config E' if args.config == 'C' and world == 8 and not args.slabs else ''})"
@@ -353,6 +356,8 @@ def main():
                        round(n_coll / max(1.0, float(np.sum(pcg_its))), 1)} if world > 1 else {}),
                    **(comm_report if world > 1 else {}),
                    "last_solve_rel_residual": float(lin_status["rel_res"]), "last_solve_converged": lin_status["converged"],
+                   **({"linear_solver": "sparse direct (the engine's multifrontal Cholesky, --linsolve-method 1): the "
+                                        "preconditioner entry below does not apply"} if args.linsolve_method == 1 else {}),
                    "preconditioner": ("block-Jacobi (3x3)" if deg_eff <= 1 else
                                       ((f"three-level p-multigrid V-cycle (T10 -> vertex mesh of {pmg[0]} nodes -> rigid-body modes "
                                         f"of aggregates, {cyc['level3_nodes']} nodes; Galerkin operators; Chebyshev smoothers of "

@@ -1626,6 +1626,13 @@ extern "C" int tlfea_rccl_comm_create_timeout(const char* id128, int rank, int w
   *comm_out = comm;
   return 0;
 }
+// hipGraph replay of the partitioned CG iteration (collectives included): on unless TLFEA_HALO_GRAPH=0, and off for the
+// process once the self-check below finds that RCCL cannot be captured / replayed here
+static bool g_rccl_graph_ok = true;
+static bool halo_graph_wanted() {
+  static const bool on = !(std::getenv("TLFEA_HALO_GRAPH") && std::atoi(std::getenv("TLFEA_HALO_GRAPH")) == 0);
+  return on && g_rccl_graph_ok;
+}
 extern "C" int tlfea_rccl_self_check(void* comm, int rank, int world, double timeout_s) {
   RcclApi& a = rccl_api();
   if (!a.lib || !comm) return fail("tlfea_rccl_self_check: no communicator");
@@ -1659,8 +1666,6 @@ extern "C" int tlfea_rccl_self_check(void* comm, int rank, int world, double tim
       rccl_watchdog_abort("the RCCL self-check (all-reduce + ring send/recv)", rank, timeout_s);
   }
   HIP_TRY(hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost));
-  (void)hipFree(d);
-  (void)hipStreamDestroy(st);
   const double s1 = world * (world + 1.0) / 2.0, s2 = world * (world + 1.0) * (2.0 * world + 1.0) / 6.0;
   const double ring = world > 1 ? 1000.0 + (rank + world - 1) % world : -1.0;
   if (h[0] != s1 || h[1] != s2 || h[4] != ring) {
@@ -1669,6 +1674,72 @@ extern "C" int tlfea_rccl_self_check(void* comm, int rank, int world, double tim
     std::fflush(stderr);
     _exit(97);
   }
+  // The same collectives once more, captured in a hipGraph and replayed -- what the solver does with its CG iteration.
+  // A capture RCCL refuses, or a replay with the wrong answer, switches the partitioned solve to eager launches on EVERY
+  // rank (agreed with an eager all-reduce); a replay that never finishes ends the job through the watchdog.
+  double ok = 1.0;
+  if (halo_graph_wanted()) {
+    const double h2[8] = {rank + 1.0, (rank + 1.0) * (rank + 1.0), 1000.0 + rank, 0, -1.0, 0, 0, 0};
+    double hr[8];
+    HIP_TRY(hipMemcpy(d, h2, sizeof(h2), hipMemcpyHostToDevice));
+    hipGraph_t g = nullptr;
+    hipGraphExec_t ge = nullptr;
+    g_rccl_stream = st;
+    bool captured = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess;
+    if (captured) {
+      int rc3 = rccl_allreduce_cb(comm, d, 2);
+      if (rc3 == 0 && world > 1) {
+        const int next = (rank + 1) % world, prev = (rank + world - 1) % world;
+        rc3 = a.group_start();
+        if (rc3 == 0) rc3 = a.send(d + 2, sizeof(double), 0, next, comm, st);
+        if (rc3 == 0) rc3 = a.recv(d + 4, sizeof(double), 0, prev, comm, st);
+        const int rc4 = a.group_end();
+        rc3 = rc3 ? rc3 : rc4;
+      }
+      captured = hipStreamEndCapture(st, &g) == hipSuccess && rc3 == 0 && g &&
+                 hipGraphInstantiate(&ge, g, nullptr, nullptr, 0) == hipSuccess;
+    }
+    g_rccl_stream = nullptr;
+    (void)hipGetLastError();
+    if (captured && hipGraphLaunch(ge, st) == hipSuccess) {
+      const auto t1 = std::chrono::steady_clock::now();
+      while (hipStreamQuery(st) == hipErrorNotReady) {
+        std::this_thread::sleep_for(std::chrono::milliseconds(5));
+        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count() > timeout_s)
+          rccl_watchdog_abort("the hipGraph replay of the RCCL self-check (set TLFEA_HALO_GRAPH=0 to run the partitioned "
+                              "solve without graph capture)", rank, timeout_s);
+      }
+      HIP_TRY(hipMemcpy(hr, d, sizeof(hr), hipMemcpyDeviceToHost));
+      if (hr[0] != s1 || hr[1] != s2 || hr[4] != ring) ok = 0.0;
+    } else {
+      ok = 0.0;
+    }
+    if (ge) (void)hipGraphExecDestroy(ge);
+    if (g) (void)hipGraphDestroy(g);
+    (void)hipGetLastError();
+    // agree: every rank replays graphs, or none does
+    HIP_TRY(hipMemcpy(d, &ok, sizeof(double), hipMemcpyHostToDevice));
+    g_rccl_stream = st;
+    const int rc5 = rccl_allreduce_cb(comm, d, 1);
+    g_rccl_stream = nullptr;
+    if (rc5) return fail("tlfea_rccl_self_check: RCCL refused the agreement all-reduce");
+    const auto t2 = std::chrono::steady_clock::now();
+    while (hipStreamQuery(st) == hipErrorNotReady) {
+      std::this_thread::sleep_for(std::chrono::milliseconds(5));
+      if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t2).count() > timeout_s)
+        rccl_watchdog_abort("the RCCL self-check (agreement all-reduce)", rank, timeout_s);
+    }
+    double sum = 0.0;
+    HIP_TRY(hipMemcpy(&sum, d, sizeof(double), hipMemcpyDeviceToHost));
+    if (sum != (double)world) {
+      g_rccl_graph_ok = false;
+      if (rank == 0)
+        std::fprintf(stderr, "tlfea: RCCL collectives could not be captured / replayed in a hipGraph on %d of %d ranks: the "
+                     "partitioned CG iteration runs with eager launches\n", world - (int)sum, world);
+    }
+  }
+  (void)hipFree(d);
+  (void)hipStreamDestroy(st);
   return 0;
 }
 
@@ -3676,7 +3747,26 @@ static int pcg(tlfea_newton_t s, const double* d_b, double* d_x, int* iters_out,
     }
     // hipGraph replay: single GPU, and the overlapping partition when its exchange is the built-in RCCL one (enqueued
     // from C++ on this stream, so the neighbour exchanges and all-reduces are captured with the kernels)
-    const bool graphs = s->use_graphs && !s->ar && !s->profiling && (!s->halo.on || s->halo.native);
+    bool graphs = s->use_graphs && !s->ar && !s->profiling && (!s->halo.on || (s->halo.native && halo_graph_wanted()));
+    // a capture that fails with collectives inside (RCCL refusing it) is not fatal: back to eager launches, once
+    auto prepare_graphs = [&]() -> int {
+      if (!graphs) return 0;
+      const int rc = cg_graphs_prepare(s, d_x, fused, deg, bits);
+      if (rc == 0 || !s->halo.on) return rc;
+      hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+      if (hipStreamIsCapturing(s->stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) {
+        hipGraph_t g = nullptr;
+        (void)hipStreamEndCapture(s->stream, &g);
+        if (g) (void)hipGraphDestroy(g);
+      }
+      (void)hipGetLastError();
+      cg_graphs_destroy(s);
+      g_rccl_graph_ok = false;
+      graphs = false;
+      std::fprintf(stderr, "tlfea: hipGraph capture of the partitioned CG iteration failed (%s): eager launches from here on\n",
+                   tlfea_last_error());
+      return 0;
+    };
     // mixed-precision iteration: where the fp32 polynomial path runs (its update kernel writes the start vectors the
     // replacement rewrites), on one GPU
     s->cur_b = d_b;
@@ -3695,7 +3785,7 @@ static int pcg(tlfea_newton_t s, const double* d_b, double* d_x, int* iters_out,
     // overlapping partition: the start residual r = b of a ghost is its owner's (grad L is evaluated redundantly on the
     // overlap and differs by round-off)
     if (s->halo.on) TRY(halo_refresh_f64(s, 0, halo_dr(s), 3, s->d_r));
-    if (graphs) TRY(cg_graphs_prepare(s, d_x, fused, deg, bits));
+    TRY(prepare_graphs());
     double indefinite = 0.0;
     HIP_TRY(hipMemsetAsync(s->d_scal + 3, 0, sizeof(double), s->stream));
     // p-multigrid converges in 30-45 iterations when its coarse polynomial covers the vertex-level spectrum; far more
@@ -3772,7 +3862,7 @@ static int pcg(tlfea_newton_t s, const double* d_b, double* d_x, int* iters_out,
         stalled = false;
         stall_check = pmg_coarse_degree_eff(s) < kPmgMaxCoarseDeg ? kStallIters : 0;
         TRY(pmg_coefficients(s));
-        if (graphs) TRY(cg_graphs_prepare(s, d_x, fused, deg, bits));
+        TRY(prepare_graphs());
       } else {
         s->lam_safety *= 1.5;  // kept for the following solves: the estimate is systematically low on this mesh
         if (s->verbose) std::printf("PCG breakdown: Chebyshev interval widened to %.3g x lambda_max estimate\n", s->lam_safety);
