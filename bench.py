@@ -185,6 +185,8 @@ def main():
         else:
             par.attach(s, part, torch, dist, local_preconditioner=args.local_precond, native_rccl=comm)
     d.UpdatePositions(w["x0"][:, 0], w["x0"][:, 1], w["x0"][:, 2])
+    if os.environ.get("TLFEA_BENCH_SOLVER_VERBOSE"):
+        s.SetVerbose(1)
     E, N = w["conn"].shape[0], w["X"].shape[0]
     E_local = E
     if halo:   # throughput counts the slab's own elements; the overlap is redundant work

@@ -3725,11 +3725,14 @@ static int pcg(tlfea_newton_t s, const double* d_b, double* d_x, int* iters_out,
     int check_every = std::max(1, s->lin.check_every / deg);
     // Every convergence test drains the launch queue (tens of microseconds: as much as an iteration on a small
     // mesh).  Consecutive Newton iterations need nearly the same number of CG iterations, so after the first solve
-    // the tests start one iteration before the previous solve's count and then run every iteration.
+    // the tests start four iterations before the previous solve's count and then run every iteration.
     const int bits = cheb_bits_eff(s) + 1000 * precond_eff(s);
     int first_check = check_every;
     if (s->last_outer_iters > 1 && s->last_deg == deg && s->last_bits == bits) {
-      first_check = s->last_outer_iters - 1;
+      // (a few iterations earlier, not one: the count can DROP by more than one between solves -- from the first Newton
+      // iteration of a step to the second -- and starting at last - 1 then over-solves for several solves in a row)
+      static const int back = std::getenv("TLFEA_PCG_CHECK_BACK") ? std::max(1, std::atoi(std::getenv("TLFEA_PCG_CHECK_BACK"))) : 4;
+      first_check = std::max(1, s->last_outer_iters - back);
       check_every = 1;
     }
     s->last_deg = deg;
