@@ -2390,7 +2390,10 @@ static int estimate_lam_max(tlfea_newton_t s, const double* d_b) {
   tlfea_t10_t d = s->d;
   const int N = s->N;
   const bool cold = !(s->lam_max > 0.0);
-  const int iters = cold ? 16 : 2;  // warm: H moves little between Newton iterations, the vector is kept
+  // warm: H moves little between Newton iterations and the vector is kept, so the power iteration simply continues across
+  // solves -- one product per solve (each is a full fp64 SpMV: 0.7 ms at config C)
+  static const int warm_its = std::getenv("TLFEA_LMAX_WARM_ITERS") ? std::max(1, std::atoi(std::getenv("TLFEA_LMAX_WARM_ITERS"))) : 1;
+  const int iters = cold ? 16 : warm_its;
   // v <- D^-1 H v / ||D^-1 H v||, the norm stays on the device between iterations: one host read at the end
   // overlapping partition: the iteration lives on the owned rows; ghost layer 1 of the vector is refreshed before every
   // product, deeper ghosts are never touched
