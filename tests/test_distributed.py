@@ -313,11 +313,13 @@ def test_halo_structured_blocks_agree(world):
     assert n_fixed == (2 * cfg["cells"][1] * pg[1] + 1) * (2 * cfg["cells"][2] * pg[2] + 1)   # the x = 0 face, owned once
 
 
-@pytest.mark.parametrize("world,partitioner", [(2, "slab"), (3, "rcb")])
+@pytest.mark.parametrize("world,partitioner", [(2, "slab"), (3, "rcb"), (8, "rcb")])
 def test_halo_gloo_oracle_engine(tmp_path, world, partitioner):
     """CPU coverage of the overlapping partition (no GPU): every rank runs the oracle on its overlapped sub-mesh; the
     exchange lists of partition.halo_partition drive gloo send / recv pairs (ghost refresh of the CG direction and of the
-    Newton update), dot products run over owned DOFs; owned AND ghost positions equal the un-partitioned oracle's."""
+    Newton update), dot products run over owned DOFs; owned AND ghost positions equal the un-partitioned oracle's.
+    8 ranks: three levels of coordinate bisection, i.e. the 2 x 2 x 2 arrangement of the scaling run (a rank exchanges with
+    face, edge and corner neighbours)."""
     rep = launch(world, ["--engine", "oracle", "--mesh", "box", "--steps", "2", "--mode", "halo", "--depth", "2",
                          "--partitioner", partitioner], tmp_path)
     assert rep["ok"] and rep["n_iface"] > 0 and rep["max_dup"] <= 1e-12, rep
