@@ -368,7 +368,10 @@ def main():
                                         f"two-level p-multigrid V-cycle (T10 -> vertex mesh, {pmg[0]} coarse nodes, Galerkin "
                                         f"coarse operator, {cyc['fine_terms']}-term Chebyshev smoothers, degree-{pmg[2]} coarse "
                                         f"polynomial), ")
-                                       if pmg else f"Chebyshev degree {deg_eff} of block-Jacobi, ") + "steps stream a "
+                                       if pmg else (f"Chebyshev degree {deg_eff} of the operator scaled by its 12 x 12 node "
+                                                    f"blocks (L^-1 H L^-T, the four coefficient vectors of an ANCF node), "
+                                                    if s.GetPolynomialInfo()["block"] == 12 else
+                                                    f"Chebyshev degree {deg_eff} of block-Jacobi, ")) + "steps stream a "
                                       f"{'scaled fp%d copy of H' % bits_eff if bits_eff != 64 else 'fp64 H'} "
                                       f"with fp{vec_bits} work vectors; "
                                       "outer CG, residual and convergence test in fp64 on H")},

@@ -330,6 +330,10 @@ int tlfea_newton_get_comm_stats(tlfea_newton_t s, double *out8);
  * (0: polynomial preconditioner), fine smoother terms, vertex-level smoother terms (three levels), vertex-level polynomial
  * degree (two levels), level-3 polynomial degree, level-3 nodes. */
 int tlfea_newton_pmg_cycle_info(tlfea_newton_t s, int *out6);
+/* Polynomial preconditioner in use (no reference counterpart: the reference calls cuDSS): out3 = degree, interval ratio
+ * kappa (rounded), block size of the diagonal scaling of its operator -- 3 (per coefficient vector / node) or 12 (ANCF:
+ * the four coefficient vectors of a node together, as a change of variables L^-1 H L^-T). */
+int tlfea_newton_polynomial_info(tlfea_newton_t s, int *out3);
 
 /* ---- SyncedAdamWNocoopSolver (SyncedAdamWNocoop.cuh:22-198, SyncedAdamWNocoop.cu:262-500) ------------------------
  * First-order ALM solver on the same velocity unknowns: per inner iteration one AdamW moment update, x = x_prev + dt v,

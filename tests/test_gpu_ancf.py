@@ -189,6 +189,8 @@ def test_newton_steps(pname, steps):
         xo = np.stack([o.x, o.y, o.z], axis=1)
         assert disp_err_ok(xg, xo, X0), (st_g, st_o)
         assert st_g["outer"] == st_o[0] and st_g["newton"] == st_o[1]
+    # the default preconditioner of the ANCF kinds: degree-16 polynomial of the operator scaled by its 12 x 12 node blocks
+    assert s.GetPolynomialInfo() == dict(degree=16, kappa=200, block=12)
     del s
     d.Destroy()
 

@@ -631,6 +631,151 @@ void launch_lp_convert(hipStream_t s, int N, const Incidence& inc, const double*
                        (float*)B1);
 }
 
+// ---- ANCF: node-block (12 x 12) scaling of the polynomial's operator -------------------------------------------------
+// The four coefficient vectors of an ANCF node (r, r_x, r_y, r_z) are strongly coupled (thickness / gradient stiffness
+// against the position's): block-Jacobi on the 12 x 12 node blocks D12 = L L^T instead of the 3 x 3 ones cuts kappa by ~2
+// on the plate (CPU prototype: 416 -> 315 polynomial steps per solve).  Done as a change of variables, so that every
+// polynomial kernel stays as it is: the streamed copy holds  H^ = L^-1 H L^-T  (its 12 x 12 diagonal blocks are the
+// identity: no diagonal scaling, (S D S)^-1 = I), the preconditioner is  z = L^-T p(H^) L^-1 r.
+//
+// Linv[p]: row-major 12 x 12, lower triangle = inverse of the Cholesky factor of node p's diagonal block, zeros above
+__global__ void blk12_factor_kernel(int Np, Incidence inc, const double* __restrict__ Hval, double* __restrict__ Linv,
+                                    double* __restrict__ sc, double* __restrict__ Dinv_s, int* __restrict__ err) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= Np) return;
+  double A[12][12];
+  for (int a = 0; a < 4; a++) {
+    const int i = 4 * p + a, off0 = inc.off[i], deg = inc.off[i + 1] - off0, row = 3 * deg;
+    const int k0 = inc.diagpos[i] - a;  // the node's four columns are adjacent in the sorted row
+    const double* Hi = Hval + (size_t)9 * off0;
+    for (int b = 0; b < 4; b++)
+      for (int d = 0; d < 3; d++)
+        for (int e = 0; e < 3; e++) A[3 * a + d][3 * b + e] = Hi[(size_t)d * row + 3 * (k0 + b) + e];
+  }
+  bool bad = false;
+  for (int j = 0; j < 12; j++) {  // Cholesky, lower, in place
+    double dj = A[j][j];
+    for (int q = 0; q < j; q++) dj -= A[j][q] * A[j][q];
+    if (!(dj > 0.0)) {
+      bad = true;
+      dj = 1.0;
+    }
+    const double l = sqrt(dj), il = 1.0 / l;
+    A[j][j] = l;
+    for (int i = j + 1; i < 12; i++) {
+      double v = A[i][j];
+      for (int q = 0; q < j; q++) v -= A[i][q] * A[j][q];
+      A[i][j] = v * il;
+    }
+  }
+  if (bad) *err = 1;
+  double* out = Linv + (size_t)144 * p;
+  for (int c = 0; c < 12; c++) {  // column c of L^-1 by forward substitution
+    double x[12];
+    for (int i = 0; i < 12; i++) {
+      double v = i == c ? 1.0 : 0.0;
+      for (int q = c; q < i; q++) v -= A[i][q] * x[q];
+      x[i] = i < c ? 0.0 : v / A[i][i];
+    }
+    for (int i = 0; i < 12; i++) out[12 * i + c] = x[i];
+  }
+  for (int a = 0; a < 4; a++) {
+    const int i = 4 * p + a;
+    for (int d = 0; d < 3; d++) {
+      sc[3 * i + d] = 1.0;
+      for (int e = 0; e < 3; e++) Dinv_s[(size_t)9 * i + 3 * d + e] = d == e ? 1.0 : 0.0;
+    }
+  }
+}
+
+// out = L^-1 in (T = false) or L^-T in (T = true), node by node; 12 lanes per node
+template <bool T>
+__global__ void blk12_apply_kernel(int Np, const double* __restrict__ Linv, const double* __restrict__ in,
+                                   double* __restrict__ out) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int p = t / 12, r = t - 12 * p;
+  if (p >= Np) return;
+  const double* M = Linv + (size_t)144 * p;
+  const double* v = in + (size_t)12 * p;
+  double s = 0.0;
+  if (T) {
+    for (int q = r; q < 12; q++) s += M[12 * q + r] * v[q];
+  } else {
+    for (int q = 0; q <= r; q++) s += M[12 * r + q] * v[q];
+  }
+  out[(size_t)12 * p + r] = s;
+}
+
+// streamed copy of H^ = L^-1 H L^-T: one lane per 3 x 3 block (row node i = 4p + a, column node 4q + b):
+// H^(a, b) = sum_{a' <= a, b' <= b} Linv_p(a, a') H(4p + a', 4q + b') Linv_q(b, b')^T   (3 x 3 sub-blocks)
+template <typename HT>
+__global__ __launch_bounds__(256) void lp_convert12_kernel(int N, Incidence inc, const double* __restrict__ Hval,
+                                                          const double* __restrict__ Linv, Blk8<HT>* __restrict__ B8,
+                                                          HT* __restrict__ B1) {
+  const int l32 = threadIdx.x & 31;
+  const int i = blockIdx.x * 8 + (threadIdx.x >> 5);
+  if (i >= N) return;
+  const int p = i >> 2, a = i & 3;
+  const int off0 = inc.off[i], deg = inc.off[i + 1] - off0, row = 3 * deg;
+  const double* Lp = Linv + (size_t)144 * p + 36 * a;  // rows 3a .. 3a + 2 of Linv_p
+  for (int k = l32; k < deg; k += 32) {
+    const int c = inc.cols[off0 + k], q = c >> 2, b = c & 3;
+    const double* Lq = Linv + (size_t)144 * q + 36 * b;
+    double R[3][3] = {};
+    for (int a2 = 0; a2 <= a; a2++) {
+      // T = Linv_p(a, a2) . H(4p + a2, 4q + 0..b): the row of node 4p + a2 has the same columns, its block of column
+      // 4q + b2 sits at k - b + b2
+      const int i2 = 4 * p + a2;
+      const double* H2 = Hval + (size_t)9 * inc.off[i2];
+      for (int b2 = 0; b2 <= b; b2++) {
+        const double* Hb = H2 + 3 * (k - b + b2);
+        double Tm[3][3];
+#pragma unroll
+        for (int d = 0; d < 3; d++)
+#pragma unroll
+          for (int e = 0; e < 3; e++)
+            Tm[d][e] = Lp[12 * d + 3 * a2] * Hb[e] + Lp[12 * d + 3 * a2 + 1] * Hb[row + e] +
+                       Lp[12 * d + 3 * a2 + 2] * Hb[2 * (size_t)row + e];
+#pragma unroll
+        for (int d = 0; d < 3; d++)
+#pragma unroll
+          for (int e = 0; e < 3; e++)
+            R[d][e] += Tm[d][0] * Lq[12 * e + 3 * b2] + Tm[d][1] * Lq[12 * e + 3 * b2 + 1] + Tm[d][2] * Lq[12 * e + 3 * b2 + 2];
+      }
+    }
+    Blk8<HT> blk;
+    HT last = (HT)0;
+#pragma unroll
+    for (int d = 0; d < 3; d++)
+#pragma unroll
+      for (int e = 0; e < 3; e++) {
+        const HT v = (HT)R[d][e];
+        if (3 * d + e < 8) blk.v[3 * d + e] = v;
+        else last = v;
+      }
+    B8[off0 + k] = blk;
+    B1[off0 + k] = last;
+  }
+}
+
+void launch_blk12_factor(hipStream_t s, int Np, const Incidence& inc, const double* Hval, double* Linv, double* sc,
+                         double* Dinv_s, int* err) {
+  hipLaunchKernelGGL(blk12_factor_kernel, dim3((Np + 63) / 64), dim3(64), 0, s, Np, inc, Hval, Linv, sc, Dinv_s, err);
+}
+void launch_blk12_apply(hipStream_t s, int Np, const double* Linv, bool transpose, const double* in, double* out) {
+  const dim3 g((unsigned)(((size_t)12 * Np + 255) / 256)), b(256);
+  if (transpose) hipLaunchKernelGGL(blk12_apply_kernel<true>, g, b, 0, s, Np, Linv, in, out);
+  else hipLaunchKernelGGL(blk12_apply_kernel<false>, g, b, 0, s, Np, Linv, in, out);
+}
+void launch_lp_convert12(hipStream_t s, int N, const Incidence& inc, const double* Hval, const double* Linv, void* B8,
+                         void* B1, int bits) {
+  const dim3 g((N + 7) / 8), b(256);
+  if (bits == 16)
+    hipLaunchKernelGGL(lp_convert12_kernel<_Float16>, g, b, 0, s, N, inc, Hval, Linv, (Blk8<_Float16>*)B8, (_Float16*)B1);
+  else
+    hipLaunchKernelGGL(lp_convert12_kernel<float>, g, b, 0, s, N, inc, Hval, Linv, (Blk8<float>*)B8, (float*)B1);
+}
+
 // sc_mask = own ? sc : 0 : scaling into / out of the polynomial that also drops the nodes another rank owns
 __global__ void mask_scale_kernel(int N, const double* __restrict__ sc, const int* __restrict__ own,
                                   double* __restrict__ out) {

@@ -1024,6 +1024,10 @@ struct tlfea_newton_s {
   long cg_graph_key[6] = {0, 0, 0, 0, 0, 0};
   bool use_graphs = true;     // TLFEA_GRAPH=0 launches every kernel eagerly
   int last_outer_iters = 0;   // CG iterations of the previous solve: where the next one starts testing convergence
+  // ANCF: 12 x 12 node-block scaling of the polynomial's operator (solver_kernels.hip, blk12_*): -1 not decided yet
+  int blk12 = -1;
+  double* d_L12inv = nullptr;
+  int* d_blk12_err = nullptr;
   int last_deg = 0, last_bits = 0;
   int h_nnz = 0;
   std::vector<int> h_row_offsets, h_col_indices;  // reference DOF-level CSR index arrays (host)
@@ -1142,6 +1146,8 @@ extern "C" int tlfea_newton_destroy(tlfea_newton_t s) {
     if (p) (void)hipFree(p);
   for (int* p : s->d_rg4)
     if (p) (void)hipFree(p);
+  if (s->d_L12inv) (void)hipFree(s->d_L12inv);
+  if (s->d_blk12_err) (void)hipFree(s->d_blk12_err);
   if (s->d_gvec) (void)hipFree(s->d_gvec);
   if (s->d_cmass) (void)hipFree(s->d_cmass);
   if (s->d_Fq) (void)hipFree(s->d_Fq);
@@ -2307,13 +2313,18 @@ static int assemble(tlfea_newton_t s, bool fq_fresh = true) {
 // of H, fp32 vectors) and need no reductions, so a high degree wins on every mesh size: measured (MI355X, rel 1e-12)
 // config B 12/16/20/24/32 -> 5.3/5.1/4.7/4.7/4.8 ms per Newton iteration, config C 555/531/539/513/528 ms, against
 // 12.8 ms / 1.3-1.5 s with plain block-Jacobi.  The matching interval ratio kappa grows with the degree.
+static bool blk12_on(tlfea_newton_t s);
+// auto: T10 (the polynomial alone, where no p-multigrid hierarchy exists) degree 24 on [lmax/1600, lmax]; the ANCF kinds
+// degree 16 on [lmax/200, lmax] with the 12 x 12 node-block scaling, [lmax/400, lmax] without (config D sweep,
+// profiles/r03_sweep_ancf_block12.txt: 140.7 ms at 24/1600 -> 82.8 at 16/400 -> 73.8 with the node blocks)
 static int cheb_degree_eff(tlfea_newton_t s) {
   if (s->lin.cheb_degree > 0) return s->lin.cheb_degree;
-  return 24;
+  return s->d->kind != kT10 ? 16 : 24;
 }
 static double cheb_kappa_eff(tlfea_newton_t s) {
   if (s->lin.cheb_kappa > 1.0) return s->lin.cheb_kappa;
   const int deg = cheb_degree_eff(s);
+  if (s->d->kind != kT10 && s->lin.cheb_degree <= 0) return blk12_on(s) ? 200.0 : 400.0;
   return deg >= 22 ? 1600.0 : (deg >= 14 ? 800.0 : 400.0);
 }
 
@@ -2332,6 +2343,31 @@ static int fine_bits(tlfea_newton_t s) {
   const int bits = cheb_bits_eff(s);
   return (forced == 8 && bits == 16 && precond_eff(s) == 2 && !s->ar) ? 8 : bits;
 }
+// ANCF kinds, one GPU, polynomial preconditioner on the low-precision copy: the copy is that of L^-1 H L^-T with the 12 x 12
+// node blocks D12 = L L^T (TLFEA_ANCF_BLOCK12=0 keeps the 3 x 3 scaling).  Needs the pattern to come in complete 4 x 4
+// groups of blocks (constraint rows that couple single coefficient vectors break that: then the 3 x 3 form stays).
+static bool blk12_on(tlfea_newton_t s) {
+  if (s->blk12 >= 0) return s->blk12 == 1;
+  tlfea_t10_t d = s->d;
+  static const bool wanted = !(std::getenv("TLFEA_ANCF_BLOCK12") && std::atoi(std::getenv("TLFEA_ANCF_BLOCK12")) == 0);
+  bool ok = wanted && d->kind != kT10 && !dist_on(s) && s->N % 4 == 0 && !d->h_off.empty();
+  for (int p = 0; ok && p < s->N / 4; p++) {
+    const int o0 = d->h_off[4 * p], deg = d->h_off[4 * p + 1] - o0;
+    ok = deg % 4 == 0;
+    for (int k = 0; ok && k < deg; k++) {
+      const int c = d->h_cols[o0 + k];
+      ok = c == (d->h_cols[o0 + (k & ~3)] | (k & 3)) && (d->h_cols[o0 + (k & ~3)] & 3) == 0;
+    }
+    for (int a = 1; ok && a < 4; a++) {
+      const int oa = d->h_off[4 * p + a];
+      ok = d->h_off[4 * p + a + 1] - oa == deg && std::equal(d->h_cols.begin() + o0, d->h_cols.begin() + o0 + deg, d->h_cols.begin() + oa);
+    }
+  }
+  s->blk12 = ok ? 1 : 0;
+  return ok;
+}
+static bool blk12_now(tlfea_newton_t s);
+
 // (re)build the low-precision copy from the current H and block diagonal (d_D, d_Dinv must be current)
 static int lp_build(tlfea_newton_t s) {
   tlfea_t10_t d = s->d;
@@ -2346,6 +2382,18 @@ static int lp_build(tlfea_newton_t s) {
     HIP_TRY(hipMalloc(&s->d_B1, (size_t)d->nnz_coef * eb));
     s->lp_bits_alloc = bits;
   }
+  if (blk12_now(s)) {
+    if (!s->d_L12inv) {
+      HIP_TRY(hipMalloc((void**)&s->d_L12inv, (size_t)36 * s->N * sizeof(double)));  // 144 per node of 4 coefficient vectors
+      HIP_TRY(hipMalloc((void**)&s->d_blk12_err, sizeof(int)));
+      HIP_TRY(hipMemsetAsync(s->d_blk12_err, 0, sizeof(int), s->stream));
+    }
+    launch_blk12_factor(s->stream, s->N / 4, d->inc(), s->d_H, s->d_L12inv, s->d_sc, s->d_Dinv_s, s->d_blk12_err);
+    launch_lp_convert12(s->stream, s->N, d->inc(), s->d_H, s->d_L12inv, s->d_B8, s->d_B1, bits);
+    launch_to_float(s->stream, (size_t)9 * s->N, s->d_Dinv_s, s->d_f32 + (size_t)18 * s->N);
+    HIP_TRY(hipGetLastError());
+    return 0;
+  }
   launch_lp_scale(s->stream, s->N, s->d_D, s->d_Dinv, s->d_sc, s->d_Dinv_s);
   const bool local = s->ar && s->d_own;  // rank-local preconditioner on the owned nodes
   launch_lp_convert(s->stream, s->N, d->inc(), s->d_H, s->d_sc, local ? s->d_own : nullptr, s->d_D, s->d_B8, s->d_B1,
@@ -2355,6 +2403,10 @@ static int lp_build(tlfea_newton_t s) {
     launch_to_float(s->stream, (size_t)9 * s->N, s->d_Dinv_s, s->d_f32 + (size_t)18 * s->N);
   HIP_TRY(hipGetLastError());
   return 0;
+}
+
+static bool blk12_now(tlfea_newton_t s) {
+  return blk12_on(s) && precond_eff(s) != 2 && cheb_degree_eff(s) > 1 && cheb_bits_eff(s) != 64 && s->lin.method == 0;
 }
 
 // lambda_max(D^-1 H) by power iteration (warm-started from the previous solve's vector; H changes little between
@@ -2401,12 +2453,16 @@ static int estimate_lam_max(tlfea_newton_t s, const double* d_b) {
   if (cold) launch_apply_dinv(s->stream, Nr, s->d_Dinv, d_b, s->d_eigv);
   TRY(device_sumsq_async(s, s->d_eigv, s->d_w, nr));
   launch_scale_inv_sqrt(s->stream, nr, s->d_scal, s->d_eigv);
+  const bool b12 = blk12_now(s);  // lambda_max of L^-1 H L^-T: v <- L^-1 H L^-T v
   for (int k = 0; k < iters; k++) {
     TRY(halo_refresh_f64(s, 0, 1, 3, s->d_eigv));
-    launch_spmv_dir_dot(s->stream, Nr, d->inc(), s->d_H, s->d_eigv, s->d_eigv, 1, part(s, 1), part(s, 0), s->d_p2, s->d_q,
+    if (b12) launch_blk12_apply(s->stream, N / 4, s->d_L12inv, true, s->d_eigv, s->d_cd);
+    const double* vv = b12 ? s->d_cd : s->d_eigv;
+    launch_spmv_dir_dot(s->stream, Nr, d->inc(), s->d_H, vv, vv, 1, part(s, 1), part(s, 0), s->d_p2, s->d_q,
                         part(s, 2), false, s->spmv_nt);
     if (s->ar) TRY(iface_sum(s, s->d_q, 3));
-    launch_apply_dinv(s->stream, Nr, s->d_Dinv, s->d_q, s->d_eigv);
+    if (b12) launch_blk12_apply(s->stream, N / 4, s->d_L12inv, false, s->d_q, s->d_eigv);
+    else launch_apply_dinv(s->stream, Nr, s->d_Dinv, s->d_q, s->d_eigv);
     TRY(device_sumsq_async(s, s->d_eigv, s->d_w, nr));
     launch_scale_inv_sqrt(s->stream, nr, s->d_scal, s->d_eigv);
   }
@@ -3282,7 +3338,8 @@ static int enqueue_cg_iteration_impl(tlfea_newton_t s, double* d_x, bool first, 
   double *p_old = s->d_p, *p_new = s->d_p2;
   if (fused && cur) std::swap(p_old, p_new);
   // single-GPU fp32 polynomial: its start vectors come out of the previous iteration's update kernel
-  const bool fuse_init = deg > 1 && cheb_bits_eff(s) != 64 && !s->ar;
+  const bool b12 = blk12_now(s);
+  const bool fuse_init = deg > 1 && cheb_bits_eff(s) != 64 && !s->ar && !b12;
   // Overlapping partition: the CG recurrences (x, r, p, q) live on the OWNED rows.  Two neighbour exchanges per iteration on
   // this level: layer 1 of the direction z (the SpMV's ghost columns) and layers <= Dr of the updated residual (what the
   // next V-cycle starts from).  The residual of a ghost is its OWNER's, bit for bit: recomputing it redundantly (q = H p on
@@ -3298,7 +3355,11 @@ static int enqueue_cg_iteration_impl(tlfea_newton_t s, double* d_x, bool first, 
     // polynomial preconditioner: z = Cheb(r), r.z slots -> part(cur)   (deg-1 SpMV launches, no reductions)
     if (precond_eff(s) == 2)
       TRY(pmg_apply(s, s->d_r, s->d_zv, part(s, cur), fuse_init && !first));
-    else
+    else if (b12) {  // z = L^-T p(L^-1 H L^-T) L^-1 r; the polynomial's r.z slots are r^.z^ = r.z
+      launch_blk12_apply(s->stream, N / 4, s->d_L12inv, false, s->d_r, s->d_cd);
+      TRY(cheb_apply(s, s->d_cd, s->d_cd2, part(s, cur), false));
+      launch_blk12_apply(s->stream, N / 4, s->d_L12inv, true, s->d_cd2, s->d_zv);
+    } else
       TRY(cheb_apply(s, s->d_r, s->d_zv, part(s, cur), fuse_init && !first));
     if ((s->ar && !(s->d_own && cheb_bits_eff(s) != 64)) || hal) TRY(parts_sum(s, part(s, cur)));
     if (hal) TRY(halo_refresh_f64(s, 0, 1, 3, s->d_zv));
@@ -3983,6 +4044,13 @@ extern "C" int tlfea_newton_pmg_cycle_info(tlfea_newton_t s, int* out6) {
   out6[3] = l3 ? 0 : pmg_coarse_degree_eff(s);
   out6[4] = l3 ? pmg_level3_degree(s->pmg.agg.N3) : 0;
   out6[5] = l3 ? s->pmg.agg.N3 : 0;
+  return 0;
+}
+extern "C" int tlfea_newton_polynomial_info(tlfea_newton_t s, int* out3) {
+  if (!s || !out3) return fail("null argument");
+  out3[0] = cheb_degree_eff(s);
+  out3[1] = (int)std::lround(cheb_kappa_eff(s));
+  out3[2] = blk12_now(s) ? 12 : 3;
   return 0;
 }
 extern "C" int tlfea_newton_pmg_coarse_degree(tlfea_newton_t s) { return s && s->pmg.ok ? pmg_coarse_degree_eff(s) : 0; }

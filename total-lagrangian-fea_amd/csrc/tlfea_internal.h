@@ -282,6 +282,13 @@ void launch_unpack(hipStream_t s, int n, int dim, const int* node, const int* sl
 void launch_extract_diag(hipStream_t s, int N, const Incidence& inc, const double* Hval, double* D);
 void launch_invert_diag(hipStream_t s, int N, const double* D, double* Dinv);
 
+// ANCF node-block (12 x 12) scaling of the polynomial's operator (solver_kernels.hip)
+void launch_blk12_factor(hipStream_t s, int Np, const Incidence& inc, const double* Hval, double* Linv, double* sc,
+                         double* Dinv_s, int* err);
+void launch_blk12_apply(hipStream_t s, int Np, const double* Linv, bool transpose, const double* in, double* out);
+void launch_lp_convert12(hipStream_t s, int N, const Incidence& inc, const double* Hval, const double* Linv, void* B8,
+                         void* B1, int bits);
+
 // ---- sparse direct solve (direct_kernels.hip on the plan of mf_host.h) ------------------------------------------------
 struct MfFrontDev {  // a front as the kernels see it (DOF units)
   long long F_off, L_off, v_off, map_off, rows_off;

@@ -100,6 +100,12 @@ class SyncedNewtonSolver:
         check(self._lib.tlfea_newton_pmg_cycle_info(self._h, out))
         return dict(zip(("levels", "fine_terms", "vertex_terms", "vertex_degree", "level3_degree", "level3_nodes"), list(out)))
 
+    def GetPolynomialInfo(self):
+        """dict(degree, kappa, block) of the polynomial preconditioner in use; block 12 = ANCF node-block scaling"""
+        out = (C.c_int * 3)()
+        check(self._lib.tlfea_newton_polynomial_info(self._h, out))
+        return dict(zip(("degree", "kappa", "block"), list(out)))
+
     def GetPmgLevel3Info(self):
         """(aggregates, 3x3 blocks, polynomial degree) of the third level, (0, 0, 0) when the cycle has two levels"""
         na, nnz, deg = C.c_int(), C.c_int(), C.c_int()
