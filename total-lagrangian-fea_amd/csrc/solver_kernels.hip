@@ -640,7 +640,8 @@ void launch_lp_convert(hipStream_t s, int N, const Incidence& inc, const double*
 //
 // Linv[p]: row-major 12 x 12, lower triangle = inverse of the Cholesky factor of node p's diagonal block, zeros above
 __global__ void blk12_factor_kernel(int Np, Incidence inc, const double* __restrict__ Hval, double* __restrict__ Linv,
-                                    double* __restrict__ sc, double* __restrict__ Dinv_s, int* __restrict__ err) {
+                                    float* __restrict__ Linv_f, double* __restrict__ sc, double* __restrict__ Dinv_s,
+                                    int* __restrict__ err) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= Np) return;
   double A[12][12];
@@ -677,7 +678,10 @@ __global__ void blk12_factor_kernel(int Np, Incidence inc, const double* __restr
       for (int q = c; q < i; q++) v -= A[i][q] * x[q];
       x[i] = i < c ? 0.0 : v / A[i][i];
     }
-    for (int i = 0; i < 12; i++) out[12 * i + c] = x[i];
+    for (int i = 0; i < 12; i++) {
+      out[12 * i + c] = x[i];
+      Linv_f[(size_t)144 * p + 12 * i + c] = (float)x[i];  // the copy the two applications per CG iteration stream
+    }
   }
   for (int a = 0; a < 4; a++) {
     const int i = 4 * p + a;
@@ -690,12 +694,12 @@ __global__ void blk12_factor_kernel(int Np, Incidence inc, const double* __restr
 
 // out = L^-1 in (T = false) or L^-T in (T = true), node by node; 12 lanes per node
 template <bool T>
-__global__ void blk12_apply_kernel(int Np, const double* __restrict__ Linv, const double* __restrict__ in,
+__global__ void blk12_apply_kernel(int Np, const float* __restrict__ Linv, const double* __restrict__ in,
                                    double* __restrict__ out) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   const int p = t / 12, r = t - 12 * p;
   if (p >= Np) return;
-  const double* M = Linv + (size_t)144 * p;
+  const float* M = Linv + (size_t)144 * p;
   const double* v = in + (size_t)12 * p;
   double s = 0.0;
   if (T) {
@@ -706,74 +710,89 @@ __global__ void blk12_apply_kernel(int Np, const double* __restrict__ Linv, cons
   out[(size_t)12 * p + r] = s;
 }
 
-// streamed copy of H^ = L^-1 H L^-T: one lane per 3 x 3 block (row node i = 4p + a, column node 4q + b):
-// H^(a, b) = sum_{a' <= a, b' <= b} Linv_p(a, a') H(4p + a', 4q + b') Linv_q(b, b')^T   (3 x 3 sub-blocks)
+// streamed copy of H^ = L^-1 H L^-T.  One wavefront per node p; a 12 x 12 block (p, q) is a tile of 16 lanes (a, b), four
+// tiles at a time: every lane loads ITS 3 x 3 block of H once, then two passes through LDS --
+//   T(a, b)  = sum_{a2 <= a} Linv_p(a, a2) H(a2, b)         (left factor; the tile's column b)
+//   H^(a, b) = sum_{b2 <= b} T(a, b2) Linv_q(b, b2)^T       (right factor; the tile's row a)
+// 8 x 27 multiply-adds per block at most (a single pass over both sums is 16 x 54 and re-reads every block 16 times:
+// 8.3 ms at config D against 1.9 for this form).
+__device__ __forceinline__ void wave_sync_s() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 template <typename HT>
-__global__ __launch_bounds__(256) void lp_convert12_kernel(int N, Incidence inc, const double* __restrict__ Hval,
-                                                          const double* __restrict__ Linv, Blk8<HT>* __restrict__ B8,
-                                                          HT* __restrict__ B1) {
-  const int l32 = threadIdx.x & 31;
-  const int i = blockIdx.x * 8 + (threadIdx.x >> 5);
-  if (i >= N) return;
-  const int p = i >> 2, a = i & 3;
-  const int off0 = inc.off[i], deg = inc.off[i + 1] - off0, row = 3 * deg;
+__global__ __launch_bounds__(64) void lp_convert12_kernel(int Np, Incidence inc, const double* __restrict__ Hval,
+                                                         const double* __restrict__ Linv, Blk8<HT>* __restrict__ B8,
+                                                         HT* __restrict__ B1) {
+  __shared__ double Hs[64][9], Ts[64][9];
+  const int p = blockIdx.x, lane = threadIdx.x, tl = lane >> 4, a = (lane >> 2) & 3, b = lane & 3;
+  const int i = 4 * p + a, off0 = inc.off[i], deg = inc.off[i + 1] - off0, row = 3 * deg, tiles = deg >> 2;
   const double* Lp = Linv + (size_t)144 * p + 36 * a;  // rows 3a .. 3a + 2 of Linv_p
-  for (int k = l32; k < deg; k += 32) {
-    const int c = inc.cols[off0 + k], q = c >> 2, b = c & 3;
-    const double* Lq = Linv + (size_t)144 * q + 36 * b;
-    double R[3][3] = {};
-    for (int a2 = 0; a2 <= a; a2++) {
-      // T = Linv_p(a, a2) . H(4p + a2, 4q + 0..b): the row of node 4p + a2 has the same columns, its block of column
-      // 4q + b2 sits at k - b + b2
-      const int i2 = 4 * p + a2;
-      const double* H2 = Hval + (size_t)9 * inc.off[i2];
-      for (int b2 = 0; b2 <= b; b2++) {
-        const double* Hb = H2 + 3 * (k - b + b2);
-        double Tm[3][3];
+  const double* Hi = Hval + (size_t)9 * off0;
+  for (int t0 = 0; t0 < tiles; t0 += 4) {
+    const int t = t0 + tl, k = 4 * t + b;
+    const bool act = t < tiles;
+    int q = 0;
+    if (act) {
+      q = inc.cols[off0 + k] >> 2;
 #pragma unroll
-        for (int d = 0; d < 3; d++)
+      for (int d = 0; d < 3; d++)
 #pragma unroll
-          for (int e = 0; e < 3; e++)
-            Tm[d][e] = Lp[12 * d + 3 * a2] * Hb[e] + Lp[12 * d + 3 * a2 + 1] * Hb[row + e] +
-                       Lp[12 * d + 3 * a2 + 2] * Hb[2 * (size_t)row + e];
-#pragma unroll
-        for (int d = 0; d < 3; d++)
-#pragma unroll
-          for (int e = 0; e < 3; e++)
-            R[d][e] += Tm[d][0] * Lq[12 * e + 3 * b2] + Tm[d][1] * Lq[12 * e + 3 * b2 + 1] + Tm[d][2] * Lq[12 * e + 3 * b2 + 2];
-      }
+        for (int e = 0; e < 3; e++) Hs[lane][3 * d + e] = Hi[(size_t)d * row + 3 * k + e];
     }
-    Blk8<HT> blk;
-    HT last = (HT)0;
+    wave_sync_s();
+    if (act) {
+      double T[9] = {};
+      for (int a2 = 0; a2 <= a; a2++) {
+        const double* Hb = Hs[(lane & ~12) | (a2 << 2)];
 #pragma unroll
-    for (int d = 0; d < 3; d++)
+        for (int d = 0; d < 3; d++)
 #pragma unroll
-      for (int e = 0; e < 3; e++) {
-        const HT v = (HT)R[d][e];
-        if (3 * d + e < 8) blk.v[3 * d + e] = v;
-        else last = v;
+          for (int e = 0; e < 3; e++)
+            T[3 * d + e] += Lp[12 * d + 3 * a2] * Hb[e] + Lp[12 * d + 3 * a2 + 1] * Hb[3 + e] + Lp[12 * d + 3 * a2 + 2] * Hb[6 + e];
       }
-    B8[off0 + k] = blk;
-    B1[off0 + k] = last;
+#pragma unroll
+      for (int v = 0; v < 9; v++) Ts[lane][v] = T[v];
+    }
+    wave_sync_s();
+    if (act) {
+      const double* Lq = Linv + (size_t)144 * q + 36 * b;
+      double R[9] = {};
+      for (int b2 = 0; b2 <= b; b2++) {
+        const double* Tb = Ts[(lane & ~3) | b2];
+#pragma unroll
+        for (int d = 0; d < 3; d++)
+#pragma unroll
+          for (int e = 0; e < 3; e++)
+            R[3 * d + e] += Tb[3 * d] * Lq[12 * e + 3 * b2] + Tb[3 * d + 1] * Lq[12 * e + 3 * b2 + 1] + Tb[3 * d + 2] * Lq[12 * e + 3 * b2 + 2];
+      }
+      Blk8<HT> blk;
+#pragma unroll
+      for (int v = 0; v < 8; v++) blk.v[v] = (HT)R[v];
+      B8[off0 + k] = blk;
+      B1[off0 + k] = (HT)R[8];
+    }
+    wave_sync_s();
   }
 }
 
-void launch_blk12_factor(hipStream_t s, int Np, const Incidence& inc, const double* Hval, double* Linv, double* sc,
-                         double* Dinv_s, int* err) {
-  hipLaunchKernelGGL(blk12_factor_kernel, dim3((Np + 63) / 64), dim3(64), 0, s, Np, inc, Hval, Linv, sc, Dinv_s, err);
+void launch_blk12_factor(hipStream_t s, int Np, const Incidence& inc, const double* Hval, double* Linv, float* Linv_f,
+                         double* sc, double* Dinv_s, int* err) {
+  hipLaunchKernelGGL(blk12_factor_kernel, dim3((Np + 63) / 64), dim3(64), 0, s, Np, inc, Hval, Linv, Linv_f, sc, Dinv_s, err);
 }
-void launch_blk12_apply(hipStream_t s, int Np, const double* Linv, bool transpose, const double* in, double* out) {
+void launch_blk12_apply(hipStream_t s, int Np, const float* Linv, bool transpose, const double* in, double* out) {
   const dim3 g((unsigned)(((size_t)12 * Np + 255) / 256)), b(256);
   if (transpose) hipLaunchKernelGGL(blk12_apply_kernel<true>, g, b, 0, s, Np, Linv, in, out);
   else hipLaunchKernelGGL(blk12_apply_kernel<false>, g, b, 0, s, Np, Linv, in, out);
 }
 void launch_lp_convert12(hipStream_t s, int N, const Incidence& inc, const double* Hval, const double* Linv, void* B8,
                          void* B1, int bits) {
-  const dim3 g((N + 7) / 8), b(256);
+  const dim3 g(N / 4), b(64);
   if (bits == 16)
-    hipLaunchKernelGGL(lp_convert12_kernel<_Float16>, g, b, 0, s, N, inc, Hval, Linv, (Blk8<_Float16>*)B8, (_Float16*)B1);
+    hipLaunchKernelGGL(lp_convert12_kernel<_Float16>, g, b, 0, s, N / 4, inc, Hval, Linv, (Blk8<_Float16>*)B8, (_Float16*)B1);
   else
-    hipLaunchKernelGGL(lp_convert12_kernel<float>, g, b, 0, s, N, inc, Hval, Linv, (Blk8<float>*)B8, (float*)B1);
+    hipLaunchKernelGGL(lp_convert12_kernel<float>, g, b, 0, s, N / 4, inc, Hval, Linv, (Blk8<float>*)B8, (float*)B1);
 }
 
 // sc_mask = own ? sc : 0 : scaling into / out of the polynomial that also drops the nodes another rank owns

@@ -1027,6 +1027,7 @@ struct tlfea_newton_s {
   // ANCF: 12 x 12 node-block scaling of the polynomial's operator (solver_kernels.hip, blk12_*): -1 not decided yet
   int blk12 = -1;
   double* d_L12inv = nullptr;
+  float* d_L12inv_f = nullptr;
   int* d_blk12_err = nullptr;
   int last_deg = 0, last_bits = 0;
   int h_nnz = 0;
@@ -1147,6 +1148,7 @@ extern "C" int tlfea_newton_destroy(tlfea_newton_t s) {
   for (int* p : s->d_rg4)
     if (p) (void)hipFree(p);
   if (s->d_L12inv) (void)hipFree(s->d_L12inv);
+  if (s->d_L12inv_f) (void)hipFree(s->d_L12inv_f);
   if (s->d_blk12_err) (void)hipFree(s->d_blk12_err);
   if (s->d_gvec) (void)hipFree(s->d_gvec);
   if (s->d_cmass) (void)hipFree(s->d_cmass);
@@ -2385,10 +2387,11 @@ static int lp_build(tlfea_newton_t s) {
   if (blk12_now(s)) {
     if (!s->d_L12inv) {
       HIP_TRY(hipMalloc((void**)&s->d_L12inv, (size_t)36 * s->N * sizeof(double)));  // 144 per node of 4 coefficient vectors
+      HIP_TRY(hipMalloc((void**)&s->d_L12inv_f, (size_t)36 * s->N * sizeof(float)));
       HIP_TRY(hipMalloc((void**)&s->d_blk12_err, sizeof(int)));
       HIP_TRY(hipMemsetAsync(s->d_blk12_err, 0, sizeof(int), s->stream));
     }
-    launch_blk12_factor(s->stream, s->N / 4, d->inc(), s->d_H, s->d_L12inv, s->d_sc, s->d_Dinv_s, s->d_blk12_err);
+    launch_blk12_factor(s->stream, s->N / 4, d->inc(), s->d_H, s->d_L12inv, s->d_L12inv_f, s->d_sc, s->d_Dinv_s, s->d_blk12_err);
     launch_lp_convert12(s->stream, s->N, d->inc(), s->d_H, s->d_L12inv, s->d_B8, s->d_B1, bits);
     launch_to_float(s->stream, (size_t)9 * s->N, s->d_Dinv_s, s->d_f32 + (size_t)18 * s->N);
     HIP_TRY(hipGetLastError());
@@ -2456,12 +2459,12 @@ static int estimate_lam_max(tlfea_newton_t s, const double* d_b) {
   const bool b12 = blk12_now(s);  // lambda_max of L^-1 H L^-T: v <- L^-1 H L^-T v
   for (int k = 0; k < iters; k++) {
     TRY(halo_refresh_f64(s, 0, 1, 3, s->d_eigv));
-    if (b12) launch_blk12_apply(s->stream, N / 4, s->d_L12inv, true, s->d_eigv, s->d_cd);
+    if (b12) launch_blk12_apply(s->stream, N / 4, s->d_L12inv_f, true, s->d_eigv, s->d_cd);
     const double* vv = b12 ? s->d_cd : s->d_eigv;
     launch_spmv_dir_dot(s->stream, Nr, d->inc(), s->d_H, vv, vv, 1, part(s, 1), part(s, 0), s->d_p2, s->d_q,
                         part(s, 2), false, s->spmv_nt);
     if (s->ar) TRY(iface_sum(s, s->d_q, 3));
-    if (b12) launch_blk12_apply(s->stream, N / 4, s->d_L12inv, false, s->d_q, s->d_eigv);
+    if (b12) launch_blk12_apply(s->stream, N / 4, s->d_L12inv_f, false, s->d_q, s->d_eigv);
     else launch_apply_dinv(s->stream, Nr, s->d_Dinv, s->d_q, s->d_eigv);
     TRY(device_sumsq_async(s, s->d_eigv, s->d_w, nr));
     launch_scale_inv_sqrt(s->stream, nr, s->d_scal, s->d_eigv);
@@ -3356,9 +3359,9 @@ static int enqueue_cg_iteration_impl(tlfea_newton_t s, double* d_x, bool first, 
     if (precond_eff(s) == 2)
       TRY(pmg_apply(s, s->d_r, s->d_zv, part(s, cur), fuse_init && !first));
     else if (b12) {  // z = L^-T p(L^-1 H L^-T) L^-1 r; the polynomial's r.z slots are r^.z^ = r.z
-      launch_blk12_apply(s->stream, N / 4, s->d_L12inv, false, s->d_r, s->d_cd);
+      launch_blk12_apply(s->stream, N / 4, s->d_L12inv_f, false, s->d_r, s->d_cd);
       TRY(cheb_apply(s, s->d_cd, s->d_cd2, part(s, cur), false));
-      launch_blk12_apply(s->stream, N / 4, s->d_L12inv, true, s->d_cd2, s->d_zv);
+      launch_blk12_apply(s->stream, N / 4, s->d_L12inv_f, true, s->d_cd2, s->d_zv);
     } else
       TRY(cheb_apply(s, s->d_r, s->d_zv, part(s, cur), fuse_init && !first));
     if ((s->ar && !(s->d_own && cheb_bits_eff(s) != 64)) || hal) TRY(parts_sum(s, part(s, cur)));

@@ -283,9 +283,9 @@ void launch_extract_diag(hipStream_t s, int N, const Incidence& inc, const doubl
 void launch_invert_diag(hipStream_t s, int N, const double* D, double* Dinv);
 
 // ANCF node-block (12 x 12) scaling of the polynomial's operator (solver_kernels.hip)
-void launch_blk12_factor(hipStream_t s, int Np, const Incidence& inc, const double* Hval, double* Linv, double* sc,
-                         double* Dinv_s, int* err);
-void launch_blk12_apply(hipStream_t s, int Np, const double* Linv, bool transpose, const double* in, double* out);
+void launch_blk12_factor(hipStream_t s, int Np, const Incidence& inc, const double* Hval, double* Linv, float* Linv_f,
+                         double* sc, double* Dinv_s, int* err);
+void launch_blk12_apply(hipStream_t s, int Np, const float* Linv_f, bool transpose, const double* in, double* out);
 void launch_lp_convert12(hipStream_t s, int N, const Incidence& inc, const double* Hval, const double* Linv, void* B8,
                          void* B1, int bits);
 
