@@ -3782,6 +3782,11 @@ static int pcg(tlfea_newton_t s, const double* d_b, double* d_x, int* iters_out,
   launch_sum_parts(s->stream, part(s, 4), s->d_scal + 1);
   double bb = 0.0;
   TRY(fetch_scalar(s, s->d_scal + 1, &bb));
+  if (lp && blk12_now(s)) {  // the stream is drained: the flag of this solve's node-block factorisation is final
+    int bad = 0;
+    HIP_TRY(hipMemcpy(&bad, s->d_blk12_err, sizeof(int), hipMemcpyDeviceToHost));
+    if (bad) return fail("a 12 x 12 node block of H is not positive definite (H is not SPD)");
+  }
   int it = 0;
   double rr = bb;
   if (bb > 0.0) {
