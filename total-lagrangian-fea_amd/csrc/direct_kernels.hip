@@ -4,15 +4,21 @@
 // A level of the dissection tree is a batch of independent dense fronts (column-major, lower triangle used) that live in
 // HBM / L2 (a T10 leaf front is ~400 DOF = 1.3 MB: no front fits the LDS).  Per level:
 //   zero the level's workspace -> scatter H's lower node blocks -> extend-add child 0, then child 1 (fixed order) ->
-//   panel steps of kMfNB = 48 columns over the fronts that still have columns:
-//     panel  : every workgroup re-factors the 48x48 diagonal block in LDS (one wavefront, left-looking: 1128 fused
-//              multiply-adds -- cheaper than a launch that would do it once) and solves its 256 rows of the panel against
-//              it, one row per lane held in registers (L21 = F21 L11^-T); the panel goes to the factor's storage
-//     update : F22 -= L21 L21^T on 64x64 tiles, 4x4 per lane from LDS-staged panels (fp64 vector FMA: the MI355X's fp64
-//              matrix rate equals its vector rate, so MFMA would buy nothing here)
+//   panel steps of kMfNB = 48 columns over the fronts that still have columns, grouped in SUPER-PANELS of 8:
+//     panel       : every workgroup re-factors the 48x48 diagonal block (one wavefront, a row per lane in registers,
+//                   the other rows by v_readlane: redundant per workgroup, cheaper than a launch that would do it once) and
+//                   solves its 256 rows of the panel against it, a row per lane in 48 registers (L21 = F21 L11^-T); the
+//                   panel goes to the factor's storage
+//     update      : inside the super-panel only its remaining columns are updated (64x64 tiles, 4x4 per lane)
+//     wide update : a completed super-panel (K up to 384) out of everything to its right, 128x128 tiles, 8x8 per lane, K
+//                   staged through LDS in chunks of 16 -- the trailing matrix is read and written once per 384 columns
+//                   (64-tiles where 128-tiles would not fill the chip).  fp64 vector FMA: the MI355X's fp64 matrix rate
+//                   equals its vector rate, so MFMA would buy nothing here
 //   what remains below/right of the own columns is the update matrix the parent adds into its front.
 // Solve: forward by levels (front vector = right-hand side of the own DOFs + the children's remainders, through the same
-// maps), backward from the root; one workgroup per front.  No atomics anywhere: same H, same bits.
+// maps), backward from the root; levels of small fronts one workgroup per front, levels with a large front panel step by
+// panel step over many workgroups (the 48x48 triangle from LDS; backward in outer-product form: no cross-workgroup sums).
+// No atomics anywhere: same H, same bits.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
