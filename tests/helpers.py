@@ -10,7 +10,9 @@ tl = importlib.import_module("total-lagrangian-fea_amd")
 MESHES = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "meshes")
 
 MESH_FILES = {"cube": "cube.1", "beam_3x2x1": "beam_3x2x1.1", "res2": "beam_3x2x1_res2.1",
-              "res4": "beam_3x2x1_res4.1", "bunny": "bunny_ascii_26.1"}
+              "res4": "beam_3x2x1_res4.1", "bunny": "bunny_ascii_26.1",
+              # the rest of SURVEY 8(d)'s real-mesh sanity set (reference data files: data/meshes/T10/resolution, teapot)
+              "res8": "beam_3x2x1_res8.1", "res16": "beam_3x2x1_res16.1", "teapot": "teapot.1"}
 
 
 def load_mesh(tag):
