@@ -286,15 +286,22 @@ __global__ __launch_bounds__(512) void mf_forward_kernel(const MfFrontDev* __res
     __syncthreads();
   }
   __shared__ double ys[NB];
+  __shared__ double T[NB][NB + 1];  // the block's triangle, staged by all lanes: read entry by entry from HBM / L2 inside
+                                    // the substitution's dependent chain it cost ~100 us per block
   for (int j0 = 0; j0 < k; j0 += NB) {
     const int jb = min(NB, k - j0);
+    for (int idx = tid; idx < NB * NB; idx += nt) {
+      const int r = idx % NB, c = idx / NB;
+      if (r < jb && c <= r) T[r][c] = L[(long long)(j0 + r) + (long long)(j0 + c) * m];
+    }
+    __syncthreads();
     if (tid < 64) {  // the block's triangle: one wavefront, lane r owns row r
       const int r = tid;
       double val = r < jb ? w[j0 + r] : 0.0;
       for (int c = 0; c < jb; c++) {
-        const double yc = __shfl(val, c) / L[(long long)(j0 + c) + (long long)(j0 + c) * m];
+        const double yc = __shfl(val, c) / T[c][c];
         if (r == c) val = yc;
-        else if (r > c && r < jb) val -= L[(long long)(j0 + r) + (long long)(j0 + c) * m] * yc;
+        else if (r > c && r < jb) val -= T[r][c] * yc;
       }
       if (r < jb) {
         ys[r] = val;
@@ -323,6 +330,7 @@ __global__ __launch_bounds__(512) void mf_backward_kernel(const MfFrontDev* __re
   for (int i = tid; i < m; i += nt) w[i] = i < k ? y[3LL * f.c0 + i] : xp[3LL * rows[f.rows_off + i / 3] + i % 3];
   __syncthreads();
   __shared__ double ys[NB];
+  __shared__ double T[NB][NB + 1];
   const int wave = tid >> 6, lane = tid & 63, nw = nt >> 6;
   for (int j0 = ((k - 1) / NB) * NB; j0 >= 0 && k > 0; j0 -= NB) {
     const int jb = min(NB, k - j0);
@@ -334,14 +342,18 @@ __global__ __launch_bounds__(512) void mf_backward_kernel(const MfFrontDev* __re
       for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
       if (lane == 0) ys[c] = w[j0 + c] - s;
     }
+    for (int idx = tid; idx < NB * NB; idx += nt) {
+      const int r = idx % NB, c = idx / NB;
+      if (r < jb && c <= r) T[r][c] = L[(long long)(j0 + r) + (long long)(j0 + c) * m];
+    }
     __syncthreads();
     if (tid < 64) {
       const int r = tid;
       double val = r < jb ? ys[r] : 0.0;
       for (int c = jb - 1; c >= 0; c--) {
-        const double xc = __shfl(val, c) / L[(long long)(j0 + c) + (long long)(j0 + c) * m];
+        const double xc = __shfl(val, c) / T[c][c];
         if (r == c) val = xc;
-        else if (r < c) val -= L[(long long)(j0 + c) + (long long)(j0 + r) * m] * xc;
+        else if (r < c) val -= T[c][r] * xc;
       }
       if (r < jb) w[j0 + r] = val;
     }
