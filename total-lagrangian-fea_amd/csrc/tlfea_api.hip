@@ -2605,13 +2605,24 @@ static int pmg_coarse_degree_eff(tlfea_newton_t s) {
   const int base = pmg_coarse_degree((dist_on(s) && s->pmg.Nc_glob > 0) ? s->pmg.Nc_glob : s->pmg.Nc);
   return std::min(kPmgMaxCoarseDeg, (int)std::lround(base * s->pmg.kc_boost));
 }
-static const double kPmgKappaS = std::getenv("TLFEA_PMG_KAPPA_S") ? std::atof(std::getenv("TLFEA_PMG_KAPPA_S")) : 8.0;
-// terms of the fine smoother's Chebyshev polynomial (TLFEA_PMG_KS; 2 = the measured optimum): pre- and post-smoothing
-// cost ks fine passes each (ks - 1 steps + the residual / restart pass)
+// terms of the fine smoother's Chebyshev polynomial (TLFEA_PMG_KS): pre- and post-smoothing cost ks fine passes each
+// (ks - 1 steps + the residual / restart pass).  Two regimes, measured: where the fine passes are what an iteration costs
+// (bandwidth regime: config C, 2 is the optimum, profiles/r03_sweep_fine_level.txt) and where every launch costs the same
+// few microseconds and the vertex-level polynomial's 10-60 launches dominate (meshes up to ~100 k nodes, the reference's
+// real meshes: 4 terms cut res16 from 7.9 to 6.4 ms and the badly graded teapot from 35.7 to 24.6 ms per Newton iteration,
+// profiles/r03_real_mesh_timing.txt).  The partitioned solve keeps 2 (the ghost depth it needs grows with ks).
 static const int kPmgMaxKs = 12;
 static int pmg_ks(tlfea_newton_t s) {
   static const int forced = std::getenv("TLFEA_PMG_KS") ? std::atoi(std::getenv("TLFEA_PMG_KS")) : 0;
-  return forced >= 1 ? std::min(forced, kPmgMaxKs) : 2;
+  if (forced >= 1) return std::min(forced, kPmgMaxKs);
+  return (!dist_on(s) && s->N <= 100000) ? 4 : 2;
+}
+// the smoother's interval [lmax / kappa_s, lmax]: 8 for two terms, 1.5 ks^2 beyond (TLFEA_PMG_KAPPA_S)
+static double pmg_kappa_s(tlfea_newton_t s) {
+  static const double forced = std::getenv("TLFEA_PMG_KAPPA_S") ? std::atof(std::getenv("TLFEA_PMG_KAPPA_S")) : 0.0;
+  if (forced > 1.0) return forced;
+  const int ks = pmg_ks(s);
+  return ks <= 2 ? 8.0 : 1.5 * ks * ks;
 }
 // coefficient table of the cycle (device doubles): [0 .. 2 ks) init + steps of the fine smoother, then the residual pass
 // (0, 0), the post-smoothing restart (0, 1/theta), then the coarse polynomial
@@ -3037,7 +3048,7 @@ static int pmg_coefficients(tlfea_newton_t s) {
   double* h = s->h_pin + 8;
   const int ks = pmg_ks(s);
   {
-    const double b = s->lam_safety * s->lam_max, a = b / kPmgKappaS;
+    const double b = s->lam_safety * s->lam_max, a = b / pmg_kappa_s(s);
     const double theta = 0.5 * (b + a), delta = 0.5 * (b - a), sigma = theta / delta;
     double rho = 1.0 / sigma;
     h[0] = 1.0 / theta; h[1] = 0.0;
