@@ -2615,7 +2615,8 @@ static const int kPmgMaxKs = 12;
 static int pmg_ks(tlfea_newton_t s) {
   static const int forced = std::getenv("TLFEA_PMG_KS") ? std::atoi(std::getenv("TLFEA_PMG_KS")) : 0;
   if (forced >= 1) return std::min(forced, kPmgMaxKs);
-  return (!dist_on(s) && s->N <= 100000) ? 4 : 2;
+  if (dist_on(s)) return 2;
+  return s->N <= 100000 ? 4 : (s->N <= 500000 ? 3 : 2);  // 3: M2 (172 k nodes) 10.4 -> 9.7 ms, M3 (402 k) 20.5 -> 19.9 ms; C keeps 2
 }
 // the smoother's interval [lmax / kappa_s, lmax]: 8 for two terms, 1.5 ks^2 beyond (TLFEA_PMG_KAPPA_S)
 static double pmg_kappa_s(tlfea_newton_t s) {

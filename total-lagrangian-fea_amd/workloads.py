@@ -13,6 +13,7 @@ CONFIGS = {
     "C2": dict(cells=(180, 60, 30), size=(6.0, 2.0, 1.0), material="svk", desc="T10 bar 180x60x30x6, SVK"),
     "M": dict(cells=(24, 16, 8), size=(3.0, 2.0, 1.0), material="svk", desc="medium bar (rehearsals)"),
     "M2": dict(cells=(45, 30, 15), size=(3.0, 2.0, 1.0), material="svk", desc="T10 bar 45x30x15x6, SVK"),
+    "M3": dict(cells=(60, 40, 20), size=(3.0, 2.0, 1.0), material="svk", desc="T10 bar 60x40x20x6, SVK"),
     "C4": dict(cells=(360, 60, 30), size=(12.0, 2.0, 1.0), material="svk", desc="T10 bar 360x60x30x6, SVK"),
     # ANCF configs (element counts instead of cells)
     "A": dict(kind=3243, n=(30,), dims=(0.5, 0.1, 0.1), material="svk_damped", desc="ANCF-3243 cantilever, 30 beams"),
