@@ -95,3 +95,37 @@ def test_plan_refuses_what_does_not_fit(shim):
     x, y, z = (np.ascontiguousarray(X[:, k]) for k in range(3))
     info = (C.c_longlong * 8)()
     assert shim.mf_build(N, ip(off), ip(cols), dp(x), dp(y), dp(z), 16, 1000, info) == 1
+
+
+def _solve_on_graph(shim, N, pairs, leaf, seed=1):
+    """SPD matrix on an arbitrary node graph (pairs of adjacent nodes), planned, factored and solved on the CPU"""
+    adj = [set([i]) for i in range(N)]
+    for a, b in pairs:
+        adj[a].add(b)
+        adj[b].add(a)
+    off = np.zeros(N + 1, dtype=np.int32)
+    off[1:] = np.cumsum([len(a) for a in adj])
+    cols = np.concatenate([np.array(sorted(a), dtype=np.int32) for a in adj])
+    rng = np.random.default_rng(seed)
+    X = rng.uniform(size=(N, 3))
+    x, y, z = (np.ascontiguousarray(X[:, k]) for k in range(3))
+    info = (C.c_longlong * 8)()
+    assert shim.mf_build(N, ip(off), ip(cols), dp(x), dp(y), dp(z), leaf, 1 << 40, info) == 0
+    vals, A = spd_in_engine_layout(N, off, cols, seed)
+    b = rng.normal(size=3 * N)
+    xo = np.zeros(3 * N)
+    assert shim.mf_cpu_factor_solve(dp(vals), dp(b), dp(xo)) == 0
+    assert np.linalg.norm(A @ xo - b) <= 1e-12 * np.linalg.norm(b)
+    return int(info[0]), int(info[1])
+
+
+def test_plan_edge_cases(shim):
+    """One node; a mesh smaller than a leaf (one front); a chain (every separator is one node); two disconnected components
+    (an empty separator at the root: a front without own columns); a complete graph (one dense front after all)."""
+    assert _solve_on_graph(shim, 1, [], 4) == (1, 1)
+    assert _solve_on_graph(shim, 7, [(i, i + 1) for i in range(6)], 32) == (1, 1)
+    nf, nl = _solve_on_graph(shim, 200, [(i, i + 1) for i in range(199)], 4)
+    assert nf > 30 and nl > 4
+    comp = [(i, i + 1) for i in range(39)] + [(40 + i, 41 + i) for i in range(39)]       # nodes 0..39 and 40..79
+    assert _solve_on_graph(shim, 80, comp, 8)[0] > 5
+    assert _solve_on_graph(shim, 24, [(i, j) for i in range(24) for j in range(i)], 4)[0] >= 1

@@ -106,6 +106,29 @@ def test_direct_large_front_config_b():
     d.Destroy()
 
 
+def test_direct_two_disconnected_bodies():
+    """Two bodies in one mesh (the MeshManager case): the dissection's root separator is EMPTY -- a front without own
+    columns, whose update matrix is just its children's -- and the solve must still equal the iterative one."""
+    Xa, ca = tl.mesh_utils.structured_t10_box(3, 3, 4)
+    Xb, cb = tl.mesh_utils.structured_t10_box(4, 2, 3)
+    X = np.vstack([Xa, Xb + np.array([5.0, 0.0, 0.0])])
+    conn = np.vstack([ca, cb + Xa.shape[0]]).astype(np.int32)
+    fixed = np.where(X[:, 2] < 1e-12)[0].astype(np.int32)
+    d = make_gpu(X, conn, MATERIALS["svk"], fixed)
+    s = tl.SyncedNewtonSolver(d, d.get_n_constraint())
+    s.SetParameters(tl.SyncedNewtonParams(1e-4, 1e-6, 1e-4, 1e14, 5, 10, 1e-3))
+    s.AssembleHessian()
+    b = np.random.default_rng(5).normal(size=3 * X.shape[0])
+    s.SetLinSolveOpts(tl.LinSolveOpts(method=1))
+    xd, it_d, rel_d = s.LinearSolve(b)
+    assert it_d == 1 and rel_d < 1e-10
+    s.SetLinSolveOpts(tl.LinSolveOpts(1e-13, 20000, 10, precond=1))
+    xi, _, _ = s.LinearSolve(b)
+    assert np.linalg.norm(xd - xi) <= 1e-7 * np.linalg.norm(xi)
+    del s
+    d.Destroy()
+
+
 def test_direct_reports_indefinite_matrix():
     """A pivot that is not positive fails the call with a message (cuDSS reports the same through its info query)."""
     X, conn = load_mesh("res2")
