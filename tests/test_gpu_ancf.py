@@ -195,6 +195,31 @@ def test_newton_steps(pname, steps):
     d.Destroy()
 
 
+def test_newton_steps_with_the_3x3_scaling_in_its_own_process():
+    """TLFEA_ANCF_BLOCK12=0 (read once per process: hence a child) keeps the polynomial on the 3 x 3 scaled operator -- the
+    form a mesh gets whose constraint rows break the 4 x 4 block groups; same steps, same parity."""
+    import subprocess
+    import sys
+    code = (
+        "import numpy as np\n"
+        "from oracle import orc\n"
+        "import tests.test_gpu_ancf as t\n"
+        "o, d = t.make_pair(t.PROBLEMS['plate3443'](), t.SVK_D)\n"
+        "s = t.tl.SyncedNewtonSolver(d, d.get_n_constraint())\n"
+        "s.Setup(); s.SetParameters(t.tl.SyncedNewtonParams(1e-4, 0.0, 1e-6, 1e14, 5, 10, 1e-3))\n"
+        "s.SetLinSolveOpts(t.tl.LinSolveOpts(1e-13, 50000, 10)); s.AnalyzeHessianSparsity()\n"
+        "X0 = np.stack([o.xt, o.yt, o.zt], axis=1)\n"
+        "s.Solve(); st_o = o.newton_step(orc.NewtonParams(1e-4, 0.0, 1e-6, 1e14, 5, 10, 1e-3)); st_g = s.GetStats()\n"
+        "xg = np.stack(d.RetrievePositionToCPU(), axis=1); xo = np.stack([o.x, o.y, o.z], axis=1)\n"
+        "assert t.disp_err_ok(xg, xo, X0), (st_g, st_o)\n"
+        "assert st_g['outer'] == st_o[0] and st_g['newton'] == st_o[1]\n"
+        "assert s.GetPolynomialInfo() == dict(degree=16, kappa=400, block=3), s.GetPolynomialInfo()\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, TLFEA_ANCF_BLOCK12="0"),
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+
+
 @pytest.mark.parametrize("pname,steps", [("beam3243", 2), ("plate3443", 1)])
 def test_newton_steps_with_the_direct_solver(pname, steps):
     """The same steps with the engine's multifrontal Cholesky as the linear solve (LinSolveOpts.method = 1; the reference's
