@@ -95,19 +95,52 @@ inline bool mf_plan_build(int N, const int* off, const int* cols, const double* 
         axis = a;
       }
     }
-    const size_t half = nodes.size() / 2;
+    size_t half = nodes.size() / 2;
     const double* c = xyz[axis];
     std::nth_element(nodes.begin(), nodes.begin() + half, nodes.end(),
                      [&](int a, int b) { return c[a] < c[b] || (c[a] == c[b] && a < b); });
+    {
+      // nodes that share the median coordinate (a plane of a structured mesh) go to ONE side -- a cut through the plane
+      // makes a staircase separator twice as large -- as long as the parts stay within 30 % / 70 %
+      const double cv = c[nodes[half]];
+      size_t nlt = 0, nle = 0;
+      for (int v : nodes) {
+        nlt += c[v] < cv;
+        nle += c[v] <= cv;
+      }
+      const size_t lo = (size_t)(0.3 * nodes.size()), hi = (size_t)(0.7 * nodes.size());
+      const size_t da = nlt > half ? nlt - half : half - nlt, db = nle > half ? nle - half : half - nle;
+      size_t pick = da <= db ? nlt : nle;
+      if (pick < lo || pick > hi) pick = (da <= db ? nle : nlt);
+      if (pick >= lo && pick <= hi && pick != half) {
+        const bool strict = pick == nlt;
+        std::partition(nodes.begin(), nodes.end(), [&](int v) { return strict ? c[v] < cv : c[v] <= cv; });
+        half = pick;
+      }
+    }
     const int sl = stamp++, sr = stamp++;
     for (size_t t = 0; t < nodes.size(); t++) mark[nodes[t]] = t < half ? sl : sr;
-    // vertex separator: the nodes of the right part that touch the left part
-    std::vector<int> left(nodes.begin(), nodes.begin() + half), right, sep;
-    for (size_t t = half; t < nodes.size(); t++) {
-      const int v = nodes[t];
-      bool touches = false;
-      for (int k = off[v]; k < off[v + 1] && !touches; k++) touches = mark[cols[k]] == sl;
-      (touches ? sep : right).push_back(v);
+    // vertex separator: the nodes of one part that touch the other part -- whichever side gives the smaller set
+    std::vector<int> left, right, sep;
+    {
+      size_t nr = 0, nl_ = 0;
+      for (size_t t = 0; t < nodes.size(); t++) {
+        const int v = nodes[t], other = t < half ? sr : sl;
+        bool touches = false;
+        for (int k = off[v]; k < off[v + 1] && !touches; k++) touches = mark[cols[k]] == other;
+        if (touches) (t < half ? nl_ : nr)++;
+      }
+      const bool from_right = nr <= nl_;
+      for (size_t t = 0; t < nodes.size(); t++) {
+        const int v = nodes[t];
+        const bool in_left = t < half;
+        bool touches = false;
+        if (in_left != from_right) {
+          const int other = in_left ? sr : sl;
+          for (int k = off[v]; k < off[v + 1] && !touches; k++) touches = mark[cols[k]] == other;
+        }
+        (touches ? sep : (in_left ? left : right)).push_back(v);
+      }
     }
     std::vector<int>().swap(nodes);
     std::sort(sep.begin(), sep.end());
