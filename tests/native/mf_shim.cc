@@ -15,10 +15,10 @@ extern "C" int mf_build(int N, const int* off, const int* cols, const double* x,
   info[0] = (long long)g_p.fronts.size();
   info[1] = g_p.n_levels();
   info[2] = g_p.L_total;
-  info[3] = g_p.F_cap[0];
-  info[4] = g_p.F_cap[1];
+  info[3] = g_p.F_cap[0] + g_p.F_cap[1];
+  info[4] = g_p.F_cap[2] + g_p.F_cap[3];
   info[5] = g_p.flops;
-  info[6] = (long long)g_p.steps.size();
+  info[6] = (long long)g_p.bsteps.size();
   info[7] = (long long)g_p.h_src.size();
   return 0;
 }
@@ -37,33 +37,31 @@ extern "C" void mf_fetch(int* order, int* front_c0, int* front_c1, int* front_pa
 extern "C" int mf_cpu_factor_solve(const double* H, const double* b, double* xout) {
   using namespace tlfea;
   const MfPlan& P = g_p;
-  std::vector<double> L((size_t)P.L_total, 0.0), Fb[2];
-  Fb[0].assign((size_t)P.F_cap[0], 0.0);
-  Fb[1].assign((size_t)P.F_cap[1], 0.0);
-  const int nl = P.n_levels();
-  auto parity = [&](int l) { return (nl - 1 - l) & 1; };  // depth of level l = nl - 1 - l
-  for (int l = 0; l < nl; l++) {
-    std::vector<double>& W = Fb[parity(l)];
-    std::fill(W.begin(), W.begin() + P.level_F[l], 0.0);
-    for (int t = P.hent_off[l]; t < P.hent_off[l + 1]; t++)
+  std::vector<double> L((size_t)P.L_total, 0.0), Fb[4];
+  for (int t = 0; t < 4; t++) Fb[t].assign((size_t)P.F_cap[t], 0.0);
+  for (const MfBatch& B : P.batches) {
+    std::vector<double>& W = Fb[B.wbuf];
+    const std::vector<double>& Wc = Fb[B.cbuf];
+    std::fill(W.begin() + B.F_base, W.begin() + B.F_base + B.F_doubles, 0.0);
+    for (int t = B.hent_off; t < B.hent_off + B.hent_count; t++)
       for (int d = 0; d < 3; d++)
         for (int e = 0; e < 3; e++)
           W[(size_t)(P.h_dst[t] + d + (long long)e * P.h_dld[t])] = H[P.h_src[t] + (long long)d * P.h_sld[t] + e];
-    for (int t = P.level_off[l]; t < P.level_off[l + 1]; t++) {
-      const MfFront& F = P.fronts[P.level_fronts[t]];
+    for (int t = B.first; t < B.first + B.count; t++) {
+      const MfFront& F = P.fronts[P.batch_fronts[t]];
       const long long m = 3LL * F.nrows, k = 3LL * (F.c1 - F.c0);
       double* A = W.data() + F.F_off;
       for (int s = 0; s < 2; s++) {
         if (F.child[s] < 0) continue;
         const MfFront& C = P.fronts[F.child[s]];
         const long long mc = 3LL * C.nrows, kc = 3LL * (C.c1 - C.c0);
-        const double* U = Fb[1 - parity(l)].data() + C.F_off;
+        const double* U = Wc.data() + C.cF_off;
         const int* mp = P.map.data() + C.map_off;
         for (long long j = 0; j < mc - kc; j++)
           for (long long i = j; i < mc - kc; i++) {
             const long long pi = 3LL * mp[i / 3] + i % 3, pj = 3LL * mp[j / 3] + j % 3;
             if (pi < pj) return 3;
-            A[pi + pj * m] += U[(kc + i) + (kc + j) * mc];
+            A[pi + pj * m] += U[(C.c_k0 + i) + (C.c_k0 + j) * (long long)C.c_ld];
           }
       }
       for (long long j = 0; j < k; j++) {
@@ -80,8 +78,12 @@ extern "C" int mf_cpu_factor_solve(const double* H, const double* b, double* xou
       }
       for (long long j = 0; j < k; j++)
         for (long long i = j; i < m; i++) L[(size_t)(F.L_off + i + j * m)] = A[i + j * m];
+      if (B.push)  // the update matrix goes onto the stack (over its children's, which are consumed)
+        for (long long j = 0; j < m - k; j++)
+          for (long long i = j; i < m - k; i++) Fb[3][(size_t)(F.cF_off + i + j * (m - k))] = A[(k + i) + (k + j) * m];
     }
   }
+  const int nl = P.n_levels();
   // forward: front vectors, children before parents
   const int n = 3 * P.N;
   std::vector<double> v((size_t)P.v_total, 0.0), y((size_t)n), xp((size_t)n);

@@ -85,6 +85,17 @@ def test_plan_factors_and_solves(shim, mesh, leaf):
     ref = spla.spsolve(A, b)
     assert np.linalg.norm(xo - ref) <= 1e-12 * np.linalg.norm(ref)
     assert np.linalg.norm(A @ xo - b) <= 1e-13 * np.linalg.norm(b)
+    # a memory bound that the whole-level workspaces exceed: the tree is cut into subtrees that reuse their workspaces
+    # (what lets config C's 118 GB factor fit next to its fronts); same ordering, same factor, same solution
+    L, ws = int(info[2]), int(info[3]) + int(info[4])
+    info2 = (C.c_longlong * 8)()
+    for frac in (0.75, 0.5, 0.35):
+        if shim.mf_build(N, ip(off), ip(cols), dp(x), dp(y), dp(z), leaf, L + int(frac * ws), info2) != 0:
+            continue
+        assert int(info2[2]) == L and int(info2[3]) + int(info2[4]) <= frac * ws and int(info2[4]) > 0
+        x2 = np.zeros(3 * N)
+        assert shim.mf_cpu_factor_solve(dp(vals), dp(b), dp(x2)) == 0
+        assert np.linalg.norm(x2 - xo) <= 1e-13 * np.linalg.norm(xo)
 
 
 def test_plan_refuses_what_does_not_fit(shim):

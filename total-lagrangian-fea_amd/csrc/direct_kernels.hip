@@ -65,13 +65,24 @@ __global__ __launch_bounds__(256) void mf_extend_add_kernel(const MfFrontDev* __
   const int i = blockIdx.x * 16 + (threadIdx.x & 15), j = blockIdx.y * 16 + (threadIdx.x >> 4);
   if (i >= mu || j > i) return;
   const int* mp = map + ch.map_off;
-  const double* U = Wc + ch.F_off + (ch.k + 3 * i) + (long long)(ch.k + 3 * j) * ch.m;
+  const double* U = Wc + ch.cF_off + (ch.c_k0 + 3 * i) + (long long)(ch.c_k0 + 3 * j) * ch.c_ld;
   double* A = Wp + f.F_off + 3LL * mp[i] + 3LL * mp[j] * f.m;
 #pragma unroll
   for (int e = 0; e < 3; e++)
 #pragma unroll
     for (int d = 0; d < 3; d++)
-      if (i > j || d >= e) A[d + (long long)e * f.m] += U[d + (long long)e * ch.m];
+      if (i > j || d >= e) A[d + (long long)e * f.m] += U[d + (long long)e * ch.c_ld];
+}
+
+// a front factored in the WORK buffer: its update matrix (lower triangle) compacted onto the stack for the parent
+__global__ __launch_bounds__(256) void mf_push_kernel(const MfFrontDev* __restrict__ fr, int front,
+                                                     const double* __restrict__ Wk, double* __restrict__ St) {
+  const MfFrontDev f = fr[front];
+  const int mu = f.m - f.k;
+  const int i = blockIdx.x * 64 + (threadIdx.x & 63), j0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * 16;
+  if (i >= mu) return;
+  for (int j = j0; j < min(j0 + 16, mu); j++)
+    if (j <= i) St[f.cF_off + i + (long long)j * mu] = Wk[f.F_off + (f.k + i) + (long long)(f.k + j) * f.m];
 }
 
 __global__ __launch_bounds__(256) void mf_panel_kernel(const MfFrontDev* __restrict__ fr, const int* __restrict__ lvl, int j0,
@@ -501,27 +512,24 @@ __global__ void mf_unpermute_kernel(int N, const int* __restrict__ order, const 
 
 // numeric factorisation of the H whose values are at `H` (the engine's layout); err is set when a pivot is not positive
 void launch_mf_factor(hipStream_t s, const MfPlan& P, const MfDev& D, const double* H) {
-  const int nl = P.n_levels();
   // super-panel: the trailing matrix is updated once per KS columns (a multiple of the panel width)
   static const int KS = NB * std::max(1, std::getenv("TLFEA_DIRECT_SUPER") ? std::atoi(std::getenv("TLFEA_DIRECT_SUPER")) : 8);
   (void)hipMemsetAsync(D.err, 0, sizeof(int), s);
-  for (int l = 0; l < nl; l++) {
-    const int par = (nl - 1 - l) & 1;
-    double* W = D.F[par];
-    const double* Wc = D.F[1 - par];
-    const int* lvl = D.lvl + P.level_off[l];
-    const int nfl = P.level_off[l + 1] - P.level_off[l];
-    (void)hipMemsetAsync(W, 0, (size_t)P.level_F[l] * sizeof(double), s);
-    const int ne = P.hent_off[l + 1] - P.hent_off[l];
-    if (ne > 0) {
-      const long long th = 9LL * ne;
-      hipLaunchKernelGGL(mf_scatter_h_kernel, dim3((unsigned)((th + 255) / 256)), dim3(256), 0, s, ne,
-                         D.hsrc + P.hent_off[l], D.hsld + P.hent_off[l], D.hdst + P.hent_off[l], D.hdld + P.hent_off[l], H, W);
+  for (const MfBatch& B : P.batches) {  // level batches, then (large problems) the top fronts one by one (mf_host.h)
+    double* W = D.F[B.wbuf];
+    const double* Wc = D.F[B.cbuf];
+    const int* lvl = D.blvl + B.first;
+    const int nfl = B.count;
+    (void)hipMemsetAsync(W + B.F_base, 0, (size_t)B.F_doubles * sizeof(double), s);
+    if (B.hent_count > 0) {
+      const long long th = 9LL * B.hent_count;
+      hipLaunchKernelGGL(mf_scatter_h_kernel, dim3((unsigned)((th + 255) / 256)), dim3(256), 0, s, B.hent_count,
+                         D.hsrc + B.hent_off, D.hsld + B.hent_off, D.hdst + B.hent_off, D.hdld + B.hent_off, H, W);
     }
     for (int slot = 0; slot < 2; slot++) {
       int mu = 0;
       for (int t = 0; t < nfl; t++) {
-        const MfFront& F = P.fronts[P.level_fronts[(size_t)P.level_off[l] + t]];
+        const MfFront& F = P.fronts[P.batch_fronts[(size_t)B.first + t]];
         if (F.child[slot] >= 0) {
           const MfFront& C = P.fronts[F.child[slot]];
           mu = std::max(mu, C.nrows - (C.c1 - C.c0));
@@ -533,8 +541,8 @@ void launch_mf_factor(hipStream_t s, const MfPlan& P, const MfDev& D, const doub
         hipLaunchKernelGGL(mf_extend_add_kernel, dim3(g, g, (unsigned)std::min(32768, nfl - z0)), dim3(256), 0, s, D.fr,
                            lvl + z0, slot, W, Wc, D.map);
     }
-    for (int t = P.step_off[l]; t < P.step_off[l + 1]; t++) {
-      const MfLevelStep& st = P.steps[t];
+    for (int t = B.step_off; t < B.step_off + B.step_count; t++) {
+      const MfLevelStep& st = P.bsteps[t];
       const int S0 = (st.j0 / KS) * KS, s1 = S0 + KS;
       const unsigned rt = (unsigned)std::max(1, (st.max_below + 255) / 256), ut = (unsigned)((st.max_below + 63) / 64);
       const unsigned ct = (unsigned)((s1 - st.j0 - NB + 63) / 64 + 1);  // column tiles left in the super-panel
@@ -545,11 +553,11 @@ void launch_mf_factor(hipStream_t s, const MfPlan& P, const MfDev& D, const doub
           hipLaunchKernelGGL(mf_update_kernel, dim3(ut, std::min(ut, ct), nz), dim3(256), 0, s, D.fr, lvl + z0, st.j0, s1, 0,
                              W, D.L);
       }
-      if (st.j0 + NB >= s1 || t + 1 == P.step_off[l + 1]) {  // the super-panel is complete: take it out of the rest
-        const MfLevelStep& s0 = P.steps[P.step_off[l] + S0 / NB];
+      if (st.j0 + NB >= s1 || t + 1 == B.step_off + B.step_count) {  // the super-panel is complete: take it out of the rest
+        const MfLevelStep& s0 = P.bsteps[B.step_off + S0 / NB];
         int below = 0;
         for (int q = 0; q < s0.n_active; q++) {
-          const MfFront& F = P.fronts[P.level_fronts[(size_t)P.level_off[l] + q]];
+          const MfFront& F = P.fronts[P.batch_fronts[(size_t)B.first + q]];
           below = std::max(below, 3 * F.nrows - std::min(s1, 3 * (F.c1 - F.c0)));
         }
         const unsigned wt = (unsigned)((below + WT - 1) / WT), wt64 = (unsigned)((below + 63) / 64);
@@ -564,6 +572,13 @@ void launch_mf_factor(hipStream_t s, const MfPlan& P, const MfDev& D, const doub
               hipLaunchKernelGGL(mf_update_kernel, dim3(wt64, wt64, nz), dim3(256), 0, s, D.fr, lvl + z0, S0, s1, 1, W, D.L);
           }
       }
+    }
+    if (B.push) {
+      const MfFront& F = P.fronts[P.batch_fronts[(size_t)B.first]];
+      const int mu = 3 * (F.nrows - (F.c1 - F.c0));
+      if (mu > 0)
+        hipLaunchKernelGGL(mf_push_kernel, dim3((unsigned)((mu + 63) / 64), (unsigned)((mu + 63) / 64)), dim3(256), 0, s, D.fr,
+                           P.batch_fronts[(size_t)B.first], W, D.F[3]);
     }
   }
 }

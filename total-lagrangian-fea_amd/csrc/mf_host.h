@@ -18,6 +18,8 @@
 #pragma once
 #include <algorithm>
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 #include <functional>
 #include <vector>
 
@@ -33,14 +35,33 @@ struct MfFront {
   long long row_off = 0;         // rows[row_off .. + nrows): new positions, ascending
   long long map_off = 0;         // map[map_off .. + nrows - (c1 - c0)): row index inside the parent's front
   long long L_off = 0;           // doubles: panel (3 nrows) x (3 (c1 - c0)), column-major
-  long long F_off = 0;           // doubles inside the workspace of depth parity (depth & 1): (3 nrows)^2, column-major
+  long long F_off = 0;           // doubles inside the workspace it is factored in: (3 nrows)^2, column-major
   long long v_off = 0;           // doubles inside the solve's front vectors: 3 nrows
+  // where the PARENT reads this front's update matrix: the front itself (c_ld = 3 nrows, c_k0 = own DOFs) or its compact
+  // copy on the stack (c_ld = rows below the own DOFs, c_k0 = 0)
+  long long cF_off = 0;
+  int c_ld = 0, c_k0 = 0;
 };
 
-struct MfLevelStep {  // one panel step of a level: fronts [0, n_active) of the level's list still have columns at j0
+struct MfLevelStep {  // one panel step of a batch / level: fronts [0, n_active) of its list still have columns at j0
   int j0, n_active, max_below;  // max_below: largest number of DOF rows below the panel among them
 };
 
+// The factorisation walks BATCHES: fronts that are assembled and factored together.  Fronts deeper than `top_depth` are
+// taken level by level (all fronts of one depth under one depth-`top_depth` ancestor: buffers 0 / 1 by depth parity, reused
+// from subtree to subtree); fronts of depth <= top_depth one by one in postorder in the WORK buffer (2), their update
+// matrices compacted onto a STACK (3) until the parent is assembled -- the classical multifrontal stack, so that the
+// workspaces are a few of the largest fronts instead of whole levels of them (config C: 156 GB of whole-level workspaces
+// next to a 118 GB factor).  top_depth = -1: every batch a whole level (everything that fits is done that way: fewest
+// launches).
+struct MfBatch {
+  int depth, first, count;      // fronts batch_fronts[first .. first + count), most own columns first
+  int step_off, step_count;     // bsteps[...]
+  int hent_off, hent_count;     // entries of h_src / h_dst / ...
+  int wbuf, cbuf;               // workspace the batch is factored in / the one its children's update matrices are read from
+  long long F_base, F_doubles;  // the part of workspace wbuf this batch zeroes before assembling
+  int push;                     // 1: a single front whose update matrix goes onto the stack afterwards
+};
 struct MfPlan {
   int N = 0;
   std::vector<int> order, inv;          // new -> old node, old -> new
@@ -48,15 +69,18 @@ struct MfPlan {
   std::vector<int> rows, map;
   std::vector<int> level_off;           // [n_levels + 1] into level_fronts; level 0 = deepest
   std::vector<int> level_fronts;        // fronts of a level, most own columns first
-  std::vector<int> step_off;            // [n_levels + 1] into steps
+  std::vector<int> step_off;            // [n_levels + 1] into steps (the SOLVE walks whole levels)
   std::vector<MfLevelStep> steps;
-  std::vector<long long> level_F;       // doubles of front workspace a level needs
-  // H -> fronts: one entry per lower node block of the permuted matrix (level order)
-  std::vector<int> hent_off;            // [n_levels + 1]
-  std::vector<long long> h_src, h_dst;  // first double of the 3x3 block in H's values / in the level's workspace
+  int top_depth = -1;                   // fronts of depth <= top_depth: one by one, postorder (see MfBatch)
+  std::vector<MfBatch> batches;         // the factorisation's order
+  std::vector<int> batch_fronts;
+  std::vector<MfLevelStep> bsteps;
+  // H -> fronts: one entry per lower node block of the permuted matrix (batch order)
+  std::vector<long long> h_src, h_dst;  // first double of the 3x3 block in H's values / in the front's workspace buffer
   std::vector<int> h_sld, h_dld;        // leading dimensions (H: row stride 3 deg, front: 3 nrows)
-  long long L_total = 0, F_cap[2] = {0, 0}, v_total = 0, flops = 0;
+  long long L_total = 0, F_cap[4] = {0, 0, 0, 0}, v_total = 0, flops = 0;  // F_cap: level buffers 0 / 1, WORK, STACK
   int n_levels() const { return (int)level_off.size() - 1; }
+  long long F_total() const { return F_cap[0] + F_cap[1] + F_cap[2] + F_cap[3]; }
 };
 
 // off/cols: node adjacency (sorted columns, diagonal included), x/y/z: coordinates of the N nodes; leaf: nodes below
@@ -223,21 +247,32 @@ inline bool mf_plan_build(int N, const int* off, const int* cols, const double* 
     std::vector<int> w(P.level_off.begin(), P.level_off.end() - 1);
     for (int f = 0; f < nf; f++) P.level_fronts[(size_t)w[maxd - P.fronts[f].depth]++] = f;
   }
-  P.level_F.assign((size_t)nl, 0);
   P.step_off.assign((size_t)nl + 1, 0);
-  for (int l = 0; l < nl; l++) {
+  auto by_columns = [&](int a, int c) {
+    const int ka = P.fronts[a].c1 - P.fronts[a].c0, kc = P.fronts[c].c1 - P.fronts[c].c0;
+    return ka > kc || (ka == kc && a < c);
+  };
+  auto push_steps = [&](const int* b, const int* e, std::vector<MfLevelStep>& out) {
+    const int kmax = b == e ? 0 : 3 * (P.fronts[*b].c1 - P.fronts[*b].c0);
+    for (int j0 = 0; j0 < kmax; j0 += kMfNB) {
+      MfLevelStep st{j0, 0, 0};
+      for (const int* it = b; it != e; ++it) {
+        const MfFront& F = P.fronts[*it];
+        const int k = 3 * (F.c1 - F.c0), m = 3 * F.nrows;
+        if (k <= j0) break;
+        st.n_active++;
+        st.max_below = std::max(st.max_below, m - j0 - std::min(kMfNB, k - j0));
+      }
+      out.push_back(st);
+    }
+  };
+  for (int l = 0; l < nl; l++) {  // levels: factor / vector storage and the solve's step lists
     int* b = P.level_fronts.data() + P.level_off[l];
     int* e = P.level_fronts.data() + P.level_off[l + 1];
-    std::sort(b, e, [&](int a, int c) {
-      const int ka = P.fronts[a].c1 - P.fronts[a].c0, kc = P.fronts[c].c1 - P.fronts[c].c0;
-      return ka > kc || (ka == kc && a < c);
-    });
-    long long fo = 0;
+    std::sort(b, e, by_columns);
     for (int* it = b; it != e; ++it) {
       MfFront& F = P.fronts[*it];
       const long long m = 3LL * F.nrows, k = 3LL * (F.c1 - F.c0);
-      F.F_off = fo;
-      fo += m * m;
       F.L_off = P.L_total;
       P.L_total += m * k;
       F.v_off = P.v_total;
@@ -245,29 +280,104 @@ inline bool mf_plan_build(int N, const int* off, const int* cols, const double* 
       P.flops += k * k * k / 3 + (m - k) * k * k + (m - k) * (m - k) * k;
       if (P.L_total > max_doubles) return false;
     }
-    P.level_F[l] = fo;
-    const int par = (maxd - l) & 1;
-    P.F_cap[par] = std::max(P.F_cap[par], fo);
-    const int kmax = b == e ? 0 : 3 * (P.fronts[*b].c1 - P.fronts[*b].c0);
-    for (int j0 = 0; j0 < kmax; j0 += kMfNB) {
-      MfLevelStep st{j0, 0, 0};
-      for (int* it = b; it != e; ++it) {
-        const MfFront& F = P.fronts[*it];
-        const int k = 3 * (F.c1 - F.c0), m = 3 * F.nrows;
-        if (k <= j0) break;
-        st.n_active++;
-        st.max_below = std::max(st.max_below, m - j0 - std::min(kMfNB, k - j0));
-      }
-      P.steps.push_back(st);
-    }
+    push_steps(b, e, P.steps);
     P.step_off[l + 1] = (int)P.steps.size();
   }
-  if (P.L_total + P.F_cap[0] + P.F_cap[1] > max_doubles) return false;
-  // ---- H's lower node blocks -> front entries --------------------------------------------------------------------------
-  P.hent_off.assign((size_t)nl + 1, 0);
-  for (int l = 0; l < nl; l++) {
-    for (int t = P.level_off[l]; t < P.level_off[l + 1]; t++) {
-      const MfFront& F = P.fronts[P.level_fronts[t]];
+  // ---- batches ----------------------------------------------------------------------------------------------------------
+  std::vector<long long> msq((size_t)nf), usq((size_t)nf);
+  for (int f = 0; f < nf; f++) {
+    const MfFront& F = P.fronts[f];
+    msq[f] = 9LL * F.nrows * F.nrows;
+    usq[f] = 9LL * (F.nrows - (F.c1 - F.c0)) * (F.nrows - (F.c1 - F.c0));
+  }
+  // workspaces for a given top depth T: level buffers = the largest level of any subtree hanging below depth T (T = -1: of
+  // the whole tree), WORK = the largest front of depth <= T, STACK = peak of the postorder walk over those fronts
+  std::vector<int> anc((size_t)nf, -1);
+  auto workspace = [&](int T, long long cap[4]) {
+    cap[0] = cap[1] = cap[2] = cap[3] = 0;
+    for (int f = nf - 1; f >= 0; f--) {
+      const int d = P.fronts[f].depth;
+      anc[f] = d <= T ? -1 : (d == T + 1 ? (T < 0 ? 0 : P.fronts[f].parent) : anc[P.fronts[f].parent]);
+    }
+    std::vector<int> slot((size_t)nf, -1);
+    std::vector<std::vector<long long>> deep;
+    for (int f = 0; f < nf; f++) {
+      const int d = P.fronts[f].depth;
+      if (d <= T) {
+        cap[2] = std::max(cap[2], msq[f]);
+        continue;
+      }
+      int& sl = slot[anc[f] < 0 ? 0 : anc[f]];
+      if (sl < 0) {
+        sl = (int)deep.size();
+        deep.emplace_back((size_t)nl, 0);
+      }
+      deep[sl][d] += msq[f];
+    }
+    for (const auto& v : deep)
+      for (int d = 0; d < nl; d++) cap[d & 1] = std::max(cap[d & 1], v[d]);
+    // stack: postorder over the fronts of depth <= T (children before parents in index order IS a postorder)
+    long long sp = 0;
+    std::vector<long long> at((size_t)nf, 0);
+    for (int f = 0; f < nf; f++) {
+      const MfFront& F = P.fronts[f];
+      if (F.depth > T) continue;
+      long long base = sp;
+      if (F.depth < T)
+        for (int c : F.child)
+          if (c >= 0) base = std::min(base, at[c]);
+      at[f] = base;
+      sp = base + (F.parent >= 0 ? usq[f] : 0);
+      cap[3] = std::max(cap[3], std::max(sp, base));
+      // while f is factored its children's matrices are still on the stack: the peak is before the pop
+      long long before = base;
+      if (F.depth < T)
+        for (int c : F.child)
+          if (c >= 0) before = std::max(before, at[c] + usq[c]);
+      cap[3] = std::max(cap[3], before);
+    }
+    return cap[0] + cap[1] + cap[2] + cap[3];
+  };
+  {
+    long long cap[4];
+    int T = -1;
+    if (std::getenv("TLFEA_MF_DEBUG"))
+      for (int c = -1; c <= maxd; c++) {
+        const long long w = workspace(c, cap);
+        std::fprintf(stderr, "top depth %d: workspace %.4g (levels %.4g %.4g, work %.4g, stack %.4g)\n", c, (double)w, (double)cap[0],
+                     (double)cap[1], (double)cap[2], (double)cap[3]);
+      }
+    static const int forced = std::getenv("TLFEA_DIRECT_TOP_DEPTH") ? std::atoi(std::getenv("TLFEA_DIRECT_TOP_DEPTH")) : -2;
+    if (forced >= -1) T = std::min(forced, maxd);
+    else
+      while (T < maxd && P.L_total + workspace(T, cap) > max_doubles) T++;
+    if (P.L_total + workspace(T, cap) > max_doubles) return false;
+    P.top_depth = T;
+    for (int t = 0; t < 4; t++) P.F_cap[t] = cap[t];
+  }
+  bool entries_ok = true;
+  auto emit = [&](int depth, std::vector<int>& fl, int wbuf, int cbuf, long long base, int push) {
+    if (fl.empty()) return;
+    std::sort(fl.begin(), fl.end(), by_columns);
+    MfBatch B{depth, (int)P.batch_fronts.size(), (int)fl.size(), (int)P.bsteps.size(), 0, (int)P.h_src.size(), 0, wbuf, cbuf, base, 0,
+              push};
+    long long fo = base;
+    for (int f : fl) {
+      MfFront& F = P.fronts[f];
+      F.F_off = fo;
+      fo += msq[f];
+      if (!push) {  // the parent reads the front where it was factored
+        F.cF_off = F.F_off;
+        F.c_ld = 3 * F.nrows;
+        F.c_k0 = 3 * (F.c1 - F.c0);
+      }
+      P.batch_fronts.push_back(f);
+    }
+    B.F_doubles = fo - base;
+    push_steps(fl.data(), fl.data() + fl.size(), P.bsteps);
+    B.step_count = (int)P.bsteps.size() - B.step_off;
+    for (int f : fl) {
+      const MfFront& F = P.fronts[f];
       const int* pr = P.rows.data() + F.row_off;
       const int ld = 3 * F.nrows;
       for (int p = F.c0; p < F.c1; p++) {
@@ -276,20 +386,60 @@ inline bool mf_plan_build(int N, const int* off, const int* cols, const double* 
           const int q = P.inv[cols[u]];
           if (q < p) continue;
           const int* it = std::lower_bound(pr, pr + F.nrows, q);
-          if (it == pr + F.nrows || *it != q) return false;
-          const int ri = (int)(it - pr), i = cols[u];
-          // block (row node i, column node c) of H: row i's values start at 9 off[i], row stride 3 deg(i)
+          const int i = cols[u];
           const int* ci = std::lower_bound(cols + off[i], cols + off[i + 1], c);
-          if (ci == cols + off[i + 1] || *ci != c) return false;  // pattern not symmetric
+          if (it == pr + F.nrows || *it != q || ci == cols + off[i + 1] || *ci != c) {
+            entries_ok = false;  // pattern not symmetric
+            continue;
+          }
+          // block (row node i, column node c) of H: row i's values start at 9 off[i], row stride 3 deg(i)
           P.h_src.push_back(9LL * off[i] + 3LL * (ci - (cols + off[i])));
           P.h_sld.push_back(3 * (off[i + 1] - off[i]));
-          P.h_dst.push_back(F.F_off + 3LL * ri + 3LL * (p - F.c0) * ld);
+          P.h_dst.push_back(F.F_off + 3LL * (int)(it - pr) + 3LL * (p - F.c0) * ld);
           P.h_dld.push_back(ld);
         }
       }
     }
-    P.hent_off[l + 1] = (int)P.h_src.size();
+    B.hent_count = (int)P.h_src.size() - B.hent_off;
+    P.batches.push_back(B);
+  };
+  {
+    const int T = P.top_depth;
+    for (int f = nf - 1; f >= 0; f--) {
+      const int d = P.fronts[f].depth;
+      anc[f] = d <= T ? -1 : (d == T + 1 ? (T < 0 ? 0 : P.fronts[f].parent) : anc[P.fronts[f].parent]);
+    }
+    std::vector<std::vector<int>> by_depth((size_t)nl);
+    auto emit_levels_under = [&](int a, int upto) {  // the level batches of everything deeper than T under ancestor a
+      for (auto& v : by_depth) v.clear();
+      for (int f = 0; f < upto; f++)
+        if (P.fronts[f].depth > T && (T < 0 || anc[f] == a)) by_depth[P.fronts[f].depth].push_back(f);
+      for (int d = maxd; d > T; d--) emit(d, by_depth[d], d & 1, (d + 1) & 1, 0, 0);
+    };
+    if (T < 0) emit_levels_under(0, nf);
+    long long sp = 0;
+    std::vector<int> one;
+    for (int f = 0; f < nf; f++) {  // index order is a postorder of the top part
+      MfFront& F = P.fronts[f];
+      if (F.depth > T) continue;
+      if (F.depth == T) emit_levels_under(f, f);
+      long long base = sp;
+      if (F.depth < T)
+        for (int c : F.child)
+          if (c >= 0) base = std::min(base, P.fronts[c].cF_off);
+      one.assign(1, f);
+      emit(F.depth, one, 2, F.depth < T ? 3 : (F.depth + 1) & 1, 0, F.parent >= 0 ? 1 : 0);
+      F.cF_off = base;
+      F.c_ld = 3 * (F.nrows - (F.c1 - F.c0));
+      F.c_k0 = 0;
+      sp = base + (F.parent >= 0 ? usq[f] : 0);
+    }
   }
+  if (!entries_ok) return false;
+  long long lower = 0;
+  for (int i = 0; i < N; i++)
+    for (int u = off[i]; u < off[i + 1]; u++) lower += P.inv[cols[u]] >= P.inv[i];
+  if ((long long)P.h_src.size() != lower) return false;  // an entry did not find its front: not a symmetric pattern
   return true;
 }
 

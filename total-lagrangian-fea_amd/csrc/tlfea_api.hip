@@ -3592,12 +3592,13 @@ static int direct_prepare_native(tlfea_newton_t s, const std::vector<double>& X)
   std::vector<MfFrontDev> fr(P.fronts.size());
   for (size_t f = 0; f < P.fronts.size(); f++) {
     const MfFront& F = P.fronts[f];
-    fr[f] = MfFrontDev{F.F_off, F.L_off, F.v_off, F.map_off, F.row_off, 3 * F.nrows, 3 * (F.c1 - F.c0), F.c0,
-                       F.child[0], F.child[1], 0};
+    fr[f] = MfFrontDev{F.F_off, F.L_off, F.v_off, F.map_off, F.row_off, F.cF_off, 3 * F.nrows, 3 * (F.c1 - F.c0), F.c0,
+                       F.child[0], F.child[1], F.c_ld, F.c_k0, 0};
   }
   MfDev& D = m.dev;
   TRY(mf_upload(m, fr, &D.fr));
   TRY(mf_upload(m, P.level_fronts, &D.lvl));
+  TRY(mf_upload(m, P.batch_fronts, &D.blvl));
   TRY(mf_upload(m, P.map, &D.map));
   TRY(mf_upload(m, P.rows, &D.rows));
   TRY(mf_upload(m, P.order, &D.order));
@@ -3611,8 +3612,7 @@ static int direct_prepare_native(tlfea_newton_t s, const std::vector<double>& X)
     return 0;
   };
   TRY(dalloc(&D.L, P.L_total));
-  TRY(dalloc(&D.F[0], P.F_cap[0]));
-  TRY(dalloc(&D.F[1], P.F_cap[1]));
+  for (int t = 0; t < 4; t++) TRY(dalloc(&D.F[t], P.F_cap[t]));
   TRY(dalloc(&D.v, P.v_total));
   TRY(dalloc(&D.y, 3LL * N));
   TRY(dalloc(&D.xp, 3LL * N));
@@ -3622,9 +3622,9 @@ static int direct_prepare_native(tlfea_newton_t s, const std::vector<double>& X)
   m.ok = true;
   if (s->verbose || std::getenv("TLFEA_DIRECT_TRACE"))
     std::printf("sparse direct solve: %d DOF, %zu fronts in %d levels, factor %.3g doubles (%.1f x the lower triangle of H), "
-                "workspaces %.3g doubles, %.3g flop per factorisation\n",
+                "workspaces %.3g doubles (fronts down to depth %d one by one with a stack), %.3g flop per factorisation\n",
                 m.n, P.fronts.size(), P.n_levels(), (double)P.L_total, (double)P.L_total / (0.5 * s->h_nnz),
-                (double)(P.F_cap[0] + P.F_cap[1]), (double)P.flops);
+                (double)P.F_total(), P.top_depth, (double)P.flops);
   return 0;
 }
 

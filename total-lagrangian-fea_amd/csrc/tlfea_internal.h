@@ -292,15 +292,17 @@ void launch_lp_convert12(hipStream_t s, int N, const Incidence& inc, const doubl
 // ---- sparse direct solve (direct_kernels.hip on the plan of mf_host.h) ------------------------------------------------
 struct MfFrontDev {  // a front as the kernels see it (DOF units)
   long long F_off, L_off, v_off, map_off, rows_off;
-  int m, k, c0, child0, child1, pad;
+  long long cF_off;  // where its PARENT reads its update matrix (the front itself, or its compact copy on the stack) ...
+  int m, k, c0, child0, child1;
+  int c_ld, c_k0, pad;  // ... with this leading dimension and first row / column
 };
 struct MfDev {
   const MfFrontDev* fr;
-  const int *lvl, *map, *rows, *order;
+  const int *lvl, *blvl, *map, *rows, *order;  // lvl: fronts by level (solve), blvl: fronts by batch (factorisation)
   const long long *hsrc, *hdst;
   const int *hsld, *hdld;
   double* L;
-  double* F[2];
+  double* F[4];  // front workspaces: level buffers (depth parity), WORK, STACK (mf_host.h, MfBatch)
   double *v, *y, *xp;
   int* err;
 };
