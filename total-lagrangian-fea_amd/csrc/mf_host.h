@@ -106,26 +106,25 @@ inline bool mf_plan_build(int N, const int* off, const int* cols, const double* 
       P.fronts.push_back(f);
       return (int)P.fronts.size() - 1;
     }
-    int axis = 0;
-    double best = -1.0;
+    // the cut: the median plane of one coordinate axis, SNAPPED so that all nodes sharing the median coordinate (a plane of a
+    // structured mesh) go to one side -- a cut through the plane makes a staircase separator twice as large -- as long as the
+    // parts stay within 30 % / 70 %.  Axis: the longest extent; axes within 60 % of it are tried too and the one with the
+    // smallest separator wins (irregular bodies: the shortest cut is not always across the longest side).
+    double ext[3];
     for (int a = 0; a < 3; a++) {
       double lo = xyz[a][nodes[0]], hi = lo;
       for (int v : nodes) {
         lo = std::min(lo, xyz[a][v]);
         hi = std::max(hi, xyz[a][v]);
       }
-      if (hi - lo > best) {
-        best = hi - lo;
-        axis = a;
-      }
+      ext[a] = hi - lo;
     }
-    size_t half = nodes.size() / 2;
-    const double* c = xyz[axis];
-    std::nth_element(nodes.begin(), nodes.begin() + half, nodes.end(),
-                     [&](int a, int b) { return c[a] < c[b] || (c[a] == c[b] && a < b); });
-    {
-      // nodes that share the median coordinate (a plane of a structured mesh) go to ONE side -- a cut through the plane
-      // makes a staircase separator twice as large -- as long as the parts stay within 30 % / 70 %
+    const double emax = std::max(ext[0], std::max(ext[1], ext[2]));
+    auto cut_axis = [&](int axis) -> size_t {  // partitions `nodes` (left part first), returns the size of the left part
+      size_t half = nodes.size() / 2;
+      const double* c = xyz[axis];
+      std::nth_element(nodes.begin(), nodes.begin() + half, nodes.end(),
+                       [&](int a, int b) { return c[a] < c[b] || (c[a] == c[b] && a < b); });
       const double cv = c[nodes[half]];
       size_t nlt = 0, nle = 0;
       for (int v : nodes) {
@@ -141,7 +140,40 @@ inline bool mf_plan_build(int N, const int* off, const int* cols, const double* 
         std::partition(nodes.begin(), nodes.end(), [&](int v) { return strict ? c[v] < cv : c[v] <= cv; });
         half = pick;
       }
+      return half;
+    };
+    auto separator_size = [&](size_t half) {  // the smaller of the two one-sided vertex separators of the current partition
+      const int sl = stamp++, sr = stamp++;
+      for (size_t t = 0; t < nodes.size(); t++) mark[nodes[t]] = t < half ? sl : sr;
+      size_t nr = 0, nl_ = 0;
+      for (size_t t = 0; t < nodes.size(); t++) {
+        const int v = nodes[t], other = t < half ? sr : sl;
+        bool touches = false;
+        for (int k = off[v]; k < off[v + 1] && !touches; k++) touches = mark[cols[k]] == other;
+        if (touches) (t < half ? nl_ : nr)++;
+      }
+      return std::min(nr, nl_);
+    };
+    static const bool try_axes = !(std::getenv("TLFEA_DIRECT_AXES") && std::atoi(std::getenv("TLFEA_DIRECT_AXES")) == 1);
+    int axis = ext[0] >= ext[1] && ext[0] >= ext[2] ? 0 : (ext[1] >= ext[2] ? 1 : 2);
+    if (try_axes && nodes.size() <= 200000) {  // (larger parts: the planning time of a 4 M-DOF mesh stays a few seconds)
+      size_t best_sep = ~(size_t)0;
+      int best_axis = axis;
+      int cands = 0;
+      for (int a = 0; a < 3; a++) cands += ext[a] >= 0.6 * emax;
+      if (cands > 1) {
+        for (int a = 0; a < 3; a++) {
+          if (ext[a] < 0.6 * emax) continue;
+          const size_t sz = separator_size(cut_axis(a));
+          if (sz < best_sep || (sz == best_sep && a == axis)) {
+            best_sep = sz;
+            best_axis = a;
+          }
+        }
+        axis = best_axis;
+      }
     }
+    size_t half = cut_axis(axis);
     const int sl = stamp++, sr = stamp++;
     for (size_t t = 0; t < nodes.size(); t++) mark[nodes[t]] = t < half ? sl : sr;
     // vertex separator: the nodes of one part that touch the other part -- whichever side gives the smaller set
