@@ -4,7 +4,9 @@
 //
 // Multifrontal Cholesky on the NODE graph (3x3 blocks stay together):
 //   ordering : nested dissection by recursive coordinate bisection -- the mesh's reference coordinates give the cut
-//              planes, the graph gives the vertex separators.  The dissection tree IS the assembly tree: every leaf set
+//              planes (snapped to coordinate planes of structured meshes; the axis with the smallest separator among the
+//              near-longest ones), the graph gives the vertex separators (from the smaller side of the cut).
+//              The dissection tree IS the assembly tree: every leaf set
 //              and every separator is one FRONT whose own nodes are contiguous in the new order (left subtree, right
 //              subtree, separator), so children sit exactly one level below their parent and a level's fronts are
 //              independent: the device works level by level, deepest first, all fronts of a level in one launch.
@@ -13,7 +15,8 @@
 //              update matrix U = F22 - L21 L21^T in place, which the parent adds into its own front through `map`
 //              (extend-add, child 0 then child 1: fixed order, no atomics, bitwise reproducible).
 //   storage  : L panels (3 rows x 3 own nodes, column-major) for the whole tree; front workspaces for two adjacent
-//              levels (a level reads its children's U from the other buffer); 64-bit offsets throughout.
+//              levels (a level reads its children's U from the other buffer) -- or, where whole levels do not fit, the top
+//              of the tree front by front with a stack of update matrices (MfBatch); 64-bit offsets throughout.
 // Integer work only.
 #pragma once
 #include <algorithm>
