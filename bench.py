@@ -304,7 +304,7 @@ def main():
             v["traffic_note"] = (f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, {pmc_file}): (2*FETCH_SIZE + "
                                  "WRITE_SIZE)*1024 B per launch; FETCH_SIZE counts 64 B per 128-B request on gfx950, calibrated "
                                  "for this engine's 8-/16-byte and scattered-row loads with tools/microbench/pmc_calib.hip")
-    if pmg:
+    if pmg and "cheb_step" in roof_all and "cheb_step_coarse" in roof_all:   # (absent with --linsolve-method 1)
         roof_all["cheb_step"]["note"] = ("fine level of the V-cycle, non-final instantiation: 3 launches per CG iteration "
                                          "(the 4th fine pass is the final instantiation, same stream, not in `launches`)")
         roof_all["cheb_step_coarse"]["note"] = ("coarse level of the V-cycle: 74 MB per launch, resident in the 256 MB Infinity "
@@ -314,6 +314,9 @@ def main():
     # HBM-roofline candidate)
     dominant = max((k for k in roof_all if k != "cheb_step_coarse"), key=lambda k: roof_all[k]["total_ms"])
     roofline = dict(roof_all[dominant], kernel=dominant)
+    if args.linsolve_method == 1:
+        roofline["note"] = ("--linsolve-method 1: the step is the multifrontal factorisation (fp64 FMA bound, see `linear_solver`); the "
+                            "kernel priced here is the largest of the HBM-bound launches that remain")
     elem_keys = ("residual", "grad", fkey) if fused else ("residual", "grad", "tangent_blocks", "assemble_rows")
     elem_ms = sum(st[k][0] for k in elem_keys) / nprof
     b_alg = 4 * d.S + 24 * d.S * d.Q + 8 * d.Q + 24 * d.S + 72.0 * nnz_coef / E + 24.0 * N / E
