@@ -43,6 +43,8 @@ def test_dndu_pre_and_connectivity(mesh):
     m = MATERIALS["svk"]
     o, d = make_oracle(X, conn, m), make_gpu(X, conn, m)
     assert np.array_equal(d.RetrieveConnectivityToCPU(), conn)
+    lib = tl.load_library()                                       # the size getters of the handle (ElementBase::get_n_*)
+    assert lib.tlfea_t10_get_n_elem(d._h) == conn.shape[0] and lib.tlfea_t10_get_n_coef(d._h) == X.shape[0]
     assert relerr(d.RetrieveDetJToCPU(), o.detJ) < 1e-13
     assert relerr(d.RetrieveDnDuPreToCPU(), o.gradN_a_d()) < 1e-12
     d.Destroy()
